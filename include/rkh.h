@@ -1,0 +1,152 @@
+/* rkh.h -- C-ABI of the MI355X-native planning hot path (librkh.so).
+ *
+ * ReaK itself has no FFI for this path: the hot path sits behind C++ template concepts
+ * (SURVEY.md 8(b)).  These entry points are what a ReaK-side adaptor binds (INTEGRATION.md shows
+ * the C++ classes modelling ReaK's NNFinder / Steerable C_free / planner concepts on top of them).
+ * Each function names the reference interface it replaces (paths relative to
+ * /root/reference/src/ReaK/).
+ *
+ * Conventions: every function returns an rkh_status (0 = ok, negative = error); no exception
+ * crosses the boundary; the caller owns every host buffer; one host thread per rkh_ctx; calls are
+ * synchronous (they return after the device work finished) unless named *_async.
+ * Pointers named d_* are device (HBM) pointers, all others are host pointers.
+ */
+#ifndef RKH_H
+#define RKH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rkh_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rkh_status {
+  RKH_OK = 0,
+  RKH_ERR_BAD_ARG = -1,     /* std::range_error in the reference (kte_nl_system.hpp:181-188) */
+  RKH_ERR_OOM = -2,
+  RKH_ERR_SINGULAR = -3,    /* singularity_error (mat_cholesky.hpp:80-82, manip_dynamics_model.cpp:206-214) */
+  RKH_ERR_DEVICE = -4,      /* HIP runtime error; rkh_last_error() has the text */
+  RKH_ERR_UNSUPPORTED = -5, /* KTE program / shape not covered by the HIP kernels */
+  RKH_ERR_CAPACITY = -6
+} rkh_status;
+
+typedef struct rkh_ctx rkh_ctx;         /* one device + stream */
+typedef struct rkh_nn rkh_nn;           /* device-resident vertex set for NN queries */
+typedef struct rkh_scene rkh_scene;     /* KTE chain + proxy environment on the device */
+typedef struct rkh_planner rkh_planner; /* batched RRT driver over a scene */
+
+const char* rkh_last_error(void);
+const char* rkh_version(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+rkh_status rkh_ctx_create(int device, rkh_ctx** out);
+rkh_status rkh_ctx_destroy(rkh_ctx* ctx);
+rkh_status rkh_ctx_synchronize(rkh_ctx* ctx);
+/* hipStream_t of the context as void* (bench.py brackets launches with HIP events on it). */
+void* rkh_ctx_stream(rkh_ctx* ctx);
+
+/* ---- nearest neighbours -------------------------------------------------------------------
+ * Replaces linear_neighbor_search<Graph> (ctrl/path_planning/topological_search.hpp:529-690):
+ *   rkh_nn_query1  = min_dist_linear_search 1-NN            (topological_search.hpp:95-118)
+ *   rkh_nn_queryk  = min_dist_linear_search k-NN + radius   (topological_search.hpp:244-274)
+ * and any_knn_synchro::added_vertex (ctrl/path_planning/any_knn_synchro.hpp:69-76) = rkh_nn_append.
+ * Distance is euclidean_distance_metric (ctrl/topologies/vect_distance_metrics.hpp:113-150),
+ * evaluated in the reference's fp64 operation order; results are bit-identical to the CPU search,
+ * including "first minimum wins" on ties.  Vertex ids are insertion indices. */
+rkh_status rkh_nn_create(rkh_ctx* ctx, int dims, uint64_t capacity, rkh_nn** out);
+rkh_status rkh_nn_destroy(rkh_nn* nn);
+rkh_status rkh_nn_clear(rkh_nn* nn);
+uint64_t rkh_nn_size(const rkh_nn* nn);
+/* pts: n points, row-major [n][dims] */
+rkh_status rkh_nn_append(rkh_nn* nn, const double* pts, uint64_t n);
+/* q: [B][dims]; idx[B] (0xFFFFFFFF if the set is empty), dist[B] */
+rkh_status rkh_nn_query1(rkh_nn* nn, const double* q, uint32_t B, uint32_t* idx, double* dist);
+/* k-NN with radius: idx/dist are [B][k], nearest first, padded with 0xFFFFFFFF / +inf; count[B].
+ * Among exactly equal distances the reference's order is std::heap-defined; this returns
+ * ascending (distance, index). */
+rkh_status rkh_nn_queryk(rkh_nn* nn, const double* q, uint32_t B, uint32_t k, double radius, uint32_t* idx,
+                         double* dist, uint32_t* count);
+/* Device-pointer variants for callers that keep queries / results in HBM (bench, planner).
+ * d_q: [B][dims] row-major in HBM; d_idx[B]; d_dist[B]. Asynchronous on the context stream. */
+rkh_status rkh_nn_query1_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32_t* d_idx, double* d_dist);
+rkh_status rkh_nn_queryk_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32_t k, double radius,
+                               uint32_t* d_idx, double* d_dist, uint32_t* d_count);
+/* Fill the set with n uniform points of the unit hypercube directly on the device (synthetic
+ * trees for the sweep microbenchmark); deterministic in seed. */
+rkh_status rkh_nn_fill_uniform(rkh_nn* nn, uint64_t n, uint64_t seed);
+/* Name and grid of the sweep kernel the last query launched (for profile bookkeeping). */
+const char* rkh_nn_kernel_name(void);
+
+/* ---- scene: KTE chain + proximity environment ----------------------------------------------
+ * rkh_scene_create flattens what the reference holds as kte_map_chain + mass_matrix_calc
+ * (ctrl/mbd_kte/kte_map_chain.hpp, mass_matrix_calculator.cpp) and one proxy_query_pair_3D
+ * (robot model = shapes with anchor >= 0, environment model = anchor -1;
+ * geometry/proximity/proxy_query_model.cpp:215-402).  The HIP kernels cover serial chains of
+ * {driving_actuator_gen, inertia_gen, revolute_joint_3D, rigid_link_3D, inertia_3D} groups
+ * (the pattern of examples/robot_airship/old/CRS_A465_models.cpp:751-785); anything else returns
+ * RKH_ERR_UNSUPPORTED. */
+rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, const rkh_chain_base* base,
+                            const rkh_shape* shapes, int n_shapes, rkh_scene** out);
+rkh_status rkh_scene_destroy(rkh_scene* scene);
+int rkh_scene_num_dof(const rkh_scene* scene);
+int rkh_scene_num_pairs(const rkh_scene* scene);
+
+/* kte_nl_system::get_state_derivative (ctrl/ctrl_sys/kte_nl_system.hpp:239-290) for B (x,u) pairs:
+ * x [B][2n] interleaved (q,qd), u [B][n]; pd [B][2n]; optional M [B][n][n], f [B][n].
+ * Returns RKH_ERR_SINGULAR if any mass matrix pivot < 1e-8 (singularity_error). */
+rkh_status rkh_state_derivative(rkh_scene* scene, const double* x, const double* u, uint32_t B, double* pd,
+                                double* M, double* f);
+/* manip_dk_proxy_env_impl::is_free's distance (ctrl/topologies/manip_free_workspace.hpp:79-99):
+ * minimum proxy-pair distance for B states (apply_to_model + findMinimumDistance). */
+rkh_status rkh_min_distance(rkh_scene* scene, const double* x, uint32_t B, double* dist);
+/* steer_position_toward of the steerable dynamic free space (rkh_dyn_space) for B (a,b) pairs:
+ * x_out [B][2n] last collision-free state, steps_free[B] accepted RK4 steps, record (optional)
+ * [B][steps_per_edge+1][2n] the steer record. RK4 = runge_kutta4_integrate_impl
+ * (ctrl/sys_integrators/runge_kutta4_integrator_sys.hpp:53-97). */
+rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const double* a, const double* b,
+                         uint32_t B, double fraction, double* x_out, uint32_t* steps_free, double* record);
+/* Quasi-static edge walk interp_topo_move_position_toward_pred
+ * (ctrl/interpolation/interpolated_topologies.hpp:137-163) over joint positions, for B (a,b) pairs:
+ * lower/upper [n] joint box, out [B][n] last free point, n_checked[B] is_free calls made. */
+rkh_status rkh_edge_check(rkh_scene* scene, const double* lower, const double* upper, double min_interval,
+                          const double* a, const double* b, uint32_t B, double fraction, double* out,
+                          uint32_t* n_checked);
+
+/* ---- planner: rrt_planner::solve_planning_query (LINEAR_SEARCH_KNN, UNIDIRECTIONAL) ----------
+ * (ctrl/path_planning/rrt_path_planner.tpp:66-145 -> generate_rrt, ctrl/graph_alg/rr_tree.hpp:179-199)
+ * over the steerable dynamic space.  Expansion is speculative in batches but commits vertices in
+ * exactly the order of the sequential algorithm, so vertex ids, parents and sample consumption
+ * equal the CPU planner's on the same seed. */
+typedef struct rkh_planner_stats {
+  uint64_t num_vertices;   /* num_vertices(g), root included */
+  uint64_t iterations;     /* samples consumed = generate_rrt loop iterations */
+  uint64_t edges_checked;  /* steer_towards_position + goal probes committed */
+  uint64_t edges_speculated; /* propagate kernel edges launched (incl. discarded speculation) */
+  uint64_t rounds;         /* speculative batches */
+  uint64_t num_solutions;
+  double best_cost;
+  uint32_t done;
+} rkh_planner_stats;
+
+rkh_status rkh_planner_create(rkh_scene* scene, const rkh_dyn_space* space, const rkh_rrt_params* prm,
+                              rkh_planner** out);
+rkh_status rkh_planner_destroy(rkh_planner* p);
+/* Enqueue `rounds` speculative batches on the planner's stream (no host sync). */
+rkh_status rkh_planner_enqueue(rkh_planner* p, uint32_t rounds);
+/* Wait for the enqueued batches and refresh stats; *done is set once keep_going() turned false. */
+rkh_status rkh_planner_sync(rkh_planner* p, rkh_planner_stats* stats);
+/* Run to completion (keep_going() false): enqueue + sync until done. */
+rkh_status rkh_planner_solve(rkh_planner* p, rkh_planner_stats* stats);
+/* Copy the motion graph out: pos [num_vertices][2n], parent[num_vertices] (root 0xFFFFFFFF),
+ * nn_seq[iterations], accept[iterations], goal_dist[num_vertices-1].  Any pointer may be NULL. */
+rkh_status rkh_planner_get_tree(rkh_planner* p, double* pos, uint32_t* parent, uint32_t* nn_seq, uint8_t* accept,
+                                double* goal_dist);
+void* rkh_planner_stream(rkh_planner* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

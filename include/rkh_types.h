@@ -1,0 +1,100 @@
+/* rkh_types.h -- plain-old-data scene description shared across the C-ABI boundary.
+ *
+ * Everything here is a flat C struct (no pointers to C++ objects) so that a
+ * ReaK-side adaptor can flatten its shared_ptr object graph once and hand it over.
+ * Each struct names the ReaK class whose *state* it carries (paths relative to
+ * /root/reference/src/ReaK/).
+ */
+#ifndef RKH_TYPES_H
+#define RKH_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RKH_MAX_DOF 16
+#define RKH_MAX_STATE (2 * RKH_MAX_DOF)
+
+/* pose_3D<double> (core/kinetostatics/pose_3D.hpp): Position + Quat (w,x,y,z). Parent is implicit. */
+typedef struct rkh_pose {
+  double pos[3];
+  double quat[4];
+} rkh_pose;
+
+/* KTE op-codes: one entry of kte_map_chain::mKTEs (ctrl/mbd_kte/kte_map_chain.hpp:49-112).
+ * doMotion runs the ops in order, doForce in reverse order (kte_map_chain.hpp:71-83). */
+enum rkh_kte_kind {
+  RKH_KTE_DRIVING_ACTUATOR_GEN = 1, /* ctrl/mbd_kte/driving_actuator.cpp:31-39  : coord, joint_op            */
+  RKH_KTE_INERTIA_GEN = 2,          /* ctrl/mbd_kte/inertia.cpp:47-54           : coord, mass                */
+  RKH_KTE_REVOLUTE_JOINT_3D = 3,    /* ctrl/mbd_kte/revolute_joint.cpp:121-213  : coord, axis, base, end     */
+  RKH_KTE_RIGID_LINK_3D = 4,        /* ctrl/mbd_kte/rigid_link.cpp:152-186      : base, end, pose offset     */
+  RKH_KTE_INERTIA_3D = 5            /* ctrl/mbd_kte/inertia.cpp:111-122         : frame(end), mass, tensor   */
+};
+
+typedef struct rkh_kte_op {
+  int32_t kind;        /* rkh_kte_kind */
+  int32_t coord;       /* generalized coordinate index (gen_coord), or -1 */
+  int32_t base_frame;  /* frame index (frame_3D), or -1 */
+  int32_t end_frame;   /* frame index (frame_3D), or -1 */
+  int32_t joint_op;    /* DRIVING_ACTUATOR_GEN: index of the joint op receiving applyReactionForce */
+  uint32_t upstream;   /* INERTIA_*: bitmask of coords in mUpStreamJoints (jacobian_joint_map.hpp) */
+  double axis[3];      /* REVOLUTE_JOINT_3D: mAxis */
+  rkh_pose offset;     /* RIGID_LINK_3D: mPoseOffset */
+  double mass;         /* INERTIA_GEN / INERTIA_3D: mMass */
+  double inertia[6];   /* INERTIA_3D: mInertiaTensor, symmetric (a11,a12,a13,a22,a23,a33) */
+} rkh_kte_op;
+
+/* Base frame of the chain (frame index 0). Gravity enters as base Acceleration
+ * (ctrl/mbd_kte/test_bm.cpp:52). The base frame has no Parent (global). */
+typedef struct rkh_chain_base {
+  rkh_pose pose;
+  double acceleration[3];
+} rkh_chain_base;
+
+/* shape_3D subclasses (geometry/shapes/{sphere,box,capped_cylinder}.hpp) with their geometry_3D
+ * anchor + pose (geometry/shapes/geometry_3D.cpp:32-51). */
+enum rkh_shape_kind {
+  RKH_SHAPE_SPHERE = 1,    /* dims[0] = radius                              */
+  RKH_SHAPE_BOX = 2,       /* dims[0..2] = full side lengths (mDimensions)  */
+  RKH_SHAPE_CCYLINDER = 3  /* dims[0] = length, dims[1] = radius (capped_cylinder, axis = local z) */
+};
+
+typedef struct rkh_shape {
+  int32_t kind;    /* rkh_shape_kind */
+  int32_t anchor;  /* frame index of the KTE chain the shape is anchored to, -1 = world (no anchor) */
+  rkh_pose pose;   /* mPose relative to the anchor */
+  double dims[3];
+} rkh_shape;
+
+/* Steerable dynamic free space over a KTE chain ("kte_dynamic_free_space").  There is no verbatim
+ * reference class; the loop shape restates examples/misc/MEAQR_topology.hpp:503-565 with a PD law
+ * held constant over each RK4 step (ctrl/interpolation/constant_trajectory.hpp:138-150).
+ * State layout is kte_nl_system's: x = (q0, qd0, q1, qd1, ...) (ctrl/ctrl_sys/kte_nl_system.hpp:190-193). */
+typedef struct rkh_dyn_space {
+  int32_t n_dof;
+  int32_t steps_per_edge; /* RK4 steps of one full steer (fraction 1.0) */
+  double dt;              /* RK4 step (one runge_kutta4_integrate_impl call per step) */
+  double kp, kd, u_max;   /* u_i = clamp(kp (q*_i - q_i) + kd (qd*_i - qd_i), +-u_max) */
+  double goal_tol;        /* steering stops once distance(x, target) <= goal_tol */
+  double lower[RKH_MAX_STATE]; /* hyperbox_topology lower_corner (interleaved q, qd) */
+  double upper[RKH_MAX_STATE]; /* hyperbox_topology upper_corner */
+} rkh_dyn_space;
+
+/* sample_based_planner options (ctrl/path_planning/motion_planner_base.hpp:400-422) and the
+ * point-to-point query (ctrl/path_planning/p2p_planning_query.hpp:74-229). */
+typedef struct rkh_rrt_params {
+  uint32_t seed;            /* get_global_rng().seed(seed) */
+  uint32_t max_vertices;    /* m_max_vertex_count */
+  uint32_t max_results;     /* path_planning_p2p_query::max_num_results */
+  double steer_tol;         /* m_steer_progress_tolerance (default 0.1) */
+  double conn_tol;          /* m_connection_tolerance (default 0.05) */
+  double start[RKH_MAX_STATE];
+  double goal[RKH_MAX_STATE];
+} rkh_rrt_params;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

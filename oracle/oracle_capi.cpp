@@ -1,0 +1,332 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see reak_math.hpp header).
+// Flat C entry points over the restatement so tests/ and bench.py's cpu_baseline leg can drive it
+// through ctypes.  Built by oracle/Makefile into oracle/liboracle.so (git-ignored).
+#include <chrono>
+#include <cstring>
+#include <random>
+
+#include "reak_kte.hpp"
+#include "reak_math.hpp"
+#include "reak_planning.hpp"
+#include "reak_proximity.hpp"
+
+using namespace oracle;
+
+namespace {
+struct Scene {
+  KteChain chain;
+  ProxyEnv env;
+};
+Quat mkq(const double* q) { return Quat(q[0], q[1], q[2], q[3]); }
+}  // namespace
+
+extern "C" {
+
+// ---- RNG / sampling
+uint32_t orc_mt19937_nth(uint32_t seed, uint32_t n) {
+  std::mt19937 e(seed);
+  uint32_t v = 0;
+  for (uint32_t i = 0; i < n; ++i) v = uint32_t(e());
+  return v;
+}
+void orc_sample_hyperbox(uint32_t seed, const double* lower, const double* upper, int D, int n, double* out) {
+  GlobalRng rng(seed);
+  for (int i = 0; i < n; ++i) {
+    Point p = hyperbox_random_point(rng, lower, upper, D);
+    std::memcpy(out + std::size_t(i) * D, p.data(), sizeof(double) * D);
+  }
+}
+
+// ---- metric / NN
+double orc_euclid(const double* a, const double* b, int D) { return euclid(a, b, D); }
+void orc_nn1(const double* q, int B, const double* pts, uint64_t n, int D, uint32_t* idx, double* dist) {
+  for (int b = 0; b < B; ++b) {
+    double d = std::numeric_limits<double>::infinity();
+    std::size_t r = linear_nn(q + std::size_t(b) * D, pts, n, D, &d);
+    idx[b] = uint32_t(r);
+    dist[b] = d;
+  }
+}
+// out idx/dist are [B][k] padded with 0xFFFFFFFF / +inf; count[b] = number found
+void orc_knn(const double* q, int B, const double* pts, uint64_t n, int D, uint32_t k, double radius,
+             uint32_t* idx, double* dist, uint32_t* count) {
+  std::vector<std::pair<double, std::size_t>> out;
+  for (int b = 0; b < B; ++b) {
+    linear_knn(q + std::size_t(b) * D, pts, n, D, k, radius, out);
+    count[b] = uint32_t(out.size());
+    for (uint32_t j = 0; j < k; ++j) {
+      idx[std::size_t(b) * k + j] = j < out.size() ? uint32_t(out[j].second) : 0xFFFFFFFFu;
+      dist[std::size_t(b) * k + j] = j < out.size() ? out[j].first : std::numeric_limits<double>::infinity();
+    }
+  }
+}
+void orc_star_neighborhood(uint64_t N, double dims, double gamma, uint64_t* k, double* radius) {
+  std::size_t kk;
+  star_neighborhood(N, dims, gamma, &kk, radius);
+  *k = kk;
+}
+uint64_t orc_highest_set_bit(uint64_t N) { return highest_set_bit(N); }
+
+// ---- leaf math (known-answer tests)
+void orc_quat_mul(const double* a, const double* b, double* out) {
+  Quat r = mkq(a) * mkq(b);
+  std::memcpy(out, r.q, 4 * sizeof(double));
+}
+void orc_quat_rotmat(const double* a, double* out9_rowmajor) {
+  RotMat R = mkq(a).getRotMat();
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) out9_rowmajor[i * 3 + j] = R.q[j * 3 + i];
+}
+void orc_quat_rotate(const double* a, const double* v, double* out) {
+  V3 r = mkq(a) * V3(v[0], v[1], v[2]);
+  std::memcpy(out, r.q, 3 * sizeof(double));
+}
+void orc_quat_from_vector(const double* v4, double* out) {
+  Quat r = Quat::from_vector(v4[0], v4[1], v4[2], v4[3]);
+  std::memcpy(out, r.q, 4 * sizeof(double));
+}
+void orc_axis_angle_quat(double angle, const double* axis, double* out) {
+  Quat r = AxisAngle(angle, V3(axis[0], axis[1], axis[2])).getQuaternion();
+  std::memcpy(out, r.q, 4 * sizeof(double));
+}
+void orc_axis_angle_rotmat(double angle, const double* axis, double* out9_rowmajor) {
+  RotMat R = AxisAngle(angle, V3(axis[0], axis[1], axis[2])).getRotMat();
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) out9_rowmajor[i * 3 + j] = R.q[j * 3 + i];
+}
+// returns 0 ok, -3 singular
+int orc_cholesky_solve(const double* A, double* b, int N, double tol) {
+  try {
+    linsolve_Cholesky(A, b, N, tol);
+  } catch (const singularity_error&) {
+    return -3;
+  }
+  return 0;
+}
+int orc_cholesky_decompose(const double* A, double* L, int N, double tol) {
+  try {
+    for (int i = 0; i < N * N; ++i) L[i] = 0.0;
+    decompose_Cholesky(A, L, N, tol);
+  } catch (const singularity_error&) {
+    return -3;
+  }
+  return 0;
+}
+// RK4 (runge_kutta4_integrate_impl arithmetic) on small initial-value problems (known-answer tests):
+//  problem 0: x' = -x                  (exact e^-t)
+//  problem 1: harmonic oscillator x'' = -x (exact cos/sin)
+//  problem 2: HIRES, 8 states, the reference's own IVP with a literature end value at t = 321.8122
+//             (core/integrators/unit_test_integrators_problems.hpp:53-97)
+int orc_rk4_ivp(int problem, const double* x0, int D, double t0, double t1, double h, double* x1) {
+  auto f = [&](const double* p, const double*, double* pd) {
+    switch (problem) {
+      case 0: pd[0] = -p[0]; break;
+      case 1: pd[0] = p[1]; pd[1] = -p[0]; break;
+      case 2:
+        pd[0] = -1.71 * p[0] + 0.43 * p[1] + 8.32 * p[2] + 0.0007;
+        pd[1] = 1.71 * p[0] - 8.75 * p[1];
+        pd[2] = -10.03 * p[2] + 0.43 * p[3] + 0.035 * p[4];
+        pd[3] = 8.32 * p[1] + 1.71 * p[2] - 1.12 * p[3];
+        pd[4] = -1.745 * p[4] + 0.43 * p[5] + 0.43 * p[6];
+        pd[5] = -280.0 * p[5] * p[7] + 0.69 * p[3] + 1.71 * p[4] - 0.43 * p[5] + 0.69 * p[6];
+        pd[6] = 280.0 * p[5] * p[7] - 1.81 * p[6];
+        pd[7] = -280.0 * p[5] * p[7] + 1.81 * p[6];
+        break;
+    }
+  };
+  double u = 0.0;
+  return runge_kutta4_integrate(f, D, x0, x1, &u, t0, t1, h);
+}
+
+// ---- scenes
+void* orc_scene_create(const rkh_kte_op* ops, int n_ops, const rkh_chain_base* base, const rkh_shape* shapes,
+                       int n_shapes) {
+  Scene* s = new Scene();
+  s->chain = KteChain(ops, n_ops, *base);
+  s->env = ProxyEnv(shapes, n_shapes);
+  return s;
+}
+void orc_scene_destroy(void* h) { delete static_cast<Scene*>(h); }
+int orc_scene_num_frames(void* h) { return static_cast<Scene*>(h)->chain.n_frames; }
+int orc_scene_num_finders(void* h) { return int(static_cast<Scene*>(h)->env.finders.size()); }
+
+// x' = f(x,u) for B states. pd [B][2n]; M [B][n][n] and f [B][n] optional. returns 0 / -3
+int orc_state_derivative(void* h, const double* x, const double* u, int B, double* pd, double* M, double* f) {
+  Scene* s = static_cast<Scene*>(h);
+  const int n = s->chain.n_coords;
+  try {
+    for (int b = 0; b < B; ++b)
+      s->chain.get_state_derivative(x + std::size_t(b) * 2 * n, u + std::size_t(b) * n, pd + std::size_t(b) * 2 * n,
+                                    M ? M + std::size_t(b) * n * n : nullptr, f ? f + std::size_t(b) * n : nullptr);
+  } catch (const singularity_error&) {
+    return -3;
+  }
+  return 0;
+}
+// forward kinematics: frames out [B][n_frames][7] (pos, quat)
+void orc_fk(void* h, const double* x, int B, double* frames) {
+  Scene* s = static_cast<Scene*>(h);
+  const int n = s->chain.n_coords, nf = s->chain.n_frames;
+  for (int b = 0; b < B; ++b) {
+    s->chain.apply_kinematics(x + std::size_t(b) * 2 * n);
+    for (int k = 0; k < nf; ++k) {
+      double* o = frames + (std::size_t(b) * nf + k) * 7;
+      for (int i = 0; i < 3; ++i) o[i] = s->chain.frames[k].Position[i];
+      for (int i = 0; i < 4; ++i) o[3 + i] = s->chain.frames[k].Q.q[i];
+    }
+  }
+}
+// min distance over the proxy pair list for B states (full state layout x = (q, qd) interleaved)
+void orc_min_distance(void* h, const double* x, int B, double* d) {
+  Scene* s = static_cast<Scene*>(h);
+  const int n = s->chain.n_coords;
+  for (int b = 0; b < B; ++b) {
+    s->chain.apply_kinematics(x + std::size_t(b) * 2 * n);
+    d[b] = s->env.min_distance(s->chain);
+  }
+}
+// one closed-form pair, both shapes world-anchored
+double orc_pair_distance(const rkh_shape* a, const rkh_shape* b) {
+  std::vector<rkh_shape> sh = {*a, *b};
+  sh[0].anchor = 0;  // model 1
+  sh[1].anchor = -1; // model 2
+  std::vector<ProxFinder> f;
+  createProxFinderList(sh, {0}, {1}, f);
+  if (f.empty()) return std::numeric_limits<double>::quiet_NaN();
+  std::vector<ShapeG> g(2);
+  for (int i = 0; i < 2; ++i) {
+    g[i].kind = sh[i].kind;
+    g[i].g = to_pose(sh[i].pose);
+    for (int k = 0; k < 3; ++k) g[i].dims[k] = sh[i].dims[k];
+  }
+  return computeProximity(f[0], g).mDistance;
+}
+
+static DynSpace make_dyn(Scene* s, const rkh_dyn_space* P) {
+  DynSpace sp;
+  sp.P = *P;
+  sp.D = 2 * P->n_dof;
+  sp.chain = s->chain;
+  sp.env = s->env;
+  return sp;
+}
+// one RK4 step for B (x,u) pairs
+int orc_rk4_step(void* h, const rkh_dyn_space* P, const double* x, const double* u, int B, double t, double* x_next) {
+  Scene* s = static_cast<Scene*>(h);
+  DynSpace sp = make_dyn(s, P);
+  const int D = sp.D;
+  try {
+    for (int b = 0; b < B; ++b) {
+      Point xi(x + std::size_t(b) * D, x + std::size_t(b + 1) * D), xn;
+      sp.rk4_step(xi, u + std::size_t(b) * P->n_dof, t, xn);
+      std::memcpy(x_next + std::size_t(b) * D, xn.data(), sizeof(double) * D);
+    }
+  } catch (const singularity_error&) {
+    return -3;
+  }
+  return 0;
+}
+// steer_position_toward for B (a,b) pairs. record (optional) [B][steps_per_edge+1][D]
+int orc_steer(void* h, const rkh_dyn_space* P, const double* a, const double* b, int B, double fraction,
+              double* x_out, uint32_t* steps_free, double* record) {
+  Scene* s = static_cast<Scene*>(h);
+  DynSpace sp = make_dyn(s, P);
+  const int D = sp.D;
+  try {
+    for (int i = 0; i < B; ++i) {
+      Point ai(a + std::size_t(i) * D, a + std::size_t(i + 1) * D), bi(b + std::size_t(i) * D, b + std::size_t(i + 1) * D);
+      int nf = 0;
+      std::vector<Point> rec;
+      Point r = sp.steer_position_toward(ai, fraction, bi, &nf, record ? &rec : nullptr);
+      std::memcpy(x_out + std::size_t(i) * D, r.data(), sizeof(double) * D);
+      steps_free[i] = uint32_t(nf);
+      if (record) {
+        double* ro = record + std::size_t(i) * (P->steps_per_edge + 1) * D;
+        for (std::size_t k = 0; k < rec.size() && k < std::size_t(P->steps_per_edge + 1); ++k)
+          std::memcpy(ro + k * D, rec[k].data(), sizeof(double) * D);
+      }
+    }
+  } catch (const singularity_error&) {
+    return -3;
+  }
+  return 0;
+}
+
+struct OrcRrtOut {
+  uint64_t num_vertices, iterations, num_solutions, edges_checked, states_checked, f_evals, pair_tests;
+  double best_cost;
+  double seconds;
+};
+static RrtResult g_last;  // kept so the caller can copy arrays out after the run
+
+static void fill_out(const RrtResult& r, long pair_tests, double secs, OrcRrtOut* out) {
+  out->num_vertices = r.parent.size();
+  out->iterations = r.iterations;
+  out->num_solutions = r.num_solutions;
+  out->edges_checked = r.cnt.edges_checked;
+  out->states_checked = r.cnt.states_checked;
+  out->f_evals = r.cnt.f_evals;
+  out->pair_tests = pair_tests;
+  out->best_cost = r.best_cost;
+  out->seconds = secs;
+}
+// RRT over the steerable dynamic space
+int orc_rrt_dyn(void* h, const rkh_dyn_space* P, const rkh_rrt_params* prm, int64_t max_iterations, OrcRrtOut* out) {
+  Scene* s = static_cast<Scene*>(h);
+  DynSpace sp = make_dyn(s, P);
+  auto t0 = std::chrono::steady_clock::now();
+  try {
+    generate_rrt(sp, *prm, long(max_iterations), g_last);
+  } catch (const singularity_error&) {
+    return -3;
+  }
+  double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  fill_out(g_last, sp.env.n_pair_tests, secs, out);
+  return 0;
+}
+// RRT over the quasi-static joint space (positions only, D = n_dof)
+int orc_rrt_qs(void* h, int D, const double* lower, const double* upper, double min_interval,
+               const rkh_rrt_params* prm, int64_t max_iterations, OrcRrtOut* out) {
+  Scene* s = static_cast<Scene*>(h);
+  QuasiStaticSpace sp;
+  sp.D = D;
+  sp.lower.assign(lower, lower + D);
+  sp.upper.assign(upper, upper + D);
+  sp.min_interval = min_interval;
+  sp.chain = s->chain;
+  sp.env = s->env;
+  auto t0 = std::chrono::steady_clock::now();
+  generate_rrt(sp, *prm, long(max_iterations), g_last);
+  double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  fill_out(g_last, sp.env.n_pair_tests, secs, out);
+  return 0;
+}
+// quasi-static edge walk for B (a,b) pairs: end point + number of free interpolation states
+void orc_qs_move(void* h, int D, const double* lower, const double* upper, double min_interval, const double* a,
+                 const double* b, int B, double fraction, double* out, uint32_t* n_checked) {
+  Scene* s = static_cast<Scene*>(h);
+  QuasiStaticSpace sp;
+  sp.D = D;
+  sp.lower.assign(lower, lower + D);
+  sp.upper.assign(upper, upper + D);
+  sp.min_interval = min_interval;
+  sp.chain = s->chain;
+  sp.env = s->env;
+  for (int i = 0; i < B; ++i) {
+    Point ai(a + std::size_t(i) * D, a + std::size_t(i + 1) * D), bi(b + std::size_t(i) * D, b + std::size_t(i + 1) * D);
+    long before = sp.cnt.states_checked;
+    Point r = sp.move_position_toward(ai, fraction, bi);
+    std::memcpy(out + std::size_t(i) * D, r.data(), sizeof(double) * D);
+    n_checked[i] = uint32_t(sp.cnt.states_checked - before);
+  }
+}
+// copy the arrays of the last RRT run
+void orc_rrt_copy(double* pos, uint32_t* parent, uint32_t* nn_seq, uint8_t* accept, double* goal_dist) {
+  if (pos) std::memcpy(pos, g_last.pos.data(), g_last.pos.size() * sizeof(double));
+  if (parent) std::memcpy(parent, g_last.parent.data(), g_last.parent.size() * sizeof(uint32_t));
+  if (nn_seq) std::memcpy(nn_seq, g_last.nn_seq.data(), g_last.nn_seq.size() * sizeof(uint32_t));
+  if (accept) std::memcpy(accept, g_last.accept.data(), g_last.accept.size());
+  if (goal_dist) std::memcpy(goal_dist, g_last.goal_dist.data(), g_last.goal_dist.size() * sizeof(double));
+}
+
+}  // extern "C"

@@ -1,0 +1,382 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see reak_math.hpp header).
+//
+// CPU restatement of the sampling-based-planning layer: global RNG + hyperbox sampling, Euclidean
+// metric, linear 1-NN / k-NN search, star_neighborhood, the quasi-static edge-stepping loop,
+// RK4 (runge_kutta4_integrate_impl), the steerable dynamic free space, the planning-visitor
+// predicates and generate_rrt.
+//
+// Third-party arithmetic restated from its published definition (source not in /root/reference):
+//   Boost.Random mt19937 + uniform_01<Engine&,double> (Boost >= 1.46, R/CMakeLists.txt:73-75):
+//   std::mt19937 is the same generator (10000th output of the default seed is 4123659995);
+//   uniform_01 on a 32-bit engine is  u = eng() * 2^-32  (one draw per coordinate, redrawn if it
+//   rounds to 1.0, which cannot happen in double).  "parity unpinned": no reference test fixes a
+//   seed or an expected sample (global_rng.hpp:50-54 seeds from random_device).
+// Planner-level results (node counts, trees) are pinned by nothing in the reference; the golden
+// vectors under tests/golden/ generated from this restatement are the pin.
+#ifndef REAK_ORACLE_PLANNING_HPP
+#define REAK_ORACLE_PLANNING_HPP
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <random>
+#include <utility>
+#include <vector>
+
+#include "../include/rkh_types.h"
+#include "reak_kte.hpp"
+#include "reak_proximity.hpp"
+
+namespace oracle {
+
+typedef std::vector<double> Point;
+
+// get_global_rng(): core/base/global_rng.hpp:44-54 ; boost::uniform_01<global_rng_type&,double>
+struct GlobalRng {
+  std::mt19937 eng;
+  explicit GlobalRng(uint32_t seed = 5489u) : eng(seed) {}
+  double uniform_01() {
+    for (;;) {
+      double result = double(eng() - std::mt19937::min()) * (1.0 / 4294967296.0);
+      if (result < 1.0) return result;
+    }
+  }
+};
+
+// hyperbox_topology::random_point: ctrl/topologies/hyperbox_topology.hpp:97-103
+inline Point hyperbox_random_point(GlobalRng& rng, const double* lower, const double* upper, int D) {
+  Point p(lower, lower + D);
+  for (int i = 0; i < D; ++i) p[i] += rng.uniform_01() * (upper[i] - lower[i]);
+  return p;
+}
+// hyperbox_topology::is_in_bounds: hyperbox_topology.hpp:178-189
+inline bool hyperbox_is_in_bounds(const double* a, const double* lower, const double* upper, int D) {
+  for (int i = 0; i < D; ++i) {
+    if (lower[i] < upper[i]) {
+      if ((a[i] < lower[i]) || (a[i] > upper[i])) return false;
+    } else {
+      if ((a[i] > lower[i]) || (a[i] < upper[i])) return false;
+    }
+  }
+  return true;
+}
+// euclidean_distance_metric: ctrl/topologies/vect_distance_metrics.hpp:113-150
+// (difference = a - b, vector_topology.hpp; result += d*d left to right; sqrt)
+inline double euclid(const double* a, const double* b, int D) {
+  double result = 0.0;
+  for (int i = 0; i < D; ++i) {
+    double d = a[i] - b[i];
+    result += d * d;
+  }
+  return std::sqrt(result);
+}
+
+// min_dist_linear_search (1-NN): ctrl/path_planning/topological_search.hpp:95-118
+// vertices are visited in insertion order; strict '<' => first minimum wins.  Returns n if empty.
+inline std::size_t linear_nn(const double* q, const double* pts, std::size_t n, int D, double* d_out = nullptr) {
+  if (n == 0) return n;
+  double d_best = std::numeric_limits<double>::infinity();
+  std::size_t result = n;
+  for (std::size_t i = 0; i < n; ++i) {
+    double d = euclid(q, pts + i * D, D);
+    if (d < d_best) {
+      d_best = d;
+      result = i;
+    }
+  }
+  if (d_out) *d_out = d_best;
+  return result;
+}
+
+// min_dist_linear_search (k-NN + radius): topological_search.hpp:244-274
+// compare_pair_first orders the heap by distance only (detail::compare_pair_first :57-66).
+inline void linear_knn(const double* q, const double* pts, std::size_t n, int D, std::size_t max_neighbors,
+                       double radius, std::vector<std::pair<double, std::size_t>>& out) {
+  out.clear();
+  if (n == 0) return;
+  auto p_compare = [](const std::pair<double, std::size_t>& a, const std::pair<double, std::size_t>& b) {
+    return a.first < b.first;
+  };
+  for (std::size_t i = 0; i < n; ++i) {
+    double d = euclid(q, pts + i * D, D);
+    if (!(d < radius)) continue;
+    out.push_back(std::make_pair(d, i));
+    std::push_heap(out.begin(), out.end(), p_compare);
+    if (out.size() > max_neighbors) {
+      std::pop_heap(out.begin(), out.end(), p_compare);
+      out.pop_back();
+      radius = out.front().first;
+    }
+  }
+  std::sort_heap(out.begin(), out.end(), p_compare);
+}
+
+// math::highest_set_bit: core/base/misc_math.hpp:50-59
+inline std::size_t highest_set_bit(std::size_t N) {
+  std::size_t temp = 0;
+  for (std::size_t shift = sizeof(std::size_t) * 4; (shift && (N != 1)); shift >>= 1) {
+    if (N >> shift) {
+      temp |= shift;
+      N >>= shift;
+    }
+  }
+  return temp;
+}
+// star_neighborhood::operator(): ctrl/graph_alg/neighborhood_functors.hpp:95-102
+inline void star_neighborhood(std::size_t N, double c_space_dimensions, double gamma_value, std::size_t* k,
+                              double* radius) {
+  std::size_t log_N = highest_set_bit(N) + 1;
+  *k = 4 * log_N;
+  *radius = gamma_value * std::pow(log_N / double(N), 1.0 / c_space_dimensions);
+}
+
+// --------------------------------------------------------------------------------------------
+// Free spaces.  Common surface used by the visitor predicates / generate_rrt below.
+struct SpaceCounters {
+  long edges_checked = 0;   // steer_towards_position + can_be_connected + goal probes
+  long states_checked = 0;  // is_free calls
+  long f_evals = 0;
+};
+
+// Quasi-static manipulator free space over joint positions:
+// manip_quasi_static_env (ctrl/topologies/manip_free_workspace.hpp:113-300) on a hyperbox joint space
+// with linear interpolation (vector_topology::move_position_toward).
+struct QuasiStaticSpace {
+  int D = 0;
+  std::vector<double> lower, upper;
+  double min_interval = 0.1;
+  KteChain chain;
+  ProxyEnv env;
+  SpaceCounters cnt;
+
+  Point random_point(GlobalRng& rng) const { return hyperbox_random_point(rng, lower.data(), upper.data(), D); }
+  double metric(const Point& a, const Point& b) const { return euclid(a.data(), b.data(), D); }
+  // manip_quasi_static_env::is_free :154-156 ; manip_dk_proxy_env_impl::is_free :79-99
+  bool is_free(const Point& p) {
+    ++cnt.states_checked;
+    if (!hyperbox_is_in_bounds(p.data(), lower.data(), upper.data(), D)) return false;
+    std::vector<double> x(2 * D, 0.0);
+    for (int i = 0; i < D; ++i) x[2 * i] = p[i];
+    chain.apply_kinematics(x.data());
+    return env.is_free(chain);
+  }
+  // vector_topology::move_position_toward: a + (b - a) * fraction
+  Point lin_move(const Point& a, double fraction, const Point& b) const {
+    Point r(D);
+    for (int i = 0; i < D; ++i) r[i] = a[i] + (b[i] - a[i]) * fraction;
+    return r;
+  }
+  // interp_topo_move_position_toward_pred: ctrl/interpolation/interpolated_topologies.hpp:137-163
+  Point move_position_toward(const Point& a, double fraction, const Point& b) {
+    ++cnt.edges_checked;
+    double dist_tot = metric(a, b);
+    if (dist_tot == std::numeric_limits<double>::infinity()) return a;
+    if (dist_tot < min_interval) return lin_move(a, fraction, b);
+    double dist_inter = dist_tot * fraction;
+    double dist_cur = min_interval;
+    Point result = a;
+    Point last_result = a;
+    while (dist_cur < dist_inter) {
+      result = lin_move(a, dist_cur / dist_tot, b);
+      if (!is_free(result)) return last_result;
+      dist_cur += min_interval;
+      last_result = result;
+    }
+    if (fraction == 1.0) return b;
+    else if (fraction == 0.0) return a;
+    return lin_move(a, fraction, b);
+  }
+  // interp_topo_get_distance_pred: interpolated_topologies.hpp:193-199
+  double distance(const Point& a, const Point& b) {
+    Point b_tmp = move_position_toward(a, 1.0, b);
+    if (metric(b_tmp, b) < std::numeric_limits<double>::epsilon()) return metric(a, b);
+    return std::numeric_limits<double>::infinity();
+  }
+  // planning_visitor_base::dispatched_steer_towards_position case 4 (planning_visitors.hpp:288-296)
+  double steer(const Point& src, const Point& dest, double fraction, Point& p_result) {
+    p_result = move_position_toward(src, fraction, dest);
+    return metric(src, p_result);
+  }
+};
+
+// runge_kutta4_integrate_impl: ctrl/sys_integrators/runge_kutta4_integrator_sys.hpp:53-97 with a
+// constant_trajectory input (ctrl/interpolation/constant_trajectory.hpp:138-150: the waypoint is
+// the same u at every time).  Returns the number of loop iterations.
+template <typename F>
+int runge_kutta4_integrate(F get_state_derivative, int D, const double* start_point, double* end_point,
+                           const double* u, double start_time, double end_time, double time_step) {
+  std::vector<double> dp(D), w(D), k1(D), k2(D), k3(D);
+  get_state_derivative(start_point, u, dp.data());
+  double t = start_time;
+  for (int i = 0; i < D; ++i) end_point[i] = start_point[i];
+  int iters = 0;
+  while (((time_step > 0.0) && (t < end_time)) || ((time_step < 0.0) && (t > end_time))) {
+    ++iters;
+    for (int i = 0; i < D; ++i) w[i] = end_point[i];
+    for (int i = 0; i < D; ++i) k1[i] = time_step * dp[i];
+    for (int i = 0; i < D; ++i) end_point[i] = end_point[i] + 0.5 * k1[i];
+    t += time_step * 0.5;
+    get_state_derivative(end_point, u, dp.data());
+    for (int i = 0; i < D; ++i) k2[i] = time_step * dp[i];
+    for (int i = 0; i < D; ++i) end_point[i] = w[i] + 0.5 * k2[i];
+    get_state_derivative(end_point, u, dp.data());
+    for (int i = 0; i < D; ++i) k3[i] = time_step * dp[i];
+    for (int i = 0; i < D; ++i) end_point[i] = w[i] + k3[i];
+    t += time_step * 0.5;
+    get_state_derivative(end_point, u, dp.data());
+    for (int i = 0; i < D; ++i)
+      end_point[i] = end_point[i] + ((((1.0 / 6.0) * k1[i] + (2.0 / 6.0) * k2[i]) + (time_step / 6.0) * dp[i]) -
+                                     (2.0 / 3.0) * k3[i]);
+    get_state_derivative(end_point, u, dp.data());  // primes the next iteration (:95)
+  }
+  return iters;
+}
+
+// Steerable dynamic free space over a KTE chain ("kte_dynamic_free_space", build-defined; loop shape
+// of examples/misc/MEAQR_topology.hpp:503-565 (steer_with_constant_control) and :995-1003 (distance)).
+struct DynSpace {
+  rkh_dyn_space P;
+  int D = 0;
+  KteChain chain;
+  ProxyEnv env;
+  SpaceCounters cnt;
+
+  Point random_point(GlobalRng& rng) const { return hyperbox_random_point(rng, P.lower, P.upper, D); }
+  double metric(const Point& a, const Point& b) const { return euclid(a.data(), b.data(), D); }
+  // MEAQR_topology_with_CD::is_free_impl :919-940 : in_bounds, then DK, then proximity
+  bool is_free(const Point& x) {
+    ++cnt.states_checked;
+    if (!hyperbox_is_in_bounds(x.data(), P.lower, P.upper, D)) return false;
+    chain.apply_kinematics(x.data());
+    return env.is_free(chain);
+  }
+  void control(const Point& x, const Point& target, double* u) const {
+    for (int i = 0; i < P.n_dof; ++i) {
+      double v = P.kp * (target[2 * i] - x[2 * i]) + P.kd * (target[2 * i + 1] - x[2 * i + 1]);
+      if (v > P.u_max) v = P.u_max;
+      else if (v < -P.u_max) v = -P.u_max;
+      u[i] = v;
+    }
+  }
+  void rk4_step(const Point& x, const double* u, double t, Point& x_next) {
+    x_next.resize(D);
+    auto f = [&](const double* p, const double* uu, double* pd) {
+      ++cnt.f_evals;
+      chain.get_state_derivative(p, uu, pd);
+    };
+    runge_kutta4_integrate(f, D, x.data(), x_next.data(), u, t, t + P.dt, P.dt);
+  }
+  // steer_position_toward(a, fraction, b): returns the last free state; steps_free = number of
+  // accepted RK4 steps; record (optional) = the steer_record (a, then every accepted state).
+  Point steer_position_toward(const Point& a, double fraction, const Point& b, int* steps_free = nullptr,
+                              std::vector<Point>* record = nullptr) {
+    ++cnt.edges_checked;
+    double T_goal = fraction * (P.steps_per_edge * P.dt);
+    double current_time = 0.0;
+    Point x_current = a;
+    if (record) record->push_back(x_current);
+    int n_free = 0;
+    Point x_next;
+    std::vector<double> u(P.n_dof);
+    while ((current_time < T_goal) && (metric(x_current, b) > P.goal_tol)) {
+      control(x_current, b, u.data());
+      rk4_step(x_current, u.data(), current_time, x_next);
+      if (is_free(x_next)) {
+        x_current = x_next;
+        current_time += P.dt;
+        ++n_free;
+        if (record) record->push_back(x_current);
+      } else {
+        break;
+      }
+    }
+    if (steps_free) *steps_free = n_free;
+    return x_current;
+  }
+  // C_free distance (goal probe): MEAQR_topology_with_CD::distance :995-1003
+  double distance(const Point& a, const Point& b) {
+    Point result = steer_position_toward(a, 1.0, b);
+    if (metric(a, b) * 0.05 > metric(result, b)) return metric(a, b);
+    return std::numeric_limits<double>::infinity();
+  }
+  // dispatched_steer_towards_position case 3 (planning_visitors.hpp:277-285)
+  double steer(const Point& src, const Point& dest, double fraction, Point& p_result) {
+    p_result = steer_position_toward(src, fraction, dest);
+    return metric(src, p_result);
+  }
+};
+
+// --------------------------------------------------------------------------------------------
+// RRT (unidirectional, linear-search NN): rrt_planner::solve_planning_query
+// (ctrl/path_planning/rrt_path_planner.tpp:66-145) -> generate_rrt (ctrl/graph_alg/rr_tree.hpp:179-199).
+struct RrtResult {
+  int D = 0;
+  std::vector<double> pos;       // n x D, insertion order (vertices(g) order)
+  std::vector<uint32_t> parent;  // parent index; root: 0xFFFFFFFF
+  std::vector<uint32_t> nn_seq;  // per iteration: nearest-neighbour vertex
+  std::vector<uint8_t> accept;   // per iteration: steer accepted (vertex added)
+  std::vector<double> goal_dist; // per added vertex (non-root): goal-probe distance
+  long iterations = 0;
+  long num_solutions = 0;
+  double best_cost = std::numeric_limits<double>::infinity();
+  SpaceCounters cnt;
+};
+
+template <typename Space>
+void generate_rrt(Space& space, const rkh_rrt_params& prm, long max_iterations, RrtResult& res) {
+  const int D = space.D;
+  GlobalRng rng(prm.seed);
+  res = RrtResult();
+  res.D = D;
+  Point start(prm.start, prm.start + D), goal(prm.goal, prm.goal + D);
+  // create_root(vp_start): rrt_path_planner.tpp:131-133 (no vertex_added call => not counted)
+  res.pos.insert(res.pos.end(), start.begin(), start.end());
+  res.parent.push_back(0xFFFFFFFFu);
+  unsigned long m_iteration_count = 0;  // sample_based_planner::m_iteration_count
+  // keep_going: planning_visitors.hpp:203-205 -> motion_planner_base.hpp:374 && p2p_planning_query.hpp:121-123
+  auto keep_going = [&]() {
+    return (m_iteration_count < prm.max_vertices) && (prm.max_results > (unsigned long)res.num_solutions);
+  };
+  while (keep_going() && (max_iterations < 0 || res.iterations < max_iterations)) {
+    ++res.iterations;
+    Point p_rnd = space.random_point(rng);                                   // rr_tree.hpp:194
+    std::size_t n = res.parent.size();
+    std::size_t u = linear_nn(p_rnd.data(), res.pos.data(), n, D);           // rr_tree.hpp:195
+    res.nn_seq.push_back(uint32_t(u));
+    // steer_towards_position: planning_visitors.hpp:349-360
+    Point pu(res.pos.begin() + u * D, res.pos.begin() + (u + 1) * D);
+    Point p_v;
+    double traveled_dist = space.steer(pu, p_rnd, 1.0, p_v);
+    double best_case_dist = space.metric(pu, p_rnd);
+    bool reached_new = (!std::isinf(traveled_dist)) && (traveled_dist < 2.0 * best_case_dist) &&
+                       (traveled_dist > prm.steer_tol * best_case_dist);
+    res.accept.push_back(reached_new ? 1 : 0);
+    if (!reached_new) continue;
+    // add_child_vertex; vis.vertex_added (iteration_count++); vis.edge_added (goal probe)
+    res.pos.insert(res.pos.end(), p_v.begin(), p_v.end());
+    res.parent.push_back(uint32_t(u));
+    ++m_iteration_count;  // report_progress: motion_planner_base.hpp:343-347
+    // edge_added: planning_visitors.hpp:186-201
+    double goal_dist = space.distance(p_v, goal);
+    res.goal_dist.push_back(goal_dist);
+    if (goal_dist < std::numeric_limits<double>::infinity()) {
+      // register_basic_solution_path_impl: solution_path_factories.hpp:132-152
+      double total = goal_dist;
+      std::size_t v = res.parent.size() - 1;
+      while (res.parent[v] != 0xFFFFFFFFu) {
+        std::size_t pv = res.parent[v];
+        total += euclid(&res.pos[pv * D], &res.pos[v * D], D);
+        v = pv;
+      }
+      if (res.num_solutions == 0 || total < res.best_cost) {
+        res.best_cost = total;
+        ++res.num_solutions;
+      }
+    }
+  }
+  res.cnt = space.cnt;
+}
+
+}  // namespace oracle
+#endif

@@ -1,0 +1,273 @@
+// nn_sweep.hip -- exact batched nearest-neighbour sweeps over the growing tree (gfx950).
+//
+// Replaces min_dist_linear_search (ctrl/path_planning/topological_search.hpp:95-118 1-NN,
+// :244-274 k-NN) with euclidean_distance_metric (ctrl/topologies/vect_distance_metrics.hpp:113-150).
+//
+// Layout: vertex positions are row-major [n][Dp] fp64 in HBM (Dp = D rounded up to a supported
+// width, pad = 0.0 which leaves the left-to-right sum of squares bit-identical).  A 256-thread block
+// streams its slice of the rows linearly through a 256-row LDS tile (contiguous 16-B/lane global
+// loads, no transpose); thread (q, r) keeps query q in registers and walks rows r, r+R, r+2R ...
+// of the tile through LDS broadcast reads, so the inner loop has no cross-lane traffic at all.
+// Bit-exact argmin: squares are compared first; sqrt (correctly rounded) is taken only for
+// candidates within 4 ulp of the running best square, and ties resolve to the lower vertex index
+// ("first minimum wins", strict '<' in the reference).
+//
+// Roofline: one sweep reads n*Dp*8 bytes once; per (row, query) it issues 3*Dp-1 fp64 VALU ops, so
+// with <= ~8 queries per sweep the kernel is HBM-bound, above ~16 it is fp64-VALU-bound.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+
+#include "rkh_internal.h"
+
+namespace rkh {
+
+static constexpr int kTileRows = 256;
+static constexpr int kThreads = 256;
+
+__device__ __forceinline__ bool lex_less(double da, uint32_t ia, double db, uint32_t ib) {
+  return (da < db) || (da == db && ia < ib);
+}
+
+// One block: rows [row0, row1) x queries [blockIdx.y*QB, +QB).
+template <int DP, int QB>
+__global__ __launch_bounds__(kThreads) void nn1_sweep_kernel(const double* __restrict__ pos, uint64_t n_host,
+                                                              const uint32_t* __restrict__ d_n,
+                                                              const double* __restrict__ q,
+                                                              const uint32_t* __restrict__ d_qoff, int D,
+                                                              uint32_t B_host, const uint32_t* __restrict__ d_B,
+                                                              double* __restrict__ part_dist,
+                                                              uint32_t* __restrict__ part_idx, uint32_t Bpad) {
+  constexpr int R = kThreads / QB;          // row sub-ranges per block
+  constexpr int ROWS_PER_THREAD = kTileRows / R;
+  __shared__ __attribute__((aligned(16))) double tile[kTileRows * DP];
+  __shared__ double red_d[kThreads];
+  __shared__ uint32_t red_i[kThreads];
+
+  const uint64_t n = d_n ? uint64_t(*d_n) : n_host;
+  const uint32_t B = d_B ? *d_B : B_host;
+  const int tid = threadIdx.x;
+  const int ql = tid % QB;
+  const int r = tid / QB;
+  const uint32_t qi = blockIdx.y * QB + ql;
+  if (blockIdx.y * QB >= B) return;  // whole block has no query (B read on device)
+
+  // query -> registers (padded with zeros)
+  double qv[DP];
+  {
+    const uint64_t qsrc = uint64_t(qi < B ? qi : (B - 1)) + (d_qoff ? uint64_t(*d_qoff) : 0ull);
+#pragma unroll
+    for (int d = 0; d < DP; ++d) qv[d] = d < D ? q[qsrc * D + d] : 0.0;
+  }
+
+  // balanced contiguous slice of rows for this block, in whole tiles
+  const uint64_t tiles_total = (n + kTileRows - 1) / kTileRows;
+  const uint64_t tiles_per_block = (tiles_total + gridDim.x - 1) / gridDim.x;
+  const uint64_t tile0 = uint64_t(blockIdx.x) * tiles_per_block;
+  uint64_t tile1 = tile0 + tiles_per_block;
+  if (tile1 > tiles_total) tile1 = tiles_total;
+
+  double best_d = INFINITY;     // sqrt of best_s
+  double best_thr = INFINITY;   // squares above this cannot tie or beat best_d
+  uint32_t best_i = 0xFFFFFFFFu;
+
+  for (uint64_t t = tile0; t < tile1; ++t) {
+    const uint64_t row_base = t * kTileRows;
+    // contiguous copy HBM -> LDS (rows beyond n become +inf so they never win)
+    {
+      const double2* src = reinterpret_cast<const double2*>(pos + row_base * DP);
+      double2* dst = reinterpret_cast<double2*>(tile);
+      constexpr int N2 = kTileRows * DP / 2;
+      const uint64_t valid2 = (n - row_base >= uint64_t(kTileRows)) ? uint64_t(N2) : (n - row_base) * DP / 2;
+#pragma unroll 4
+      for (int i = tid; i < N2; i += kThreads) {
+        double2 v;
+        if (uint64_t(i) < valid2) v = src[i];
+        else v = make_double2(INFINITY, INFINITY);
+        dst[i] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int k = 0; k < ROWS_PER_THREAD; ++k) {
+      const int row = k * R + r;
+      const double* p = tile + row * DP;
+      double s;
+      {
+        double df = qv[0] - p[0];
+        s = df * df;
+      }
+#pragma unroll
+      for (int d = 1; d < DP; ++d) {
+        double df = qv[d] - p[d];
+        s = s + df * df;
+      }
+      if (s <= best_thr) {  // rare after the first few rows
+        const double dd = sqrt(s);
+        if (dd < best_d) {
+          best_d = dd;
+          best_i = uint32_t(row_base + row);
+          best_thr = s * (1.0 + 4.0 * DBL_EPSILON);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // combine the R sub-ranges of each query (lexicographic (dist, index) = first minimum wins)
+  red_d[tid] = best_d;
+  red_i[tid] = best_i;
+  __syncthreads();
+  if (tid < QB) {
+    double bd = red_d[tid];
+    uint32_t bi = red_i[tid];
+#pragma unroll
+    for (int rr = 1; rr < R; ++rr) {
+      const double od = red_d[rr * QB + tid];
+      const uint32_t oi = red_i[rr * QB + tid];
+      if (lex_less(od, oi, bd, bi)) {
+        bd = od;
+        bi = oi;
+      }
+    }
+    if (qi < B) {
+      part_dist[uint64_t(blockIdx.x) * Bpad + qi] = bd;
+      part_idx[uint64_t(blockIdx.x) * Bpad + qi] = bi;
+    }
+  }
+}
+
+__global__ void nn1_reduce_kernel(const double* __restrict__ part_dist, const uint32_t* __restrict__ part_idx,
+                                  uint32_t nblocks, uint32_t Bpad, uint32_t B_host, const uint32_t* __restrict__ d_B,
+                                  uint32_t* __restrict__ idx, double* __restrict__ dist) {
+  const uint32_t B = d_B ? *d_B : B_host;
+  const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= B) return;
+  double bd = INFINITY;
+  uint32_t bi = 0xFFFFFFFFu;
+  for (uint32_t b = 0; b < nblocks; ++b) {
+    const double od = part_dist[uint64_t(b) * Bpad + qi];
+    const uint32_t oi = part_idx[uint64_t(b) * Bpad + qi];
+    if (lex_less(od, oi, bd, bi)) {
+      bd = od;
+      bi = oi;
+    }
+  }
+  idx[qi] = bi;
+  dist[qi] = bd;
+}
+
+static int padded_dims(int D) {
+  static const int sizes[] = {2, 4, 6, 8, 12, 16, 24, 32};
+  for (int s : sizes)
+    if (D <= s) return s;
+  return -1;
+}
+int nn_padded_dims(int D) { return padded_dims(D); }
+
+static uint32_t pick_qb(uint32_t B) {
+  if (B <= 8) return 8;
+  if (B <= 32) return 32;
+  if (B <= 128) return 128;
+  return 256;
+}
+
+static uint32_t pick_gx(uint64_t n_upper, uint32_t gy) {
+  uint64_t tiles = (n_upper + kTileRows - 1) / kTileRows;
+  if (tiles < 1) tiles = 1;
+  uint64_t want = 2048 / gy;  // ~8 blocks per CU over the whole grid
+  if (want < 1) want = 1;
+  return uint32_t(tiles < want ? tiles : want);
+}
+
+uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B) {
+  const uint32_t qb = pick_qb(B);
+  const uint32_t gy = (B + qb - 1) / qb;
+  return pick_gx(n_upper, gy);
+}
+
+static const char* g_last_kernel = "";
+const char* nn_last_kernel_name() { return g_last_kernel; }
+
+template <int DP>
+static rkh_status launch_nn1_dp(hipStream_t s, const NnStore& st, uint64_t n, const uint32_t* d_n, const double* d_q,
+                                const uint32_t* d_qoff, uint32_t B, const uint32_t* d_B, uint32_t* d_idx, double* d_dist, double* d_part_dist,
+                                uint32_t* d_part_idx, uint32_t part_capacity_blocks) {
+  const uint32_t qb = pick_qb(B);
+  const uint32_t gy = (B + qb - 1) / qb;
+  uint32_t gx = pick_gx(n, gy);
+  if (gx > part_capacity_blocks) gx = part_capacity_blocks;
+  const uint32_t Bpad = B;
+  dim3 grid(gx, gy), block(kThreads);
+#define RKH_NN1_LAUNCH(QB)                                                                                       \
+  hipLaunchKernelGGL((nn1_sweep_kernel<DP, QB>), grid, block, 0, s, st.d_pos, n, d_n, d_q, d_qoff, st.D, B,    \
+                     d_B, d_part_dist, d_part_idx, Bpad)
+  switch (qb) {
+    case 8: RKH_NN1_LAUNCH(8); break;
+    case 32: RKH_NN1_LAUNCH(32); break;
+    case 128: RKH_NN1_LAUNCH(128); break;
+    default: RKH_NN1_LAUNCH(256); break;
+  }
+#undef RKH_NN1_LAUNCH
+  hipLaunchKernelGGL(nn1_reduce_kernel, dim3((B + 255) / 256), dim3(256), 0, s, d_part_dist, d_part_idx, gx, Bpad, B,
+                     d_B, d_idx, d_dist);
+  RKH_HIP(hipGetLastError());
+  return RKH_OK;
+}
+
+rkh_status launch_nn1(hipStream_t s, const NnStore& st, uint64_t n, const uint32_t* d_n, const double* d_q,
+                      const uint32_t* d_qoff, uint32_t B, const uint32_t* d_B, uint32_t* d_idx, double* d_dist, double* d_part_dist, uint32_t* d_part_idx,
+                      uint32_t part_capacity_blocks) {
+  if (B == 0) return RKH_OK;
+  g_last_kernel = "nn1_sweep_kernel";
+  switch (padded_dims(st.D)) {
+#define RKH_CASE(DP)                                                                                              \
+  case DP:                                                                                                        \
+    return launch_nn1_dp<DP>(s, st, n, d_n, d_q, d_qoff, B, d_B, d_idx, d_dist, d_part_dist, d_part_idx,          \
+                             part_capacity_blocks)
+    RKH_CASE(2);
+    RKH_CASE(4);
+    RKH_CASE(6);
+    RKH_CASE(8);
+    RKH_CASE(12);
+    RKH_CASE(16);
+    RKH_CASE(24);
+    RKH_CASE(32);
+#undef RKH_CASE
+  }
+  set_error("nn: unsupported dimension");
+  return RKH_ERR_BAD_ARG;
+}
+
+// ---- synthetic fill: uniform points in the unit hypercube, splitmix64 per element ------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ void fill_uniform_kernel(double* pos, uint64_t n, int D, int DP, uint64_t seed) {
+  const uint64_t total = n * uint64_t(DP);
+  for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < total; i += uint64_t(gridDim.x) * blockDim.x) {
+    const int d = int(i % DP);
+    const uint64_t row = i / DP;
+    double v = 0.0;
+    if (d < D) v = double(splitmix64(seed ^ (row * 64 + d)) >> 11) * (1.0 / 9007199254740992.0);
+    pos[i] = v;
+  }
+}
+rkh_status launch_fill_uniform(hipStream_t s, const NnStore& st, uint64_t n, uint64_t seed) {
+  const int DP = padded_dims(st.D);
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(2048), dim3(256), 0, s, st.d_pos, n, st.D, DP, seed);
+  RKH_HIP(hipGetLastError());
+  return RKH_OK;
+}
+
+rkh_status launch_nnk(hipStream_t, const NnStore&, uint64_t, const double*, uint32_t, uint32_t, double, uint32_t*,
+                      double*, uint32_t*) {
+  set_error("k-NN sweep kernel not built yet");
+  return RKH_ERR_UNSUPPORTED;
+}
+
+}  // namespace rkh

@@ -1,0 +1,160 @@
+// rkh_internal.h -- shared declarations of librkh.so (host side + device structs).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/rkh.h"
+
+namespace rkh {
+
+void set_error(const std::string& msg);
+
+#define RKH_HIP(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      ::rkh::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                     \
+      return (_e == hipErrorOutOfMemory) ? RKH_ERR_OOM : RKH_ERR_DEVICE;                       \
+    }                                                                                          \
+  } while (0)
+
+constexpr int kMaxDof = 8;          // HIP kernels are instantiated for 1..kMaxDof revolute joints
+constexpr int kMaxEnvShapes = 256;  // environment shapes resident in LDS
+constexpr int kMaxSteps = 64;       // RK4 steps per edge
+
+// ---- NN sweep (nn_sweep.hip) -----------------------------------------------------------------
+// Vertex positions live row-major [n][D] in HBM (one contiguous 8*D-byte row per vertex): the sweep
+// streams them linearly through LDS tiles and the propagate kernel gathers a parent with one row read.
+struct NnStore {
+  double* d_pos = nullptr;  // [capacity][D]
+  uint64_t capacity = 0;
+  int D = 0;
+};
+
+// 1-NN of B queries over the first n rows. If d_n != nullptr the vertex count is read on the device
+// (planner rounds enqueued without host sync) and n is only the host-side upper bound used to size the grid.
+rkh_status launch_nn1(hipStream_t s, const NnStore& st, uint64_t n, const uint32_t* d_n, const double* d_q,
+                      const uint32_t* d_qoff, uint32_t B, const uint32_t* d_B, uint32_t* d_idx, double* d_dist, double* d_part_dist,
+                      uint32_t* d_part_idx, uint32_t part_capacity_blocks);
+uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B);
+rkh_status launch_nnk(hipStream_t s, const NnStore& st, uint64_t n, const double* d_q, uint32_t B, uint32_t k,
+                      double radius, uint32_t* d_idx, double* d_dist, uint32_t* d_count);
+rkh_status launch_fill_uniform(hipStream_t s, const NnStore& st, uint64_t n, uint64_t seed);
+
+// ---- scene (propagate.hip) ---------------------------------------------------------------------
+struct JointDev {  // one {actuator, rotor inertia, revolute joint, rigid link, link inertia} group
+  double axis[3];     // revolute_joint_3D::mAxis as given
+  double axis_n[3];   // axis_angle's normalised copy (rotations_3D.hpp:1961-1974)
+  double joint_inertia;
+  double off_pos[3];
+  double off_quat[4];
+  double off_R[9];   // rotmat(off_quat), row-major (same formula as the device would use)
+  double mass;
+  double inertia[6]; // a11,a12,a13,a22,a23,a33
+};
+struct ShapeDev {
+  int32_t kind;
+  int32_t link;      // robot shapes: joint index whose end frame anchors the shape; env: -1
+  double pos[3];
+  double quat[4];
+  double dims[3];
+  double brad;       // getBoundingRadius()
+};
+struct SceneDev {
+  int32_t n_dof;
+  int32_t n_robot;   // robot shapes (anchored)
+  int32_t n_env;     // environment shapes
+  int32_t pad;
+  double base_pos[3];
+  double base_quat[4];
+  double base_acc[3];
+  JointDev joints[kMaxDof];
+  ShapeDev robot[kMaxDof * 2];
+  ShapeDev env[kMaxEnvShapes];
+};
+
+}  // namespace rkh
+
+struct rkh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+};
+
+struct rkh_nn {
+  rkh_ctx* ctx = nullptr;
+  rkh::NnStore st;
+  uint64_t n = 0;
+  // scratch for host-pointer queries
+  double* d_q = nullptr;
+  uint32_t* d_idx = nullptr;
+  double* d_dist = nullptr;
+  uint32_t* d_count = nullptr;
+  uint64_t q_cap = 0, res_cap = 0;
+  double* d_part_dist = nullptr;
+  uint32_t* d_part_idx = nullptr;
+  uint64_t part_cap = 0;
+  uint32_t part_blocks = 0;
+};
+
+struct rkh_scene {
+  rkh_ctx* ctx = nullptr;
+  rkh::SceneDev host;
+  rkh::SceneDev* d_scene = nullptr;
+  void* d_pairs = nullptr;  // PairDev[n_pairs], sorted by routine
+  int* d_err = nullptr;
+  int n_pairs = 0;
+};
+
+namespace rkh {
+
+struct PairDev {
+  uint8_t routine;      // PairRoutine (proximity_device.h)
+  uint8_t s1_is_robot;  // 1: (shape1, shape2) = (robot, env); 0: (env, robot)
+  uint16_t robot;
+  uint16_t env;
+  uint16_t pad;
+};
+
+struct DynDev {  // rkh_dyn_space on the device (passed by value)
+  double dt, kp, kd, u_max, goal_tol;
+  double lower[2 * kMaxDof], upper[2 * kMaxDof];
+  int n_steps;              // RK4 steps for this fraction
+  int8_t inner[kMaxSteps];  // runge_kutta4_integrate_impl loop iterations of step k (normally 1)
+};
+
+enum EdgeMode : int { EDGE_PLAIN = 0, EDGE_STEER_ACCEPT = 1, EDGE_GOAL_PROBE = 2 };
+
+struct EdgeIO {  // inputs / outputs of one propagate launch (all device pointers)
+  const double* src = nullptr;         // source rows
+  const uint32_t* src_idx = nullptr;   // row of edge e (null: *d_src_first + e, or e)
+  const uint32_t* d_src_first = nullptr;
+  uint32_t src_stride = 0;
+  const double* tgt = nullptr;         // target rows
+  const uint32_t* d_tgt_off = nullptr; // row offset read on the device
+  uint32_t tgt_stride = 0;             // 0: one target for all edges
+  uint32_t B = 0;
+  const uint32_t* d_B = nullptr;
+  double* x_out = nullptr;
+  uint32_t* steps_free = nullptr;
+  double* record = nullptr;
+  int record_stride = 0;
+  int mode = EDGE_PLAIN;
+  const double* best_case = nullptr;
+  double steer_tol = 0.1;
+  uint8_t* accept = nullptr;
+  double* goal_dist = nullptr;         // indexed by source row - 1
+  int* err_flag = nullptr;
+};
+
+rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
+                            int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges);
+rkh_status launch_state_derivative(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x,
+                                   const double* d_u, uint32_t B, double* d_pd, double* d_M, double* d_f, int* d_err);
+rkh_status launch_min_distance(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
+                               int n_pairs, const double* d_x, uint32_t B, double* d_dist);
+rkh_status build_dyn_dev(const rkh_dyn_space& sp, double fraction, DynDev* out);
+}  // namespace rkh

@@ -1,0 +1,334 @@
+// scene.hip -- C-ABI: scene flattening (KTE program -> serial-chain tables, proxy pair list) and the
+// kernel-level entry points rkh_state_derivative / rkh_min_distance / rkh_propagate (include/rkh.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "rkh_internal.h"
+
+using namespace rkh;
+
+namespace rkh {
+
+// quaternion::getRotMat (rotations_3D.hpp:986-999), host copy used once per scene for the constant link offsets
+static void host_rotmat(const double* q, double* R) {
+  const double t01 = 2.0 * q[0] * q[1], t02 = 2.0 * q[0] * q[2], t03 = 2.0 * q[0] * q[3];
+  const double t11 = 2.0 * q[1] * q[1], t12 = 2.0 * q[1] * q[2], t13 = 2.0 * q[1] * q[3];
+  const double t22 = 2.0 * q[2] * q[2], t23 = 2.0 * q[2] * q[3], t33 = 2.0 * q[3] * q[3];
+  const double r[9] = {1.0 - t22 - t33, t12 - t03, t02 + t13, t12 + t03, 1.0 - t11 - t33, t23 - t01,
+                       t13 - t02,       t01 + t23, 1.0 - t11 - t22};
+  std::memcpy(R, r, sizeof(r));
+}
+
+static double bounding_radius(const rkh_shape& s) {
+  switch (s.kind) {
+    case RKH_SHAPE_SPHERE: return s.dims[0];
+    case RKH_SHAPE_BOX: {
+      double acc = 0.0;
+      for (int i = 0; i < 3; ++i) acc += s.dims[i] * s.dims[i];
+      return std::sqrt(acc) * 0.5;
+    }
+    case RKH_SHAPE_CCYLINDER: return s.dims[0] * 0.5 + s.dims[1];
+  }
+  return 0.0;
+}
+
+// The time loops of the steer pattern and of runge_kutta4_integrate_impl depend only on (fraction, dt,
+// steps): evaluate them on the host in the same fp64 arithmetic and hand the kernel integer counts.
+rkh_status build_dyn_dev(const rkh_dyn_space& sp, double fraction, DynDev* out) {
+  if (sp.n_dof < 1 || sp.n_dof > kMaxDof || sp.steps_per_edge < 0 || sp.steps_per_edge > kMaxSteps || !(sp.dt > 0.0)) {
+    set_error("rkh_dyn_space: n_dof / steps_per_edge / dt out of range");
+    return RKH_ERR_BAD_ARG;
+  }
+  DynDev d;
+  std::memset(&d, 0, sizeof(d));
+  d.dt = sp.dt; d.kp = sp.kp; d.kd = sp.kd; d.u_max = sp.u_max; d.goal_tol = sp.goal_tol;
+  for (int i = 0; i < 2 * sp.n_dof; ++i) {
+    d.lower[i] = sp.lower[i];
+    d.upper[i] = sp.upper[i];
+  }
+  const double T_goal = fraction * (sp.steps_per_edge * sp.dt);
+  double current_time = 0.0;
+  int k = 0;
+  while (current_time < T_goal && k < kMaxSteps) {
+    double t = current_time;
+    const double end_time = current_time + sp.dt;
+    int it = 0;
+    while (t < end_time) {  // runge_kutta4_integrator_sys.hpp:73-96
+      t += sp.dt * 0.5;
+      t += sp.dt * 0.5;
+      ++it;
+    }
+    d.inner[k] = int8_t(it);
+    current_time += sp.dt;
+    ++k;
+  }
+  d.n_steps = k;
+  *out = d;
+  return RKH_OK;
+}
+
+}  // namespace rkh
+
+extern "C" {
+
+rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, const rkh_chain_base* base,
+                            const rkh_shape* shapes, int n_shapes, rkh_scene** out) {
+  if (!ctx || !prog || !base || !out || n_ops < 1 || (n_shapes > 0 && !shapes)) return RKH_ERR_BAD_ARG;
+  if (n_ops % 5 != 0 || n_ops / 5 > kMaxDof) {
+    set_error("rkh_scene_create: KTE program is not a serial chain of {actuator, inertia_gen, revolute, link, inertia_3D} groups");
+    return RKH_ERR_UNSUPPORTED;
+  }
+  const int n = n_ops / 5;
+  rkh_scene* sc = new rkh_scene();
+  sc->ctx = ctx;
+  SceneDev& S = sc->host;
+  std::memset(&S, 0, sizeof(S));
+  S.n_dof = n;
+  for (int i = 0; i < 3; ++i) {
+    S.base_pos[i] = base->pose.pos[i];
+    S.base_acc[i] = base->acceleration[i];
+  }
+  for (int i = 0; i < 4; ++i) S.base_quat[i] = base->pose.quat[i];
+  std::vector<int> joint_end_frame(n), link_end_frame(n);
+  int prev_end = 0;  // frame 0 = chain base
+  bool first = true;
+  for (int j = 0; j < n; ++j) {
+    const rkh_kte_op& act = prog[5 * j], &gen = prog[5 * j + 1], &rev = prog[5 * j + 2], &lnk = prog[5 * j + 3],
+                     &ine = prog[5 * j + 4];
+    const bool ok = act.kind == RKH_KTE_DRIVING_ACTUATOR_GEN && gen.kind == RKH_KTE_INERTIA_GEN &&
+                    rev.kind == RKH_KTE_REVOLUTE_JOINT_3D && lnk.kind == RKH_KTE_RIGID_LINK_3D &&
+                    ine.kind == RKH_KTE_INERTIA_3D && act.coord == j && gen.coord == j && rev.coord == j &&
+                    act.joint_op == 5 * j + 2 && gen.upstream == (1u << j) &&
+                    (first ? rev.base_frame == 0 : rev.base_frame == prev_end) && lnk.base_frame == rev.end_frame &&
+                    ine.end_frame == lnk.end_frame && ine.upstream == ((1u << (j + 1)) - 1u);
+    if (!ok) {
+      delete sc;
+      set_error("rkh_scene_create: op group " + std::to_string(j) + " does not match the serial-chain pattern");
+      return RKH_ERR_UNSUPPORTED;
+    }
+    first = false;
+    prev_end = lnk.end_frame;
+    joint_end_frame[j] = rev.end_frame;
+    link_end_frame[j] = lnk.end_frame;
+    JointDev& J = S.joints[j];
+    for (int i = 0; i < 3; ++i) J.axis[i] = rev.axis[i];
+    {  // axis_angle ctor normalisation (rotations_3D.hpp:1961-1974)
+      double acc = 0.0;
+      for (int i = 0; i < 3; ++i) acc += rev.axis[i] * rev.axis[i];
+      const double tmp = std::sqrt(acc);
+      if (tmp > 0.0000001) {
+        for (int i = 0; i < 3; ++i) J.axis_n[i] = rev.axis[i] / tmp;
+      } else {
+        J.axis_n[0] = 1.0; J.axis_n[1] = 0.0; J.axis_n[2] = 0.0;
+      }
+    }
+    J.joint_inertia = gen.mass;
+    for (int i = 0; i < 3; ++i) J.off_pos[i] = lnk.offset.pos[i];
+    for (int i = 0; i < 4; ++i) J.off_quat[i] = lnk.offset.quat[i];
+    host_rotmat(J.off_quat, J.off_R);
+    J.mass = ine.mass;
+    for (int i = 0; i < 6; ++i) J.inertia[i] = ine.inertia[i];
+  }
+  // shapes: robot model (anchored) / environment model (world)
+  std::vector<int> robot_src, env_src;
+  for (int i = 0; i < n_shapes; ++i) {
+    const rkh_shape& s = shapes[i];
+    if (s.kind < RKH_SHAPE_SPHERE || s.kind > RKH_SHAPE_CCYLINDER) {
+      delete sc;
+      set_error("rkh_scene_create: unsupported shape kind");
+      return RKH_ERR_UNSUPPORTED;
+    }
+    ShapeDev d;
+    std::memset(&d, 0, sizeof(d));
+    d.kind = s.kind;
+    for (int k = 0; k < 3; ++k) { d.pos[k] = s.pose.pos[k]; d.dims[k] = s.dims[k]; }
+    for (int k = 0; k < 4; ++k) d.quat[k] = s.pose.quat[k];
+    d.brad = bounding_radius(s);
+    if (s.anchor >= 0) {
+      int link = -1;
+      for (int j = 0; j < n; ++j)
+        if (joint_end_frame[j] == s.anchor) link = j;
+      if (link < 0 || S.n_robot >= 2 * kMaxDof) {
+        delete sc;
+        set_error("rkh_scene_create: robot shapes must be anchored on a revolute joint's end frame");
+        return RKH_ERR_UNSUPPORTED;
+      }
+      d.link = link;
+      S.robot[S.n_robot++] = d;
+      robot_src.push_back(i);
+    } else {
+      if (S.n_env >= kMaxEnvShapes) {
+        delete sc;
+        set_error("rkh_scene_create: too many environment shapes");
+        return RKH_ERR_CAPACITY;
+      }
+      d.link = -1;
+      S.env[S.n_env++] = d;
+      env_src.push_back(i);
+    }
+  }
+  // proxy_query_pair_3D::createProxFinderList (proxy_query_model.cpp:215-374), then grouped by routine so
+  // that the lanes of a wave run the same closed form (the verdict does not depend on the pair order)
+  std::vector<PairDev> pairs;
+  for (int i = 0; i < S.n_robot; ++i)
+    for (int j = 0; j < S.n_env; ++j) {
+      const int ki = S.robot[i].kind, kj = S.env[j].kind;
+      PairDev p;
+      std::memset(&p, 0, sizeof(p));
+      p.robot = uint16_t(i);
+      p.env = uint16_t(j);
+      if (ki == RKH_SHAPE_SPHERE || kj == RKH_SHAPE_SPHERE) {
+        p.s1_is_robot = (ki == RKH_SHAPE_SPHERE) ? 1 : 0;  // the sphere is shape1
+        const int ko = p.s1_is_robot ? kj : ki;
+        p.routine = (ko == RKH_SHAPE_SPHERE) ? 1 : (ko == RKH_SHAPE_CCYLINDER ? 2 : 3);
+      } else if (ki == RKH_SHAPE_CCYLINDER || kj == RKH_SHAPE_CCYLINDER) {
+        p.s1_is_robot = (ki == RKH_SHAPE_CCYLINDER) ? 1 : 0;  // the capped cylinder is shape1
+        const int ko = p.s1_is_robot ? kj : ki;
+        p.routine = (ko == RKH_SHAPE_CCYLINDER) ? 4 : 5;
+      } else {
+        continue;  // box-box: no finder in the reference (proxy_query_model.cpp:367)
+      }
+      pairs.push_back(p);
+    }
+  std::stable_sort(pairs.begin(), pairs.end(), [](const PairDev& a, const PairDev& b) { return a.routine < b.routine; });
+  sc->n_pairs = int(pairs.size());
+  RKH_HIP(hipSetDevice(ctx->device));
+  RKH_HIP(hipMalloc(&sc->d_scene, sizeof(SceneDev)));
+  RKH_HIP(hipMemcpy(sc->d_scene, &S, sizeof(SceneDev), hipMemcpyHostToDevice));
+  RKH_HIP(hipMalloc(&sc->d_pairs, std::max<size_t>(1, pairs.size()) * sizeof(PairDev)));
+  if (!pairs.empty()) RKH_HIP(hipMemcpy(sc->d_pairs, pairs.data(), pairs.size() * sizeof(PairDev), hipMemcpyHostToDevice));
+  RKH_HIP(hipMalloc(&sc->d_err, sizeof(int)));
+  RKH_HIP(hipMemset(sc->d_err, 0, sizeof(int)));
+  *out = sc;
+  return RKH_OK;
+}
+
+rkh_status rkh_scene_destroy(rkh_scene* scene) {
+  if (!scene) return RKH_OK;
+  hipFree(scene->d_scene);
+  hipFree(scene->d_pairs);
+  hipFree(scene->d_err);
+  delete scene;
+  return RKH_OK;
+}
+int rkh_scene_num_dof(const rkh_scene* scene) { return scene ? scene->host.n_dof : 0; }
+int rkh_scene_num_pairs(const rkh_scene* scene) { return scene ? scene->n_pairs : 0; }
+
+}  // extern "C"
+
+namespace {
+struct DevBuf {  // scoped device scratch
+  void* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  template <typename T> T* as() { return static_cast<T*>(p); }
+};
+rkh_status check_err_flag(rkh_scene* scene) {
+  int flag = 0;
+  RKH_HIP(hipMemcpy(&flag, scene->d_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag != 0) {
+    RKH_HIP(hipMemset(scene->d_err, 0, sizeof(int)));
+    set_error("mass matrix is singular (Cholesky pivot < 1e-8)");
+    return rkh_status(flag);
+  }
+  return RKH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+rkh_status rkh_state_derivative(rkh_scene* scene, const double* x, const double* u, uint32_t B, double* pd, double* M,
+                                double* f) {
+  if (!scene || !x || !u || !pd) return RKH_ERR_BAD_ARG;
+  if (B == 0) return RKH_OK;
+  const int n = scene->host.n_dof;
+  hipStream_t s = scene->ctx->stream;
+  DevBuf dx, du, dpd, dM, df;
+  RKH_HIP(hipMalloc(&dx.p, size_t(B) * 2 * n * 8));
+  RKH_HIP(hipMalloc(&du.p, size_t(B) * n * 8));
+  RKH_HIP(hipMalloc(&dpd.p, size_t(B) * 2 * n * 8));
+  RKH_HIP(hipMalloc(&dM.p, size_t(B) * n * n * 8));
+  RKH_HIP(hipMalloc(&df.p, size_t(B) * n * 8));
+  RKH_HIP(hipMemcpyAsync(dx.p, x, size_t(B) * 2 * n * 8, hipMemcpyHostToDevice, s));
+  RKH_HIP(hipMemcpyAsync(du.p, u, size_t(B) * n * 8, hipMemcpyHostToDevice, s));
+  rkh_status st = launch_state_derivative(s, n, scene->d_scene, dx.as<double>(), du.as<double>(), B, dpd.as<double>(),
+                                          dM.as<double>(), df.as<double>(), scene->d_err);
+  if (st != RKH_OK) return st;
+  RKH_HIP(hipMemcpyAsync(pd, dpd.p, size_t(B) * 2 * n * 8, hipMemcpyDeviceToHost, s));
+  if (M) RKH_HIP(hipMemcpyAsync(M, dM.p, size_t(B) * n * n * 8, hipMemcpyDeviceToHost, s));
+  if (f) RKH_HIP(hipMemcpyAsync(f, df.p, size_t(B) * n * 8, hipMemcpyDeviceToHost, s));
+  RKH_HIP(hipStreamSynchronize(s));
+  return check_err_flag(scene);
+}
+
+rkh_status rkh_min_distance(rkh_scene* scene, const double* x, uint32_t B, double* dist) {
+  if (!scene || !x || !dist) return RKH_ERR_BAD_ARG;
+  if (B == 0) return RKH_OK;
+  const int n = scene->host.n_dof;
+  hipStream_t s = scene->ctx->stream;
+  DevBuf dx, dd;
+  RKH_HIP(hipMalloc(&dx.p, size_t(B) * 2 * n * 8));
+  RKH_HIP(hipMalloc(&dd.p, size_t(B) * 8));
+  RKH_HIP(hipMemcpyAsync(dx.p, x, size_t(B) * 2 * n * 8, hipMemcpyHostToDevice, s));
+  rkh_status st = launch_min_distance(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs,
+                                      dx.as<double>(), B, dd.as<double>());
+  if (st != RKH_OK) return st;
+  RKH_HIP(hipMemcpyAsync(dist, dd.p, size_t(B) * 8, hipMemcpyDeviceToHost, s));
+  RKH_HIP(hipStreamSynchronize(s));
+  return RKH_OK;
+}
+
+rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const double* a, const double* b, uint32_t B,
+                         double fraction, double* x_out, uint32_t* steps_free, double* record) {
+  if (!scene || !space || !a || !b || !x_out || !steps_free) return RKH_ERR_BAD_ARG;
+  if (space->n_dof != scene->host.n_dof) {
+    set_error("rkh_propagate: rkh_dyn_space.n_dof does not match the scene");
+    return RKH_ERR_BAD_ARG;
+  }
+  if (B == 0) return RKH_OK;
+  DynDev dyn;
+  rkh_status st = build_dyn_dev(*space, fraction, &dyn);
+  if (st != RKH_OK) return st;
+  const int n = scene->host.n_dof, D = 2 * n;
+  const int rec_stride = space->steps_per_edge + 1;
+  hipStream_t s = scene->ctx->stream;
+  DevBuf da, db, dxo, dsf, drec;
+  RKH_HIP(hipMalloc(&da.p, size_t(B) * D * 8));
+  RKH_HIP(hipMalloc(&db.p, size_t(B) * D * 8));
+  RKH_HIP(hipMalloc(&dxo.p, size_t(B) * D * 8));
+  RKH_HIP(hipMalloc(&dsf.p, size_t(B) * 4));
+  if (record) {
+    RKH_HIP(hipMalloc(&drec.p, size_t(B) * rec_stride * D * 8));
+    RKH_HIP(hipMemsetAsync(drec.p, 0, size_t(B) * rec_stride * D * 8, s));
+  }
+  RKH_HIP(hipMemcpyAsync(da.p, a, size_t(B) * D * 8, hipMemcpyHostToDevice, s));
+  RKH_HIP(hipMemcpyAsync(db.p, b, size_t(B) * D * 8, hipMemcpyHostToDevice, s));
+  EdgeIO io;
+  io.src = da.as<double>();
+  io.src_stride = D;
+  io.tgt = db.as<double>();
+  io.tgt_stride = D;
+  io.B = B;
+  io.x_out = dxo.as<double>();
+  io.steps_free = dsf.as<uint32_t>();
+  io.record = record ? drec.as<double>() : nullptr;
+  io.record_stride = rec_stride;
+  io.err_flag = scene->d_err;
+  st = launch_propagate(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, dyn, io, B);
+  if (st != RKH_OK) return st;
+  RKH_HIP(hipMemcpyAsync(x_out, dxo.p, size_t(B) * D * 8, hipMemcpyDeviceToHost, s));
+  RKH_HIP(hipMemcpyAsync(steps_free, dsf.p, size_t(B) * 4, hipMemcpyDeviceToHost, s));
+  if (record) RKH_HIP(hipMemcpyAsync(record, drec.p, size_t(B) * rec_stride * D * 8, hipMemcpyDeviceToHost, s));
+  RKH_HIP(hipStreamSynchronize(s));
+  return check_err_flag(scene);
+}
+
+rkh_status rkh_edge_check(rkh_scene*, const double*, const double*, double, const double*, const double*, uint32_t,
+                          double, double*, uint32_t*) {
+  set_error("rkh_edge_check: quasi-static edge kernel not built yet");
+  return RKH_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

@@ -1,0 +1,300 @@
+"""ctypes binding of the C-ABI in include/rkh.h (reak_amd/librkh.so = hand-written HIP kernels, gfx950).
+
+There is no CPU fallback: if the shared library is missing or the GPU is absent the calls fail loudly.
+The classes mirror the reference interfaces the kernels replace (paths relative to /root/reference/src/ReaK/):
+  HipNeighborSearch  ~ linear_neighbor_search + any_knn_synchro  (ctrl/path_planning/topological_search.hpp:529-690)
+  Scene              ~ kte_map_chain + mass_matrix_calc + proxy_query_pair_3D
+  RrtPlanner         ~ rrt_planner::solve_planning_query          (ctrl/path_planning/rrt_path_planner.tpp:66-145)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librkh.so")
+
+RKH_OK = 0
+STATUS_NAMES = {0: "RKH_OK", -1: "RKH_ERR_BAD_ARG", -2: "RKH_ERR_OOM", -3: "RKH_ERR_SINGULAR", -4: "RKH_ERR_DEVICE",
+                -5: "RKH_ERR_UNSUPPORTED", -6: "RKH_ERR_CAPACITY"}
+
+
+class RkhError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {msg}")
+        self.status = status
+
+
+class SingularityError(RkhError):
+    """singularity_error of the reference (core/lin_alg/mat_num_exceptions.hpp), status RKH_ERR_SINGULAR."""
+
+
+class PlannerStats(C.Structure):
+    _fields_ = [
+        ("num_vertices", C.c_uint64),
+        ("iterations", C.c_uint64),
+        ("edges_checked", C.c_uint64),
+        ("edges_speculated", C.c_uint64),
+        ("rounds", C.c_uint64),
+        ("num_solutions", C.c_uint64),
+        ("best_cost", C.c_double),
+        ("done", C.c_uint32),
+    ]
+
+
+EXPORTS = [
+    "rkh_last_error", "rkh_version", "rkh_ctx_create", "rkh_ctx_destroy", "rkh_ctx_synchronize", "rkh_ctx_stream",
+    "rkh_nn_create", "rkh_nn_destroy", "rkh_nn_clear", "rkh_nn_size", "rkh_nn_append", "rkh_nn_query1",
+    "rkh_nn_queryk", "rkh_nn_query1_async", "rkh_nn_queryk_async", "rkh_nn_fill_uniform", "rkh_nn_kernel_name",
+    "rkh_scene_create", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
+    "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
+    "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
+]
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into reak_amd/librkh.so (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc")], check=True,
+                   stdout=None if verbose else subprocess.DEVNULL, stderr=None if verbose else subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"{_LIB_PATH} is missing: run reak_amd.lib.build() (or __graft_entry__.build()); "
+                           "there is no CPU fallback for the HIP path")
+    lib = C.CDLL(_LIB_PATH)
+    vp, d, dp, u32, u32p, u64 = C.c_void_p, C.c_double, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint64
+    lib.rkh_last_error.restype = C.c_char_p
+    lib.rkh_version.restype = C.c_char_p
+    lib.rkh_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.rkh_ctx_destroy.argtypes = [vp]
+    lib.rkh_ctx_synchronize.argtypes = [vp]
+    lib.rkh_ctx_stream.restype = vp
+    lib.rkh_ctx_stream.argtypes = [vp]
+    lib.rkh_nn_create.argtypes = [vp, C.c_int, u64, C.POINTER(vp)]
+    lib.rkh_nn_destroy.argtypes = [vp]
+    lib.rkh_nn_clear.argtypes = [vp]
+    lib.rkh_nn_size.restype = u64
+    lib.rkh_nn_size.argtypes = [vp]
+    lib.rkh_nn_append.argtypes = [vp, dp, u64]
+    lib.rkh_nn_query1.argtypes = [vp, dp, u32, u32p, dp]
+    lib.rkh_nn_queryk.argtypes = [vp, dp, u32, u32, d, u32p, dp, u32p]
+    lib.rkh_nn_query1_async.argtypes = [vp, vp, u32, vp, vp]
+    lib.rkh_nn_queryk_async.argtypes = [vp, vp, u32, u32, d, vp, vp, vp]
+    lib.rkh_nn_fill_uniform.argtypes = [vp, u64, u64]
+    lib.rkh_nn_kernel_name.restype = C.c_char_p
+    lib.rkh_scene_create.argtypes = [vp, C.POINTER(T.KteOp), C.c_int, C.POINTER(T.ChainBase), C.POINTER(T.Shape), C.c_int,
+                                     C.POINTER(vp)]
+    lib.rkh_scene_destroy.argtypes = [vp]
+    lib.rkh_scene_num_dof.argtypes = [vp]
+    lib.rkh_scene_num_pairs.argtypes = [vp]
+    lib.rkh_state_derivative.argtypes = [vp, dp, dp, u32, dp, dp, dp]
+    lib.rkh_min_distance.argtypes = [vp, dp, u32, dp]
+    lib.rkh_propagate.argtypes = [vp, C.POINTER(T.DynSpace), dp, dp, u32, d, dp, u32p, dp]
+    lib.rkh_edge_check.argtypes = [vp, dp, dp, d, dp, dp, u32, d, dp, u32p]
+    lib.rkh_planner_create.argtypes = [vp, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), C.POINTER(vp)]
+    lib.rkh_planner_destroy.argtypes = [vp]
+    lib.rkh_planner_enqueue.argtypes = [vp, u32]
+    lib.rkh_planner_sync.argtypes = [vp, C.POINTER(PlannerStats)]
+    lib.rkh_planner_solve.argtypes = [vp, C.POINTER(PlannerStats)]
+    lib.rkh_planner_get_tree.argtypes = [vp, dp, u32p, u32p, C.POINTER(C.c_uint8), dp]
+    lib.rkh_planner_stream.restype = vp
+    lib.rkh_planner_stream.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def _check(status):
+    if status != RKH_OK:
+        msg = load().rkh_last_error().decode()
+        if status == -3:
+            raise SingularityError(status, msg)
+        raise RkhError(status, msg)
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = load()
+        self.h = C.c_void_p()
+        _check(self.lib.rkh_ctx_create(device, C.byref(self.h)))
+        self.device = device
+
+    def synchronize(self):
+        _check(self.lib.rkh_ctx_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.rkh_ctx_stream(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.rkh_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipNeighborSearch:
+    """Exact brute-force NN over a growing vertex set kept in HBM (NNFinder + KNN synchro)."""
+
+    def __init__(self, ctx, dims, capacity):
+        self.ctx, self.lib, self.D = ctx, ctx.lib, dims
+        self.h = C.c_void_p()
+        _check(self.lib.rkh_nn_create(ctx.h, dims, capacity, C.byref(self.h)))
+
+    def __len__(self):
+        return int(self.lib.rkh_nn_size(self.h))
+
+    def added_vertices(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, self.D)
+        _check(self.lib.rkh_nn_append(self.h, T.dptr(pts), pts.shape[0]))
+
+    def clear(self):
+        _check(self.lib.rkh_nn_clear(self.h))
+
+    def fill_uniform(self, n, seed=1):
+        _check(self.lib.rkh_nn_fill_uniform(self.h, n, seed))
+
+    def nearest(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, self.D)
+        B = q.shape[0]
+        idx = np.zeros(B, dtype=np.uint32)
+        dist = np.zeros(B)
+        _check(self.lib.rkh_nn_query1(self.h, T.dptr(q), B, T.u32ptr(idx), T.dptr(dist)))
+        return idx, dist
+
+    def nearest_async(self, d_q, B, d_idx, d_dist):
+        _check(self.lib.rkh_nn_query1_async(self.h, d_q, B, d_idx, d_dist))
+
+    def k_nearest(self, q, k, radius=np.inf):
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, self.D)
+        B = q.shape[0]
+        idx = np.zeros((B, k), dtype=np.uint32)
+        dist = np.zeros((B, k))
+        cnt = np.zeros(B, dtype=np.uint32)
+        _check(self.lib.rkh_nn_queryk(self.h, T.dptr(q), B, k, float(radius), T.u32ptr(idx), T.dptr(dist), T.u32ptr(cnt)))
+        return idx, dist, cnt
+
+    def close(self):
+        if self.h:
+            self.lib.rkh_nn_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scene:
+    def __init__(self, ctx, scn):
+        self.ctx, self.lib, self.scn = ctx, ctx.lib, scn
+        self.n, self.D = scn.n_dof, 2 * scn.n_dof
+        self._ops = scn.ops_array()
+        self._shapes = scn.shapes_array() if scn.shapes else (T.Shape * 1)()
+        self.h = C.c_void_p()
+        _check(self.lib.rkh_scene_create(ctx.h, self._ops, len(scn.ops), C.byref(scn.base), self._shapes, len(scn.shapes),
+                                         C.byref(self.h)))
+
+    @property
+    def num_pairs(self):
+        return self.lib.rkh_scene_num_pairs(self.h)
+
+    def state_derivative(self, x, u):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.D)
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(-1, self.n)
+        B = x.shape[0]
+        pd, M, f = np.zeros((B, self.D)), np.zeros((B, self.n, self.n)), np.zeros((B, self.n))
+        _check(self.lib.rkh_state_derivative(self.h, T.dptr(x), T.dptr(u), B, T.dptr(pd), T.dptr(M), T.dptr(f)))
+        return pd, M, f
+
+    def min_distance(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.D)
+        d = np.zeros(x.shape[0])
+        _check(self.lib.rkh_min_distance(self.h, T.dptr(x), x.shape[0], T.dptr(d)))
+        return d
+
+    def steer_position_toward(self, a, b, fraction=1.0, record=False, dyn=None):
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, self.D)
+        b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1, self.D)
+        dyn = dyn if dyn is not None else self.scn.dyn
+        B = a.shape[0]
+        out = np.zeros_like(a)
+        steps = np.zeros(B, dtype=np.uint32)
+        rec = np.zeros((B, dyn.steps_per_edge + 1, self.D)) if record else None
+        _check(self.lib.rkh_propagate(self.h, C.byref(dyn), T.dptr(a), T.dptr(b), B, float(fraction), T.dptr(out),
+                                      T.u32ptr(steps), T.dptr(rec) if record else None))
+        return out, steps, rec
+
+    def close(self):
+        if self.h:
+            self.lib.rkh_scene_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RrtPlanner:
+    def __init__(self, scene, prm, dyn=None):
+        self.scene, self.lib = scene, scene.lib
+        self.dyn = dyn if dyn is not None else scene.scn.dyn
+        self.prm = prm
+        self.h = C.c_void_p()
+        _check(self.lib.rkh_planner_create(scene.h, C.byref(self.dyn), C.byref(prm), C.byref(self.h)))
+        self.stats = PlannerStats()
+
+    @property
+    def stream(self):
+        return self.lib.rkh_planner_stream(self.h)
+
+    def enqueue(self, rounds):
+        _check(self.lib.rkh_planner_enqueue(self.h, rounds))
+
+    def sync(self):
+        _check(self.lib.rkh_planner_sync(self.h, C.byref(self.stats)))
+        return self.stats
+
+    def solve_planning_query(self):
+        _check(self.lib.rkh_planner_solve(self.h, C.byref(self.stats)))
+        return self.stats
+
+    def tree(self):
+        nv, it, D = int(self.stats.num_vertices), int(self.stats.iterations), self.scene.D
+        pos = np.zeros((nv, D))
+        parent = np.zeros(nv, dtype=np.uint32)
+        nn_seq = np.zeros(max(it, 1), dtype=np.uint32)
+        accept = np.zeros(max(it, 1), dtype=np.uint8)
+        gd = np.zeros(max(nv - 1, 1))
+        _check(self.lib.rkh_planner_get_tree(self.h, T.dptr(pos), T.u32ptr(parent), T.u32ptr(nn_seq),
+                                             accept.ctypes.data_as(C.POINTER(C.c_uint8)), T.dptr(gd)))
+        return {"pos": pos, "parent": parent, "nn_seq": nn_seq[:it], "accept": accept[:it], "goal_dist": gd[: nv - 1]}
+
+    def close(self):
+        if self.h:
+            self.lib.rkh_planner_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

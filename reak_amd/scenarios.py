@@ -1,0 +1,176 @@
+"""Synthetic planning scenarios: KTE chains, obstacle worlds, dynamic spaces.
+
+Everything is generated from a 64-bit seed with numpy's PCG64 (no files from the reference).
+The chain follows the blueprint of ReaK's 6-R dynamic model
+(examples/robot_airship/old/CRS_A465_models.cpp:318-790): per joint, in kte_map_chain order,
+driving_actuator_gen -> inertia_gen (rotor) -> revolute_joint_3D -> rigid_link_3D -> inertia_3D.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import types as T
+
+
+@dataclass
+class Scenario:
+    name: str
+    ops: list
+    base: T.ChainBase
+    shapes: list
+    dyn: T.DynSpace
+    n_dof: int
+    n_frames: int
+    start: np.ndarray
+    goal: np.ndarray
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def D(self):
+        return 2 * self.n_dof
+
+    def ops_array(self):
+        return T.as_array(self.ops, T.KteOp)
+
+    def shapes_array(self):
+        return T.as_array(self.shapes, T.Shape)
+
+    def rrt_params(self, seed=1, max_vertices=1000, max_results=1 << 30, steer_tol=0.1, conn_tol=0.05):
+        p = T.RrtParams()
+        p.seed = seed
+        p.max_vertices = max_vertices
+        p.max_results = max_results
+        p.steer_tol = steer_tol
+        p.conn_tol = conn_tol
+        for i in range(self.D):
+            p.start[i] = float(self.start[i])
+            p.goal[i] = float(self.goal[i])
+        return p
+
+
+def serial_chain_ops(axes, link_offsets, link_masses, link_inertias, joint_inertias):
+    """Flatten a serial revolute chain into kte_map_chain order.  Frame 0 is the base;
+    joint j: revolute base=2j, end=2j+1 ; link base=2j+1, end=2j+2 ; inertia_3D on frame 2j+2."""
+    ops = []
+    n = len(axes)
+    for j in range(n):
+        rev_index = 5 * j + 2
+        a = T.KteOp(kind=T.KTE_DRIVING_ACTUATOR_GEN, coord=j, base_frame=-1, end_frame=-1, joint_op=rev_index)
+        ops.append(a)
+        g = T.KteOp(kind=T.KTE_INERTIA_GEN, coord=j, base_frame=-1, end_frame=-1, joint_op=-1,
+                    upstream=(1 << j), mass=float(joint_inertias[j]))
+        ops.append(g)
+        r = T.KteOp(kind=T.KTE_REVOLUTE_JOINT_3D, coord=j, base_frame=2 * j, end_frame=2 * j + 1, joint_op=-1)
+        r.axis[:] = [float(v) for v in axes[j]]
+        ops.append(r)
+        l = T.KteOp(kind=T.KTE_RIGID_LINK_3D, coord=-1, base_frame=2 * j + 1, end_frame=2 * j + 2, joint_op=-1)
+        l.offset = T.make_pose(link_offsets[j])
+        ops.append(l)
+        i3 = T.KteOp(kind=T.KTE_INERTIA_3D, coord=-1, base_frame=-1, end_frame=2 * j + 2, joint_op=-1,
+                     upstream=(1 << (j + 1)) - 1, mass=float(link_masses[j]))
+        i3.inertia[:] = [float(v) for v in link_inertias[j]]
+        ops.append(i3)
+    return ops
+
+
+def _random_unit_quat(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return q
+
+
+def _dist_point_segment(p, a, b):
+    ab = b - a
+    t = np.clip(np.dot(p - a, ab) / np.dot(ab, ab), 0.0, 1.0)
+    return np.linalg.norm(p - (a + t * ab))
+
+
+def crs_like_chain():
+    """6-R arm, CRS-A465-like geometry (all links along local z)."""
+    axes = [(0, 0, 1), (0, -1, 0), (0, -1, 0), (0, 0, 1), (0, -1, 0), (0, 0, 1)]
+    lengths = [0.33, 0.305, 0.15, 0.18, 0.076, 0.06]
+    offsets = [(0.0, 0.0, L) for L in lengths]
+    masses = [5.0, 4.0, 3.0, 2.0, 1.5, 1.0]
+    inertias = [  # (a11,a12,a13,a22,a23,a33)
+        (0.10, 0, 0, 0.10, 0, 0.05),
+        (0.08, 0, 0, 0.08, 0, 0.02),
+        (0.05, 0, 0, 0.05, 0, 0.01),
+        (0.03, 0, 0, 0.03, 0, 0.01),
+        (0.02, 0, 0, 0.02, 0, 0.01),
+        (0.01, 0, 0, 0.01, 0, 0.01),
+    ]
+    joint_inertias = [1.0] * 6
+    return axes, lengths, offsets, masses, inertias, joint_inertias
+
+
+def make_c2(world_seed=1, n_obstacles=50, capsule_radius=0.05, steps_per_edge=20, dt=1e-3):
+    """BASELINE config C2: 6-DOF revolute KTE chain, RK4 dt=1e-3 x 20 steps/edge, 50 convex obstacles."""
+    rng = np.random.Generator(np.random.PCG64(world_seed))
+    axes, lengths, offsets, masses, inertias, joint_inertias = crs_like_chain()
+    n = len(axes)
+    ops = serial_chain_ops(axes, offsets, masses, inertias, joint_inertias)
+    base = T.ChainBase()
+    base.pose = T.make_pose()
+    base.acceleration[:] = [0.0, 0.0, 9.81]  # gravity as base acceleration (mbd_kte/test_bm.cpp:52)
+
+    shapes = []
+    # robot model: one capsule per link, anchored on the joint's end frame, centred half-way along the link
+    for j in range(n):
+        s = T.Shape(kind=T.SHAPE_CCYLINDER, anchor=2 * j + 1)
+        s.pose = T.make_pose((0.0, 0.0, 0.5 * lengths[j]))
+        s.dims[:] = [lengths[j], capsule_radius, 0.0]
+        shapes.append(s)
+    # environment model: spheres / boxes / capsules in a 2 m cube, kept clear of the start pose
+    reach_top = np.array([0.0, 0.0, sum(lengths)])
+    origin = np.zeros(3)
+    kinds = []
+    while len(kinds) < n_obstacles:
+        kind = [T.SHAPE_SPHERE, T.SHAPE_BOX, T.SHAPE_CCYLINDER][int(rng.integers(0, 3))]
+        c = rng.uniform([-1.0, -1.0, -0.4], [1.0, 1.0, 1.6])
+        s = T.Shape(kind=kind, anchor=-1)
+        if kind == T.SHAPE_SPHERE:
+            r = rng.uniform(0.05, 0.2)
+            dims, brad, quat = [r, 0.0, 0.0], r, (1.0, 0.0, 0.0, 0.0)
+        elif kind == T.SHAPE_BOX:
+            d = rng.uniform(0.1, 0.4, size=3)
+            dims, brad, quat = list(d), 0.5 * np.linalg.norm(d), _random_unit_quat(rng)
+        else:
+            L, r = rng.uniform(0.1, 0.4), rng.uniform(0.03, 0.1)
+            dims, brad, quat = [L, r, 0.0], 0.5 * L + r, _random_unit_quat(rng)
+        if _dist_point_segment(c, origin, reach_top) < brad + capsule_radius + 0.25:
+            continue  # keep-out around the start pose (arm straight up) and the base column
+        s.pose = T.make_pose(c, quat)
+        s.dims[:] = [float(v) for v in dims]
+        shapes.append(s)
+        kinds.append(kind)
+
+    dyn = T.DynSpace()
+    dyn.n_dof = n
+    dyn.steps_per_edge = steps_per_edge
+    dyn.dt = dt
+    dyn.kp, dyn.kd, dyn.u_max = 50.0, 10.0, 50.0
+    dyn.goal_tol = 1e-3
+    for j in range(n):
+        dyn.lower[2 * j], dyn.upper[2 * j] = -np.pi, np.pi
+        dyn.lower[2 * j + 1], dyn.upper[2 * j + 1] = -2.0, 2.0
+    start = np.zeros(2 * n)
+    goal = np.zeros(2 * n)
+    goal[0::2] = [1.5, 0.9, -0.8, 0.5, 0.7, -0.3]
+    return Scenario(name="C2", ops=ops, base=base, shapes=shapes, dyn=dyn, n_dof=n, n_frames=2 * n + 1,
+                    start=start, goal=goal,
+                    meta={"world_seed": world_seed, "n_obstacles": n_obstacles, "obstacle_kinds": kinds})
+
+
+def make_pendulum(length=0.5, mass=1.0):
+    """1-link pendulum (3D restatement of ctrl/mbd_kte/test_bm.cpp:45-77): revolute about -y at the
+    origin, link of `length` along x, point mass at the tip, gravity as base acceleration +z."""
+    ops = serial_chain_ops([(0, -1, 0)], [(length, 0.0, 0.0)], [mass], [(0, 0, 0, 0, 0, 0)], [0.0])
+    base = T.ChainBase()
+    base.pose = T.make_pose()
+    base.acceleration[:] = [0.0, 0.0, 9.81]
+    dyn = T.DynSpace()
+    dyn.n_dof, dyn.steps_per_edge, dyn.dt = 1, 20, 1e-3
+    dyn.kp, dyn.kd, dyn.u_max, dyn.goal_tol = 0.0, 0.0, 1e9, 0.0
+    dyn.lower[0], dyn.upper[0], dyn.lower[1], dyn.upper[1] = -1e9, 1e9, -1e9, 1e9
+    return Scenario(name="pendulum", ops=ops, base=base, shapes=[], dyn=dyn, n_dof=1, n_frames=3,
+                    start=np.zeros(2), goal=np.zeros(2))

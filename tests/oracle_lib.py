@@ -1,0 +1,200 @@
+"""ctypes access to the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by reak_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from reak_amd import types as T
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+
+
+class RrtOut(C.Structure):
+    _fields_ = [
+        ("num_vertices", C.c_uint64),
+        ("iterations", C.c_uint64),
+        ("num_solutions", C.c_uint64),
+        ("edges_checked", C.c_uint64),
+        ("states_checked", C.c_uint64),
+        ("f_evals", C.c_uint64),
+        ("pair_tests", C.c_uint64),
+        ("best_cost", C.c_double),
+        ("seconds", C.c_double),
+    ]
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _ORACLE_DIR], check=True)
+
+
+_libs = {}
+
+
+def load(fast=False):
+    name = "liboracle_fast.so" if fast else "liboracle.so"
+    if name in _libs:
+        return _libs[name]
+    path = os.path.join(_ORACLE_DIR, name)
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    d, dp, u32p = C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint32)
+    lib.orc_mt19937_nth.restype = C.c_uint32
+    lib.orc_mt19937_nth.argtypes = [C.c_uint32, C.c_uint32]
+    lib.orc_sample_hyperbox.argtypes = [C.c_uint32, dp, dp, C.c_int, C.c_int, dp]
+    lib.orc_euclid.restype = d
+    lib.orc_euclid.argtypes = [dp, dp, C.c_int]
+    lib.orc_nn1.argtypes = [dp, C.c_int, dp, C.c_uint64, C.c_int, u32p, dp]
+    lib.orc_knn.argtypes = [dp, C.c_int, dp, C.c_uint64, C.c_int, C.c_uint32, d, u32p, dp, u32p]
+    lib.orc_star_neighborhood.argtypes = [C.c_uint64, d, d, C.POINTER(C.c_uint64), dp]
+    lib.orc_highest_set_bit.restype = C.c_uint64
+    lib.orc_highest_set_bit.argtypes = [C.c_uint64]
+    lib.orc_quat_mul.argtypes = [dp, dp, dp]
+    lib.orc_quat_rotmat.argtypes = [dp, dp]
+    lib.orc_quat_rotate.argtypes = [dp, dp, dp]
+    lib.orc_quat_from_vector.argtypes = [dp, dp]
+    lib.orc_axis_angle_quat.argtypes = [d, dp, dp]
+    lib.orc_axis_angle_rotmat.argtypes = [d, dp, dp]
+    lib.orc_cholesky_solve.argtypes = [dp, dp, C.c_int, d]
+    lib.orc_cholesky_decompose.argtypes = [dp, dp, C.c_int, d]
+    lib.orc_rk4_ivp.argtypes = [C.c_int, dp, C.c_int, d, d, d, dp]
+    lib.orc_scene_create.restype = C.c_void_p
+    lib.orc_scene_create.argtypes = [C.POINTER(T.KteOp), C.c_int, C.POINTER(T.ChainBase), C.POINTER(T.Shape), C.c_int]
+    lib.orc_scene_destroy.argtypes = [C.c_void_p]
+    lib.orc_scene_num_frames.argtypes = [C.c_void_p]
+    lib.orc_scene_num_finders.argtypes = [C.c_void_p]
+    lib.orc_state_derivative.argtypes = [C.c_void_p, dp, dp, C.c_int, dp, dp, dp]
+    lib.orc_fk.argtypes = [C.c_void_p, dp, C.c_int, dp]
+    lib.orc_min_distance.argtypes = [C.c_void_p, dp, C.c_int, dp]
+    lib.orc_pair_distance.restype = d
+    lib.orc_pair_distance.argtypes = [C.POINTER(T.Shape), C.POINTER(T.Shape)]
+    lib.orc_rk4_step.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), dp, dp, C.c_int, d, dp]
+    lib.orc_steer.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), dp, dp, C.c_int, d, dp, u32p, dp]
+    lib.orc_rrt_dyn.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtOut)]
+    lib.orc_rrt_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtOut)]
+    lib.orc_qs_move.argtypes = [C.c_void_p, C.c_int, dp, dp, d, dp, dp, C.c_int, d, dp, u32p]
+    lib.orc_rrt_copy.argtypes = [dp, u32p, u32p, C.POINTER(C.c_uint8), dp]
+    _libs[name] = lib
+    return lib
+
+
+class OracleScene:
+    """A KTE chain + proxy environment held by the oracle."""
+
+    def __init__(self, scn, fast=False):
+        self.lib = load(fast)
+        self.scn = scn
+        self._ops = scn.ops_array()
+        self._shapes = scn.shapes_array() if scn.shapes else (T.Shape * 1)()
+        self.h = self.lib.orc_scene_create(self._ops, len(scn.ops), C.byref(scn.base), self._shapes, len(scn.shapes))
+        self.n = scn.n_dof
+        self.D = 2 * scn.n_dof
+
+    def __del__(self):
+        try:
+            self.lib.orc_scene_destroy(self.h)
+        except Exception:
+            pass
+
+    def state_derivative(self, x, u):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.D)
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(-1, self.n)
+        B = x.shape[0]
+        pd = np.zeros((B, self.D))
+        M = np.zeros((B, self.n, self.n))
+        f = np.zeros((B, self.n))
+        rc = self.lib.orc_state_derivative(self.h, T.dptr(x), T.dptr(u), B, T.dptr(pd), T.dptr(M), T.dptr(f))
+        return rc, pd, M, f
+
+    def fk(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.D)
+        nf = self.lib.orc_scene_num_frames(self.h)
+        out = np.zeros((x.shape[0], nf, 7))
+        self.lib.orc_fk(self.h, T.dptr(x), x.shape[0], T.dptr(out))
+        return out
+
+    def min_distance(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.D)
+        d = np.zeros(x.shape[0])
+        self.lib.orc_min_distance(self.h, T.dptr(x), x.shape[0], T.dptr(d))
+        return d
+
+    def rk4_step(self, x, u, t=0.0):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.D)
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(-1, self.n)
+        xn = np.zeros_like(x)
+        rc = self.lib.orc_rk4_step(self.h, C.byref(self.scn.dyn), T.dptr(x), T.dptr(u), x.shape[0], float(t), T.dptr(xn))
+        return rc, xn
+
+    def steer(self, a, b, fraction=1.0, record=False):
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, self.D)
+        b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1, self.D)
+        B = a.shape[0]
+        out = np.zeros_like(a)
+        steps = np.zeros(B, dtype=np.uint32)
+        rec = np.zeros((B, self.scn.dyn.steps_per_edge + 1, self.D)) if record else None
+        rc = self.lib.orc_steer(self.h, C.byref(self.scn.dyn), T.dptr(a), T.dptr(b), B, float(fraction), T.dptr(out),
+                                T.u32ptr(steps), T.dptr(rec) if record else None)
+        return rc, out, steps, rec
+
+    def rrt_dyn(self, prm, max_iterations=-1):
+        out = RrtOut()
+        rc = self.lib.orc_rrt_dyn(self.h, C.byref(self.scn.dyn), C.byref(prm), int(max_iterations), C.byref(out))
+        return rc, out, self._copy_rrt(out, self.D)
+
+    def rrt_qs(self, lower, upper, min_interval, prm, max_iterations=-1):
+        lower = np.ascontiguousarray(lower, dtype=np.float64)
+        upper = np.ascontiguousarray(upper, dtype=np.float64)
+        out = RrtOut()
+        rc = self.lib.orc_rrt_qs(self.h, len(lower), T.dptr(lower), T.dptr(upper), float(min_interval), C.byref(prm),
+                                 int(max_iterations), C.byref(out))
+        return rc, out, self._copy_rrt(out, len(lower))
+
+    def qs_move(self, lower, upper, min_interval, a, b, fraction=1.0):
+        lower = np.ascontiguousarray(lower, dtype=np.float64)
+        upper = np.ascontiguousarray(upper, dtype=np.float64)
+        D = len(lower)
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, D)
+        b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1, D)
+        out = np.zeros_like(a)
+        nchk = np.zeros(a.shape[0], dtype=np.uint32)
+        self.lib.orc_qs_move(self.h, D, T.dptr(lower), T.dptr(upper), float(min_interval), T.dptr(a), T.dptr(b),
+                             a.shape[0], float(fraction), T.dptr(out), T.u32ptr(nchk))
+        return out, nchk
+
+    def _copy_rrt(self, out, D):
+        nv, it = int(out.num_vertices), int(out.iterations)
+        pos = np.zeros((nv, D))
+        parent = np.zeros(nv, dtype=np.uint32)
+        nn_seq = np.zeros(max(it, 1), dtype=np.uint32)
+        accept = np.zeros(max(it, 1), dtype=np.uint8)
+        goal_dist = np.zeros(max(nv - 1, 1))
+        self.lib.orc_rrt_copy(T.dptr(pos), T.u32ptr(parent), T.u32ptr(nn_seq),
+                              accept.ctypes.data_as(C.POINTER(C.c_uint8)), T.dptr(goal_dist))
+        return {"pos": pos, "parent": parent, "nn_seq": nn_seq[:it], "accept": accept[:it], "goal_dist": goal_dist[: nv - 1]}
+
+
+def nn1(q, pts, fast=False):
+    lib = load(fast)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    B, D = q.shape
+    idx = np.zeros(B, dtype=np.uint32)
+    dist = np.zeros(B)
+    lib.orc_nn1(T.dptr(q), B, T.dptr(pts), pts.shape[0], D, T.u32ptr(idx), T.dptr(dist))
+    return idx, dist
+
+
+def knn(q, pts, k, radius=np.inf, fast=False):
+    lib = load(fast)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    B, D = q.shape
+    idx = np.zeros((B, k), dtype=np.uint32)
+    dist = np.zeros((B, k))
+    cnt = np.zeros(B, dtype=np.uint32)
+    lib.orc_knn(T.dptr(q), B, T.dptr(pts), pts.shape[0], D, k, float(radius), T.u32ptr(idx), T.dptr(dist), T.u32ptr(cnt))
+    return idx, dist, cnt
