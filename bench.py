@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on BASELINE config C2.
+
+Workload (config.workload = "C2"): 6-DOF revolute KTE chain, RRT with RK4 forward-dynamics propagation
+(dt = 1e-3, 20 steps/edge), 50 convex obstacles, goal probe per added vertex, run to --max-vertices.
+One *step* = one complete rrt_planner::solve_planning_query pass for the rank's independent problems
+(--problems seeds per GPU, each bit-for-bit the sequential planner on its seed).  `value` = valid node
+expansions per second over all ranks (vertices added / wall time, max over ranks); edges-collision-checked/s
+is reported next to it.  Inputs (scene, sample stream chunks) are device-resident before the timed region.
+
+Multi-GPU: independent seeds shard across ranks ("scaling": "weak"), no data-path collective; after the timed
+region one all-reduce(min) of the best solution cost and all-reduce(sum) of the counters.
+
+Extra objects on the JSON line:
+  roofline      NN-sweep kernel of the timed region, HIP-event timed on the planner streams
+                (algorithmic bytes n*D*8 per launch); peak 8 TB/s HBM3E.
+  nn_sweep_hbm  the same kernel in its HBM-bound regime (tree larger than the 256 MiB Infinity Cache, 8 queries
+                per sweep), measured outside the timed region
+  cpu_baseline  the CPU oracle (restatement of the reference planner, -O3 -march=native) on a bounded sample of the
+                same workload, single thread like ReaK itself
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+
+def hip_runtime():
+    for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            return C.CDLL(name)
+        except OSError:
+            continue
+    raise RuntimeError("libamdhip64.so not found")
+
+
+class HipEvents:
+    """HIP events recorded on an explicit stream (torch.cuda.Event only sees torch's current stream)."""
+
+    def __init__(self):
+        self.hip = hip_runtime()
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+
+    def create(self):
+        ev = C.c_void_p()
+        assert self.hip.hipEventCreate(C.byref(ev)) == 0
+        return ev
+
+    def record(self, ev, stream):
+        assert self.hip.hipEventRecord(ev, C.c_void_p(stream)) == 0
+
+    def elapsed_ms(self, a, b):
+        self.hip.hipEventSynchronize(b)
+        ms = C.c_float()
+        assert self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
+        return float(ms.value)
+
+
+def nn_sweep_microbench(lib, ctx, events, n_rows, B, reps):
+    """HBM-bound regime of the NN sweep: n_rows x 12 fp64 (> 256 MiB), B queries per sweep."""
+    D = 12
+    nn = lib.HipNeighborSearch(ctx, D, n_rows)
+    nn.fill_uniform(n_rows, seed=7)
+    import torch
+
+    q = torch.rand(B, D, dtype=torch.float64, device="cuda")
+    idx = torch.zeros(B, dtype=torch.int32, device="cuda")
+    dist = torch.zeros(B, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        nn.nearest_async(q.data_ptr(), B, idx.data_ptr(), dist.data_ptr())
+    ctx.synchronize()
+    a, b = events.create(), events.create()
+    events.record(a, ctx.stream)
+    for _ in range(reps):
+        nn.nearest_async(q.data_ptr(), B, idx.data_ptr(), dist.data_ptr())
+    events.record(b, ctx.stream)
+    ms = events.elapsed_ms(a, b) / reps  # sweep + its tiny reduce kernel
+    bytes_per_sweep = n_rows * D * 8
+    gbps = bytes_per_sweep / (ms * 1e-3) / 1e9
+    nn.close()
+    return {"bound": "hbm", "n": n_rows, "dims": D, "queries_per_sweep": B, "ms_per_sweep": ms, "achieved": gbps,
+            "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "queries_per_s": B / (ms * 1e-3)}
+
+
+def cpu_baseline(scn, seconds_target=15.0):
+    """Oracle (kind 'port': the reference cannot be built here) on a bounded sample."""
+    import oracle_lib
+
+    osc = oracle_lib.OracleScene(scn, fast=True)
+    nv = 1500
+    rc, out, _ = osc.rrt_dyn(scn.rrt_params(seed=1, max_vertices=nv))
+    rate = out.num_vertices / out.seconds
+    nv2 = int(min(20000, max(nv, rate * seconds_target)))
+    rc, out, _ = osc.rrt_dyn(scn.rrt_params(seed=1, max_vertices=nv2))
+    assert rc == 0
+    return {"value": (out.num_vertices - 1) / out.seconds, "unit": "valid node expansions/s", "cores": 1, "kind": "port",
+            "edges_checked_per_s": out.edges_checked / out.seconds,
+            "sample": f"seed 1 of the same C2 world, first {nv2} vertices ({out.iterations} iterations, "
+                      f"{out.seconds:.1f} s), oracle -O3 -march=native, 1 thread (ReaK is single-threaded)",
+            "note": "ReaK planner, CPU restatement (reference binary unavailable: needs Boost + BGL-Extra)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--problems", type=int, default=int(os.environ.get("RKH_BENCH_PROBLEMS", "8")))
+    ap.add_argument("--max-vertices", type=int, default=100000)
+    ap.add_argument("--rounds-per-sync", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-microbench", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from reak_amd import lib, scenarios
+
+    os.environ.setdefault("RKH_PROFILE_NN", "1")
+    ctx = lib.Context(local_rank)
+    events = HipEvents()
+    scn = scenarios.make_c2(world_seed=1)
+    scene = lib.Scene(ctx, scn)
+    P = args.problems
+
+    def run_step(step_index, timed):
+        seeds = [1 + (step_index * world + rank) * P + i for i in range(P)]
+        planners = [lib.RrtPlanner(scene, scn.rrt_params(seed=s, max_vertices=args.max_vertices)) for s in seeds]
+        for pl in planners:  # sample chunks resident before the clock starts
+            pl.enqueue(0)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        active = list(planners)
+        while active:
+            for pl in active:
+                pl.enqueue(args.rounds_per_sync)
+            nxt = []
+            for pl in active:
+                if not pl.sync().done:
+                    nxt.append(pl)
+            active = nxt
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nodes = sum(int(pl.stats.num_vertices) - 1 for pl in planners)
+        edges = sum(int(pl.stats.edges_checked) for pl in planners)
+        spec = sum(int(pl.stats.edges_speculated) for pl in planners)
+        rounds = sum(int(pl.stats.rounds) for pl in planners)
+        best = min(float(pl.stats.best_cost) for pl in planners)
+        prof = [pl.nn_profile() for pl in planners]
+        for pl in planners:
+            pl.close()
+        return {"seconds": t1 - t0, "nodes": nodes, "edges": edges, "spec": spec, "rounds": rounds, "best": best,
+                "nn_ms": sum(p[0] for p in prof), "nn_bytes": sum(p[1] for p in prof), "nn_launches": sum(p[2] for p in prof)}
+
+    for w in range(args.warmup):
+        run_step(1000 + w, False)
+    tot = {"seconds": 0.0, "nodes": 0, "edges": 0, "spec": 0, "rounds": 0, "nn_ms": 0.0, "nn_bytes": 0, "nn_launches": 0}
+    best = float("inf")
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_begin = time.perf_counter()
+    for k in range(args.steps):
+        r = run_step(k, True)
+        for key in tot:
+            tot[key] += r[key]
+        best = min(best, r["best"])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_begin
+
+    nodes_all, edges_all, spec_all = tot["nodes"], tot["edges"], tot["spec"]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([nodes_all, edges_all, spec_all], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)  # tree-size / edge counters
+        nodes_all, edges_all, spec_all = (int(v) for v in c.tolist())
+        bc = torch.tensor([best], dtype=torch.float64, device="cuda")
+        dist.all_reduce(bc, op=dist.ReduceOp.MIN)  # best solution cost over all seeds
+        best = float(bc.item())
+
+    if rank == 0:
+        nn_gbps = (tot["nn_bytes"] / (tot["nn_ms"] * 1e-3) / 1e9) if tot["nn_ms"] > 0 else 0.0
+        out = {
+            "metric": "valid RRT node-expansions/sec (+ edges-collision-checked/sec)",
+            "value": nodes_all / elapsed,
+            "unit": "valid node expansions/s",
+            "edges_collision_checked_per_s": edges_all / elapsed,
+            "edges_propagated_per_s": spec_all / elapsed,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / max(1, args.steps) * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C2: 6-DOF revolute KTE chain, RRT + RK4 dynamics (dt=1e-3, 20 steps/edge), 50 convex "
+                                   "obstacles, goal probe per vertex, LINEAR_SEARCH_KNN semantics",
+                       "max_vertices": args.max_vertices, "problems_per_gpu": P, "seeds": "independent per problem",
+                       "parallelism": f"{world} x {P} independent planners"},
+            "rounds": tot["rounds"],
+            "speculation_efficiency": (tot["edges"] / tot["spec"]) if tot["spec"] else None,
+            "best_solution_cost": None if best == float("inf") else best,
+            "roofline": {"kernel": "nn1_sweep_kernel", "bound": "hbm", "achieved": nn_gbps, "peak": 8000.0, "unit": "GB/s",
+                         "frac": nn_gbps / 8000.0, "traffic": None, "launches": tot["nn_launches"],
+                         "avg_launch_us": (tot["nn_ms"] * 1e3 / tot["nn_launches"]) if tot["nn_launches"] else None,
+                         "note": "rank-0 sweeps of the timed region; each sweep serves a whole speculative batch of "
+                                 "queries, so it is fp64-VALU-bound by design (see nn_sweep_hbm for the HBM-bound regime)"},
+        }
+        if not args.no_microbench:
+            out["nn_sweep_hbm"] = nn_sweep_microbench(lib, ctx, events, 4 * 1024 * 1024, 8, 20)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scn)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

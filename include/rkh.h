@@ -145,6 +145,9 @@ rkh_status rkh_planner_solve(rkh_planner* p, rkh_planner_stats* stats);
 rkh_status rkh_planner_get_tree(rkh_planner* p, double* pos, uint32_t* parent, uint32_t* nn_seq, uint8_t* accept,
                                 double* goal_dist);
 void* rkh_planner_stream(rkh_planner* p);
+/* With RKH_PROFILE_NN=1 in the environment at rkh_planner_create, every round brackets its NN sweep kernel with
+ * HIP events on the planner stream: total kernel time, algorithmic bytes (n*D*8 per sweep) and launch count. */
+rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* total_bytes, uint64_t* launches);
 
 #ifdef __cplusplus
 }

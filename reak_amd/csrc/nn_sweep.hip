@@ -193,7 +193,7 @@ const char* nn_last_kernel_name() { return g_last_kernel; }
 template <int DP>
 static rkh_status launch_nn1_dp(hipStream_t s, const NnStore& st, uint64_t n, const uint32_t* d_n, const double* d_q,
                                 const uint32_t* d_qoff, uint32_t B, const uint32_t* d_B, uint32_t* d_idx, double* d_dist, double* d_part_dist,
-                                uint32_t* d_part_idx, uint32_t part_capacity_blocks) {
+                                uint32_t* d_part_idx, uint32_t part_capacity_blocks, hipEvent_t ev0, hipEvent_t ev1) {
   const uint32_t qb = pick_qb(B);
   const uint32_t gy = (B + qb - 1) / qb;
   uint32_t gx = pick_gx(n, gy);
@@ -203,6 +203,7 @@ static rkh_status launch_nn1_dp(hipStream_t s, const NnStore& st, uint64_t n, co
 #define RKH_NN1_LAUNCH(QB)                                                                                       \
   hipLaunchKernelGGL((nn1_sweep_kernel<DP, QB>), grid, block, 0, s, st.d_pos, n, d_n, d_q, d_qoff, st.D, B,    \
                      d_B, d_part_dist, d_part_idx, Bpad)
+  if (ev0) (void)hipEventRecord(ev0, s);
   switch (qb) {
     case 8: RKH_NN1_LAUNCH(8); break;
     case 32: RKH_NN1_LAUNCH(32); break;
@@ -210,6 +211,7 @@ static rkh_status launch_nn1_dp(hipStream_t s, const NnStore& st, uint64_t n, co
     default: RKH_NN1_LAUNCH(256); break;
   }
 #undef RKH_NN1_LAUNCH
+  if (ev1) (void)hipEventRecord(ev1, s);
   hipLaunchKernelGGL(nn1_reduce_kernel, dim3((B + 255) / 256), dim3(256), 0, s, d_part_dist, d_part_idx, gx, Bpad, B,
                      d_B, d_idx, d_dist);
   RKH_HIP(hipGetLastError());
@@ -218,14 +220,14 @@ static rkh_status launch_nn1_dp(hipStream_t s, const NnStore& st, uint64_t n, co
 
 rkh_status launch_nn1(hipStream_t s, const NnStore& st, uint64_t n, const uint32_t* d_n, const double* d_q,
                       const uint32_t* d_qoff, uint32_t B, const uint32_t* d_B, uint32_t* d_idx, double* d_dist, double* d_part_dist, uint32_t* d_part_idx,
-                      uint32_t part_capacity_blocks) {
+                      uint32_t part_capacity_blocks, hipEvent_t ev0, hipEvent_t ev1) {
   if (B == 0) return RKH_OK;
   g_last_kernel = "nn1_sweep_kernel";
   switch (padded_dims(st.D)) {
 #define RKH_CASE(DP)                                                                                              \
   case DP:                                                                                                        \
     return launch_nn1_dp<DP>(s, st, n, d_n, d_q, d_qoff, B, d_B, d_idx, d_dist, d_part_dist, d_part_idx,          \
-                             part_capacity_blocks)
+                             part_capacity_blocks, ev0, ev1)
     RKH_CASE(2);
     RKH_CASE(4);
     RKH_CASE(6);

@@ -45,8 +45,9 @@ struct PlannerState {  // device-resident
   unsigned long long rounds, edges_speculated, fixup_cut;
 };
 
-__global__ void round_begin_kernel(PlannerState* st) {
+__global__ void round_begin_kernel(PlannerState* st, uint32_t* round_n, uint32_t round_slot) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (round_n) round_n[round_slot] = st->done ? 0u : st->n;
   uint32_t B = 0;
   if (!st->done) {
     const float want = st->batch_factor * sqrtf(float(st->n));
@@ -211,6 +212,12 @@ struct rkh_planner {
   double best_cost = INFINITY;
   bool truncated = false;
   uint64_t final_n = 0, final_iterations = 0;
+  // optional HIP-event timing of the NN sweep kernel (RKH_PROFILE_NN=1)
+  bool profile_nn = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  uint32_t* d_round_n = nullptr;
+  uint32_t prof_rounds = 0;
+  static constexpr uint32_t kProfMax = 8192;
 };
 
 namespace {
@@ -250,11 +257,25 @@ void launch_fixup(rkh_planner* p) {
 rkh_status enqueue_round(rkh_planner* p) {
   hipStream_t s = p->stream;
   const int D = p->D;
-  hipLaunchKernelGGL(round_begin_kernel, dim3(1), dim3(1), 0, s, p->d_state);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint32_t slot = 0;
+  if (p->profile_nn && p->prof_rounds < rkh_planner::kProfMax) {
+    slot = p->prof_rounds++;
+    if (p->ev.size() < 2 * size_t(slot + 1)) {
+      hipEvent_t a, b;
+      RKH_HIP(hipEventCreate(&a));
+      RKH_HIP(hipEventCreate(&b));
+      p->ev.push_back(a);
+      p->ev.push_back(b);
+    }
+    ev0 = p->ev[2 * slot];
+    ev1 = p->ev[2 * slot + 1];
+  }
+  hipLaunchKernelGGL(round_begin_kernel, dim3(1), dim3(1), 0, s, p->d_state, ev0 ? p->d_round_n : nullptr, slot);
   // 1. NN sweep of the round's samples over the snapshot
   const uint64_t n_upper = std::min<uint64_t>(p->capacity, uint64_t(p->prm.max_vertices) + 1);
   rkh_status st = launch_nn1(s, p->tree, n_upper, &p->d_state->n, p->d_samples, &p->d_state->s0, p->b_max,
-                             &p->d_state->B, p->d_nn_idx, p->d_nn_dist, p->d_part_dist, p->d_part_idx, p->part_blocks);
+                             &p->d_state->B, p->d_nn_idx, p->d_nn_dist, p->d_part_dist, p->d_part_idx, p->part_blocks, ev0, ev1);
   if (st != RKH_OK) return st;
   // 2. speculative steer of all candidates
   EdgeIO io;
@@ -361,6 +382,8 @@ rkh_status rkh_planner_create(rkh_scene* scene, const rkh_dyn_space* space, cons
   RKH_HIP(hipMalloc(&p->d_part_dist, uint64_t(p->part_blocks) * p->b_max * sizeof(double)));
   RKH_HIP(hipMalloc(&p->d_part_idx, uint64_t(p->part_blocks) * p->b_max * sizeof(uint32_t)));
   RKH_HIP(hipMalloc(&p->d_state, sizeof(PlannerState)));
+  if (const char* e = getenv("RKH_PROFILE_NN")) p->profile_nn = atoi(e) != 0;
+  if (p->profile_nn) RKH_HIP(hipMalloc(&p->d_round_n, rkh_planner::kProfMax * sizeof(uint32_t)));
   // root vertex = query start (create_root, rrt_path_planner.tpp:131-133)
   std::vector<double> row(p->DP, 0.0);
   for (int d = 0; d < p->D; ++d) row[d] = prm->start[d];
@@ -390,12 +413,34 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
                   p->d_accept_log, p->d_nn_idx, p->d_nn_dist, p->d_x_out, p->d_steps, p->d_accept, p->d_probe_x,
                   p->d_probe_steps, p->d_goal, p->d_part_dist, p->d_part_idx, p->d_state};
   for (void* b : bufs) hipFree(b);
+  hipFree(p->d_round_n);
+  for (hipEvent_t e : p->ev) hipEventDestroy(e);
   hipStreamDestroy(p->stream);
   delete p;
   return RKH_OK;
 }
 
 void* rkh_planner_stream(rkh_planner* p) { return p ? (void*)p->stream : nullptr; }
+
+rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* total_bytes, uint64_t* launches) {
+  if (!p || !total_ms || !total_bytes || !launches) return RKH_ERR_BAD_ARG;
+  *total_ms = 0.0;
+  *total_bytes = 0;
+  *launches = 0;
+  if (!p->profile_nn || p->prof_rounds == 0) return RKH_OK;
+  RKH_HIP(hipStreamSynchronize(p->stream));
+  std::vector<uint32_t> rn(p->prof_rounds);
+  RKH_HIP(hipMemcpy(rn.data(), p->d_round_n, rn.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (uint32_t r = 0; r < p->prof_rounds; ++r) {
+    if (rn[r] == 0) continue;  // no-op round after completion
+    float ms = 0.f;
+    RKH_HIP(hipEventElapsedTime(&ms, p->ev[2 * r], p->ev[2 * r + 1]));
+    *total_ms += ms;
+    *total_bytes += uint64_t(rn[r]) * p->DP * sizeof(double);  // algorithmic bytes of one sweep: n * D * 8
+    *launches += 1;
+  }
+  return RKH_OK;
+}
 
 rkh_status rkh_planner_enqueue(rkh_planner* p, uint32_t rounds) {
   if (!p) return RKH_ERR_BAD_ARG;

@@ -39,7 +39,8 @@ struct NnStore {
 // (planner rounds enqueued without host sync) and n is only the host-side upper bound used to size the grid.
 rkh_status launch_nn1(hipStream_t s, const NnStore& st, uint64_t n, const uint32_t* d_n, const double* d_q,
                       const uint32_t* d_qoff, uint32_t B, const uint32_t* d_B, uint32_t* d_idx, double* d_dist, double* d_part_dist,
-                      uint32_t* d_part_idx, uint32_t part_capacity_blocks);
+                      uint32_t* d_part_idx, uint32_t part_capacity_blocks, hipEvent_t ev0 = nullptr,
+                      hipEvent_t ev1 = nullptr);
 uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B);
 rkh_status launch_nnk(hipStream_t s, const NnStore& st, uint64_t n, const double* d_q, uint32_t B, uint32_t k,
                       double radius, uint32_t* d_idx, double* d_dist, uint32_t* d_count);

@@ -52,6 +52,7 @@ EXPORTS = [
     "rkh_scene_create", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
+    "rkh_planner_nn_profile",
 ]
 
 
@@ -110,6 +111,7 @@ def load():
     lib.rkh_planner_get_tree.argtypes = [vp, dp, u32p, u32p, C.POINTER(C.c_uint8), dp]
     lib.rkh_planner_stream.restype = vp
     lib.rkh_planner_stream.argtypes = [vp]
+    lib.rkh_planner_nn_profile.argtypes = [vp, dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = lib
     return lib
 
@@ -276,6 +278,11 @@ class RrtPlanner:
     def solve_planning_query(self):
         _check(self.lib.rkh_planner_solve(self.h, C.byref(self.stats)))
         return self.stats
+
+    def nn_profile(self):
+        ms, by, ln = C.c_double(), C.c_uint64(), C.c_uint64()
+        _check(self.lib.rkh_planner_nn_profile(self.h, C.byref(ms), C.byref(by), C.byref(ln)))
+        return ms.value, by.value, ln.value
 
     def tree(self):
         nv, it, D = int(self.stats.num_vertices), int(self.stats.iterations), self.scene.D
