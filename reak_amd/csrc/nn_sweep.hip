@@ -138,15 +138,19 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_kernel(const double* __res
   }
 }
 
-__global__ void nn1_reduce_kernel(const double* __restrict__ part_dist, const uint32_t* __restrict__ part_idx,
-                                  uint32_t nblocks, uint32_t Bpad, uint32_t B_host, const uint32_t* __restrict__ d_B,
-                                  uint32_t* __restrict__ idx, double* __restrict__ dist) {
+// one wave per query: lanes stride over the per-block partials, then a shuffle reduction
+__global__ __launch_bounds__(256) void nn1_reduce_kernel(const double* __restrict__ part_dist,
+                                                          const uint32_t* __restrict__ part_idx, uint32_t nblocks,
+                                                          uint32_t Bpad, uint32_t B_host,
+                                                          const uint32_t* __restrict__ d_B, uint32_t* __restrict__ idx,
+                                                          double* __restrict__ dist) {
   const uint32_t B = d_B ? *d_B : B_host;
-  const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (qi >= B) return;
   double bd = INFINITY;
   uint32_t bi = 0xFFFFFFFFu;
-  for (uint32_t b = 0; b < nblocks; ++b) {
+  for (uint32_t b = lane; b < nblocks; b += 64) {
     const double od = part_dist[uint64_t(b) * Bpad + qi];
     const uint32_t oi = part_idx[uint64_t(b) * Bpad + qi];
     if (lex_less(od, oi, bd, bi)) {
@@ -154,8 +158,19 @@ __global__ void nn1_reduce_kernel(const double* __restrict__ part_dist, const ui
       bi = oi;
     }
   }
-  idx[qi] = bi;
-  dist[qi] = bd;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double od = __shfl_xor(bd, off, 64);
+    const uint32_t oi = __shfl_xor(bi, off, 64);
+    if (lex_less(od, oi, bd, bi)) {
+      bd = od;
+      bi = oi;
+    }
+  }
+  if (lane == 0) {
+    idx[qi] = bi;
+    dist[qi] = bd;
+  }
 }
 
 static int padded_dims(int D) {
@@ -212,7 +227,7 @@ static rkh_status launch_nn1_dp(hipStream_t s, const NnStore& st, uint64_t n, co
   }
 #undef RKH_NN1_LAUNCH
   if (ev1) (void)hipEventRecord(ev1, s);
-  hipLaunchKernelGGL(nn1_reduce_kernel, dim3((B + 255) / 256), dim3(256), 0, s, d_part_dist, d_part_idx, gx, Bpad, B,
+  hipLaunchKernelGGL(nn1_reduce_kernel, dim3((B + 3) / 4), dim3(256), 0, s, d_part_dist, d_part_idx, gx, Bpad, B,
                      d_B, d_idx, d_dist);
   RKH_HIP(hipGetLastError());
   return RKH_OK;

@@ -34,8 +34,9 @@ struct PlannerState {  // device-resident
   uint32_t s0;           // next sample (== generate_rrt iterations so far)
   uint32_t B;            // candidates of the current round
   uint32_t F;            // first invalid candidate of the current round
-  uint32_t n_before;     // vertex count before the last commit
-  uint32_t n_new;        // vertices added by the last commit
+  uint32_t n_before;     // first vertex whose goal probe is still pending
+  uint32_t n_new;        // number of vertices whose goal probe is pending (they ride in the next propagate launch)
+  uint32_t probed_n;     // vertices [1, probed_n) have their goal probe result in goal_dist
   uint32_t done;         // keep_going() == false (vertex budget reached) or samples exhausted (2)
   uint32_t max_total;    // max_vertices + 1 (root is not counted by m_iteration_count)
   uint32_t samples_ready;  // samples uploaded so far
@@ -60,8 +61,6 @@ __global__ void round_begin_kernel(PlannerState* st, uint32_t* round_n, uint32_t
   }
   st->B = B;
   st->F = B;
-  st->n_new = 0;
-  st->n_before = st->n;
   if (B) {
     st->rounds += 1;
     st->edges_speculated += B;
@@ -159,12 +158,22 @@ __global__ __launch_bounds__(1024) void commit_kernel(PlannerState* __restrict__
   if (threadIdx.x == 0) {
     uint32_t added = carry < budget ? carry : budget;
     st->n = n0 + added;
-    st->n_new = added;
+    // the propagate launch of this round also ran the goal probes that were pending: [n_before, n_before+n_new)
+    st->probed_n = st->n_before + st->n_new;
+    st->n_new = added;  // this round's vertices are probed by the next launch
     st->n_before = n0;
     st->s0 = s0 + cut;
     st->fixup_cut += (st->B - F);
     if (st->n >= st->max_total) st->done = 1;
   }
+}
+
+// after a probe-only flush launch: nothing is pending any more
+__global__ void probes_flushed_kernel(PlannerState* st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->probed_n = st->n_before + st->n_new;
+  st->n_before = st->n;
+  st->n_new = 0;
 }
 
 }  // namespace rkh
@@ -254,6 +263,52 @@ void launch_fixup(rkh_planner* p) {
                      p->d_x_out, p->d_accept, p->d_nn_dist);
 }
 
+void make_edge_ios(rkh_planner* p, EdgeIO* io_out, EdgeIO* gp_out) {
+  EdgeIO io;
+  io.src = p->tree.d_pos;
+  io.src_idx = p->d_nn_idx;
+  io.src_stride = p->DP;
+  io.tgt = p->d_samples;
+  io.d_tgt_off = &p->d_state->s0;
+  io.tgt_stride = p->D;
+  io.B = p->b_max;
+  io.d_B = &p->d_state->B;
+  io.x_out = p->d_x_out;
+  io.steps_free = p->d_steps;
+  io.mode = EDGE_STEER_ACCEPT;
+  io.best_case = p->d_nn_dist;
+  io.steer_tol = p->prm.steer_tol;
+  io.accept = p->d_accept;
+  io.err_flag = p->scene->d_err;
+  EdgeIO gp;
+  gp.src = p->tree.d_pos;
+  gp.d_src_first = &p->d_state->n_before;
+  gp.src_stride = p->DP;
+  gp.tgt = p->d_goal;
+  gp.tgt_stride = 0;
+  gp.B = p->b_max;
+  gp.d_B = &p->d_state->n_new;
+  gp.x_out = p->d_probe_x;
+  gp.steps_free = p->d_probe_steps;
+  gp.mode = EDGE_GOAL_PROBE;
+  gp.goal_dist = p->d_goal_dist;
+  gp.err_flag = p->scene->d_err;
+  *io_out = io;
+  *gp_out = gp;
+}
+
+// goal probes still pending after the last enqueued round
+rkh_status flush_probes(rkh_planner* p) {
+  EdgeIO io, gp;
+  make_edge_ios(p, &io, &gp);
+  rkh_status st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
+                                   p->scene->n_pairs, p->dyn, gp, p->b_max);
+  if (st != RKH_OK) return st;
+  hipLaunchKernelGGL(probes_flushed_kernel, dim3(1), dim3(1), 0, p->stream, p->d_state);
+  RKH_HIP(hipGetLastError());
+  return RKH_OK;
+}
+
 rkh_status enqueue_round(rkh_planner* p) {
   hipStream_t s = p->stream;
   const int D = p->D;
@@ -277,25 +332,12 @@ rkh_status enqueue_round(rkh_planner* p) {
   rkh_status st = launch_nn1(s, p->tree, n_upper, &p->d_state->n, p->d_samples, &p->d_state->s0, p->b_max,
                              &p->d_state->B, p->d_nn_idx, p->d_nn_dist, p->d_part_dist, p->d_part_idx, p->part_blocks, ev0, ev1);
   if (st != RKH_OK) return st;
-  // 2. speculative steer of all candidates
-  EdgeIO io;
-  io.src = p->tree.d_pos;
-  io.src_idx = p->d_nn_idx;
-  io.src_stride = p->DP;
-  io.tgt = p->d_samples;
-  io.d_tgt_off = &p->d_state->s0;
-  io.tgt_stride = D;
-  io.B = p->b_max;
-  io.d_B = &p->d_state->B;
-  io.x_out = p->d_x_out;
-  io.steps_free = p->d_steps;
-  io.mode = EDGE_STEER_ACCEPT;
-  io.best_case = p->d_nn_dist;
-  io.steer_tol = p->prm.steer_tol;
-  io.accept = p->d_accept;
-  io.err_flag = p->scene->d_err;
+  // 2. speculative steer of all candidates; the same launch carries the goal probes (edge_added,
+  //    planning_visitors.hpp:194-200) of the vertices the previous round committed
+  EdgeIO io, gp;
+  make_edge_ios(p, &io, &gp);
   st = launch_propagate(s, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs, p->scene->n_pairs,
-                        p->dyn, io, p->b_max);
+                        p->dyn, io, p->b_max, &gp, p->b_max);
   if (st != RKH_OK) return st;
   // 3. fix-up against the vertices this round itself would add
   switch (p->DP) {
@@ -310,23 +352,6 @@ rkh_status enqueue_round(rkh_planner* p) {
   // 4. commit the valid prefix
   hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(1024), 0, s, p->d_state, p->tree.d_pos, D, p->DP, p->d_x_out,
                      p->d_accept, p->d_nn_idx, p->d_parent, p->d_node_sample, p->d_nn_seq, p->d_accept_log);
-  // 5. goal probes of the new vertices (planning_visitors.hpp:194-200)
-  EdgeIO gp;
-  gp.src = p->tree.d_pos;
-  gp.d_src_first = &p->d_state->n_before;
-  gp.src_stride = p->DP;
-  gp.tgt = p->d_goal;
-  gp.tgt_stride = 0;
-  gp.B = p->b_max;
-  gp.d_B = &p->d_state->n_new;
-  gp.x_out = p->d_probe_x;
-  gp.steps_free = p->d_probe_steps;
-  gp.mode = EDGE_GOAL_PROBE;
-  gp.goal_dist = p->d_goal_dist;
-  gp.err_flag = p->scene->d_err;
-  st = launch_propagate(s, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs, p->scene->n_pairs,
-                        p->dyn, gp, p->b_max);
-  if (st != RKH_OK) return st;
   RKH_HIP(hipGetLastError());
   return RKH_OK;
 }
@@ -394,6 +419,8 @@ rkh_status rkh_planner_create(rkh_scene* scene, const rkh_dyn_space* space, cons
   PlannerState& hs = p->h_state;
   std::memset(&hs, 0, sizeof(hs));
   hs.n = 1;
+  hs.n_before = 1;
+  hs.probed_n = 1;
   hs.max_total = uint32_t(max_total);
   hs.b_max = p->b_max;
   hs.b_min = 8;
@@ -468,6 +495,12 @@ rkh_status rkh_planner_sync(rkh_planner* p, rkh_planner_stats* stats) {
     return rkh_status(flag);
   }
   PlannerState& hs = p->h_state;
+  if (hs.done == 1 && hs.probed_n < hs.n) {  // finished: run the goal probes of the last committed vertices
+    rkh_status fs = flush_probes(p);
+    if (fs != RKH_OK) return fs;
+    RKH_HIP(hipMemcpyAsync(&p->h_state, p->d_state, sizeof(PlannerState), hipMemcpyDeviceToHost, p->stream));
+    RKH_HIP(hipStreamSynchronize(p->stream));
+  }
   if (hs.done == 2 && p->samples_ready < p->sample_cap) {  // sample stream ran dry mid-enqueue: refill and carry on
     hs.done = 0;
     RKH_HIP(hipMemcpy(&p->d_state->done, &hs.done, sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -475,8 +508,9 @@ rkh_status rkh_planner_sync(rkh_planner* p, rkh_planner_stats* stats) {
   // edge_added: a finite goal-probe distance registers a solution if it beats the best so far
   // (planning_visitors.hpp:194-200, solution_path_factories.hpp:58-110); keep_going() then also checks
   // max_num_results (p2p_planning_query.hpp:121-123).
-  if (!p->truncated && hs.n > 1 && p->goal_checked < uint64_t(hs.n) - 1) {
-    const uint64_t first = p->goal_checked, cnt = uint64_t(hs.n) - 1 - first;
+  const uint64_t probed = hs.probed_n < 1 ? 1 : hs.probed_n;  // vertices [1, probed) have a goal-probe result
+  if (!p->truncated && probed > 1 && p->goal_checked < probed - 1) {
+    const uint64_t first = p->goal_checked, cnt = probed - 1 - first;
     std::vector<double> gd(cnt);
     RKH_HIP(hipMemcpy(gd.data(), p->d_goal_dist + first, cnt * sizeof(double), hipMemcpyDeviceToHost));
     std::vector<double> pos;
@@ -515,7 +549,7 @@ rkh_status rkh_planner_sync(rkh_planner* p, rkh_planner_stats* stats) {
         }
       }
     }
-    p->goal_checked = uint64_t(hs.n) - 1;
+    p->goal_checked = probed - 1;
   }
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
@@ -552,6 +586,10 @@ rkh_status rkh_planner_solve(rkh_planner* p, rkh_planner_stats* stats) {
 rkh_status rkh_planner_get_tree(rkh_planner* p, double* pos, uint32_t* parent, uint32_t* nn_seq, uint8_t* accept,
                                 double* goal_dist) {
   if (!p) return RKH_ERR_BAD_ARG;
+  if (goal_dist) {  // make sure no goal probe is pending
+    rkh_status fs = flush_probes(p);
+    if (fs != RKH_OK) return fs;
+  }
   RKH_HIP(hipStreamSynchronize(p->stream));
   const uint64_t n = p->truncated ? p->final_n : p->h_state.n;
   const uint64_t it = p->truncated ? p->final_iterations : p->h_state.s0;

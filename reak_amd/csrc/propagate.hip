@@ -360,12 +360,16 @@ __device__ __forceinline__ void stage_env(const SceneDev* __restrict__ sc, Shape
 // Outputs: x_out [B][2N] last free state, steps_free[B], record (optional) [B][n_steps+1][2N]
 template <int N>
 __global__ __launch_bounds__(64) void propagate_kernel(const SceneDev* __restrict__ sc, const PairDev* __restrict__ pairs,
-                                                        int n_pairs, DynDev dyn, EdgeIO io) {
+                                                        int n_pairs, DynDev dyn, EdgeIO io_a, EdgeIO io_b,
+                                                        uint32_t grid_a) {
+  // two edge groups per launch (planner: this round's steer candidates + the previous round's goal probes)
+  const bool group_b = blockIdx.x >= grid_a;
+  const EdgeIO& io = group_b ? io_b : io_a;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   WaveWs<N>& ws = *reinterpret_cast<WaveWs<N>*>(smem_raw);
   ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + ((sizeof(WaveWs<N>) + 15) / 16) * 16);
   const uint32_t B = io.d_B ? *io.d_B : io.B;
-  const uint32_t e = blockIdx.x;
+  const uint32_t e = group_b ? blockIdx.x - grid_a : blockIdx.x;
   if (e >= B) return;
   const int lane = threadIdx.x;
   constexpr int D = 2 * N;
@@ -553,10 +557,13 @@ static size_t smem_bytes(int n_env) {
 }
 
 rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
-                            int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges) {
-  if (grid_edges == 0) return RKH_OK;
-  RKH_DISPATCH_N(n_dof, hipLaunchKernelGGL((propagate_kernel<N>), dim3(grid_edges), dim3(64), smem_bytes<N>(n_env), s,
-                                           d_scene, static_cast<const PairDev*>(d_pairs), n_pairs, dyn, io));
+                            int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges, const EdgeIO* io_b,
+                            uint32_t grid_b) {
+  if (grid_edges + grid_b == 0) return RKH_OK;
+  const EdgeIO second = io_b ? *io_b : EdgeIO();
+  RKH_DISPATCH_N(n_dof, hipLaunchKernelGGL((propagate_kernel<N>), dim3(grid_edges + (io_b ? grid_b : 0u)), dim3(64),
+                                           smem_bytes<N>(n_env), s, d_scene, static_cast<const PairDev*>(d_pairs),
+                                           n_pairs, dyn, io, second, grid_edges));
   RKH_HIP(hipGetLastError());
   return RKH_OK;
 }

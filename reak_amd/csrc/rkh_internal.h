@@ -152,7 +152,8 @@ struct EdgeIO {  // inputs / outputs of one propagate launch (all device pointer
 };
 
 rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
-                            int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges);
+                            int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges,
+                            const EdgeIO* io_b = nullptr, uint32_t grid_b = 0);
 rkh_status launch_state_derivative(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x,
                                    const double* d_u, uint32_t B, double* d_pd, double* d_M, double* d_f, int* d_err);
 rkh_status launch_min_distance(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
