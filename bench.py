@@ -117,9 +117,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--problems", type=int, default=int(os.environ.get("RKH_BENCH_PROBLEMS", "8")))
+    ap.add_argument("--problems", type=int, default=int(os.environ.get("RKH_BENCH_PROBLEMS", "32")))
     ap.add_argument("--max-vertices", type=int, default=100000)
-    ap.add_argument("--rounds-per-sync", type=int, default=8)
+    ap.add_argument("--rounds-per-sync", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
     args = ap.parse_args()
@@ -147,33 +147,27 @@ def main():
 
     def run_step(step_index, timed):
         seeds = [1 + (step_index * world + rank) * P + i for i in range(P)]
-        planners = [lib.RrtPlanner(scene, scn.rrt_params(seed=s, max_vertices=args.max_vertices)) for s in seeds]
-        for pl in planners:  # sample chunks resident before the clock starts
-            pl.enqueue(0)
+        pl = lib.RrtPlanner(scene, [scn.rrt_params(seed=s, max_vertices=args.max_vertices) for s in seeds])
+        pl.enqueue(0)  # sample chunks resident before the clock starts
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        active = list(planners)
-        while active:
-            for pl in active:
-                pl.enqueue(args.rounds_per_sync)
-            nxt = []
-            for pl in active:
-                if not pl.sync().done:
-                    nxt.append(pl)
-            active = nxt
+        while True:
+            pl.enqueue(args.rounds_per_sync)
+            pl.sync()
+            if pl.done:
+                break
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        nodes = sum(int(pl.stats.num_vertices) - 1 for pl in planners)
-        edges = sum(int(pl.stats.edges_checked) for pl in planners)
-        spec = sum(int(pl.stats.edges_speculated) for pl in planners)
-        rounds = sum(int(pl.stats.rounds) for pl in planners)
-        best = min(float(pl.stats.best_cost) for pl in planners)
-        prof = [pl.nn_profile() for pl in planners]
-        for pl in planners:
-            pl.close()
+        nodes = sum(int(st.num_vertices) - 1 for st in pl.all_stats)
+        edges = sum(int(st.edges_checked) for st in pl.all_stats)
+        spec = sum(int(st.edges_speculated) for st in pl.all_stats)
+        rounds = max(int(st.rounds) for st in pl.all_stats)
+        best = min(float(st.best_cost) for st in pl.all_stats)
+        prof = [pl.nn_profile()]
+        pl.close()
         return {"seconds": t1 - t0, "nodes": nodes, "edges": edges, "spec": spec, "rounds": rounds, "best": best,
                 "nn_ms": sum(p[0] for p in prof), "nn_bytes": sum(p[1] for p in prof), "nn_launches": sum(p[2] for p in prof)}
 

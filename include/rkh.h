@@ -115,6 +115,12 @@ rkh_status rkh_edge_check(rkh_scene* scene, const double* lower, const double* u
                           const double* a, const double* b, uint32_t B, double fraction, double* out,
                           uint32_t* n_checked);
 
+/* Diagnostics (not on the product path): shader-clock cycles of `iters` back-to-back f-evals + proximity tests,
+ * one wave per state; cycles[B][8] = {sincos, forward sweep, jacobian columns, force sweep, mass matrix, cholesky,
+ * proximity, total}. */
+rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double* u, uint32_t B, int iters,
+                                 uint64_t* cycles);
+
 /* ---- planner: rrt_planner::solve_planning_query (LINEAR_SEARCH_KNN, UNIDIRECTIONAL) ----------
  * (ctrl/path_planning/rrt_path_planner.tpp:66-145 -> generate_rrt, ctrl/graph_alg/rr_tree.hpp:179-199)
  * over the steerable dynamic space.  Expansion is speculative in batches but commits vertices in
@@ -133,6 +139,14 @@ typedef struct rkh_planner_stats {
 
 rkh_status rkh_planner_create(rkh_scene* scene, const rkh_dyn_space* space, const rkh_rrt_params* prm,
                               rkh_planner** out);
+/* A batch of n_problems independent planning problems (seeds / start-goal queries) on one scene.  They advance in
+ * lock-step rounds and share every kernel launch, which is what fills the chip (the reference's evaluation mode is
+ * Monte-Carlo over independent runs, ctrl/path_planning/planner_exec_engines.hpp:139-206).  Each problem is
+ * still, bit for bit, the sequential planner on its own seed.  Every stats pointer below is an array of
+ * rkh_planner_num_problems() entries. */
+rkh_status rkh_planner_create_batch(rkh_scene* scene, const rkh_dyn_space* space, const rkh_rrt_params* prms,
+                                    uint32_t n_problems, rkh_planner** out);
+uint32_t rkh_planner_num_problems(const rkh_planner* p);
 rkh_status rkh_planner_destroy(rkh_planner* p);
 /* Enqueue `rounds` speculative batches on the planner's stream (no host sync). */
 rkh_status rkh_planner_enqueue(rkh_planner* p, uint32_t rounds);
@@ -140,10 +154,10 @@ rkh_status rkh_planner_enqueue(rkh_planner* p, uint32_t rounds);
 rkh_status rkh_planner_sync(rkh_planner* p, rkh_planner_stats* stats);
 /* Run to completion (keep_going() false): enqueue + sync until done. */
 rkh_status rkh_planner_solve(rkh_planner* p, rkh_planner_stats* stats);
-/* Copy the motion graph out: pos [num_vertices][2n], parent[num_vertices] (root 0xFFFFFFFF),
+/* Copy the motion graph of one problem out: pos [num_vertices][2n], parent[num_vertices] (root 0xFFFFFFFF),
  * nn_seq[iterations], accept[iterations], goal_dist[num_vertices-1].  Any pointer may be NULL. */
-rkh_status rkh_planner_get_tree(rkh_planner* p, double* pos, uint32_t* parent, uint32_t* nn_seq, uint8_t* accept,
-                                double* goal_dist);
+rkh_status rkh_planner_get_tree(rkh_planner* p, uint32_t problem, double* pos, uint32_t* parent, uint32_t* nn_seq,
+                                uint8_t* accept, double* goal_dist);
 void* rkh_planner_stream(rkh_planner* p);
 /* With RKH_PROFILE_NN=1 in the environment at rkh_planner_create, every round brackets its NN sweep kernel with
  * HIP events on the planner stream: total kernel time, algorithmic bytes (n*D*8 per sweep) and launch count. */

@@ -31,22 +31,24 @@ __device__ __forceinline__ bool lex_less(double da, uint32_t ia, double db, uint
 }
 
 // One block: rows [row0, row1) x queries [blockIdx.y*QB, +QB).
+// blockIdx.z selects the problem when a table of NnArgs is given (one launch sweeps many independent trees).
 template <int DP, int QB>
-__global__ __launch_bounds__(kThreads) void nn1_sweep_kernel(const double* __restrict__ pos, uint64_t n_host,
-                                                              const uint32_t* __restrict__ d_n,
-                                                              const double* __restrict__ q,
-                                                              const uint32_t* __restrict__ d_qoff, int D,
-                                                              uint32_t B_host, const uint32_t* __restrict__ d_B,
-                                                              double* __restrict__ part_dist,
-                                                              uint32_t* __restrict__ part_idx, uint32_t Bpad) {
+__global__ __launch_bounds__(kThreads) void nn1_sweep_kernel(NnArgs single, const NnArgs* __restrict__ table, int D,
+                                                              uint32_t Bpad) {
   constexpr int R = kThreads / QB;          // row sub-ranges per block
   constexpr int ROWS_PER_THREAD = kTileRows / R;
   __shared__ __attribute__((aligned(16))) double tile[kTileRows * DP];
   __shared__ double red_d[kThreads];
   __shared__ uint32_t red_i[kThreads];
 
-  const uint64_t n = d_n ? uint64_t(*d_n) : n_host;
-  const uint32_t B = d_B ? *d_B : B_host;
+  const NnArgs a = table ? table[blockIdx.z] : single;
+  const double* __restrict__ pos = a.pos;
+  const double* __restrict__ q = a.q;
+  const uint32_t* __restrict__ d_qoff = a.d_qoff;
+  double* __restrict__ part_dist = a.part_dist;
+  uint32_t* __restrict__ part_idx = a.part_idx;
+  const uint64_t n = a.d_n ? uint64_t(*a.d_n) : a.n;
+  const uint32_t B = a.d_B ? *a.d_B : a.B;
   const int tid = threadIdx.x;
   const int ql = tid % QB;
   const int r = tid / QB;
@@ -139,12 +141,14 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_kernel(const double* __res
 }
 
 // one wave per query: lanes stride over the per-block partials, then a shuffle reduction
-__global__ __launch_bounds__(256) void nn1_reduce_kernel(const double* __restrict__ part_dist,
-                                                          const uint32_t* __restrict__ part_idx, uint32_t nblocks,
-                                                          uint32_t Bpad, uint32_t B_host,
-                                                          const uint32_t* __restrict__ d_B, uint32_t* __restrict__ idx,
-                                                          double* __restrict__ dist) {
-  const uint32_t B = d_B ? *d_B : B_host;
+__global__ __launch_bounds__(256) void nn1_reduce_kernel(NnArgs single, const NnArgs* __restrict__ table,
+                                                          uint32_t nblocks, uint32_t Bpad) {
+  const NnArgs a = table ? table[blockIdx.y] : single;
+  const double* __restrict__ part_dist = a.part_dist;
+  const uint32_t* __restrict__ part_idx = a.part_idx;
+  uint32_t* __restrict__ idx = a.idx;
+  double* __restrict__ dist = a.dist;
+  const uint32_t B = a.d_B ? *a.d_B : a.B;
   const uint32_t qi = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (qi >= B) return;
@@ -196,28 +200,26 @@ static uint32_t pick_gx(uint64_t n_upper, uint32_t gy) {
   return uint32_t(tiles < want ? tiles : want);
 }
 
-uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B) {
+uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B, uint32_t n_problems) {
   const uint32_t qb = pick_qb(B);
   const uint32_t gy = (B + qb - 1) / qb;
-  return pick_gx(n_upper, gy);
+  return pick_gx(n_upper, gy * (n_problems ? n_problems : 1));
 }
 
 static const char* g_last_kernel = "";
 const char* nn_last_kernel_name() { return g_last_kernel; }
 
 template <int DP>
-static rkh_status launch_nn1_dp(hipStream_t s, const NnStore& st, uint64_t n, const uint32_t* d_n, const double* d_q,
-                                const uint32_t* d_qoff, uint32_t B, const uint32_t* d_B, uint32_t* d_idx, double* d_dist, double* d_part_dist,
-                                uint32_t* d_part_idx, uint32_t part_capacity_blocks, hipEvent_t ev0, hipEvent_t ev1) {
+static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
+                                uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0,
+                                hipEvent_t ev1) {
   const uint32_t qb = pick_qb(B);
   const uint32_t gy = (B + qb - 1) / qb;
-  uint32_t gx = pick_gx(n, gy);
+  uint32_t gx = pick_gx(n_upper, gy * n_problems);
   if (gx > part_capacity_blocks) gx = part_capacity_blocks;
   const uint32_t Bpad = B;
-  dim3 grid(gx, gy), block(kThreads);
-#define RKH_NN1_LAUNCH(QB)                                                                                       \
-  hipLaunchKernelGGL((nn1_sweep_kernel<DP, QB>), grid, block, 0, s, st.d_pos, n, d_n, d_q, d_qoff, st.D, B,    \
-                     d_B, d_part_dist, d_part_idx, Bpad)
+  dim3 grid(gx, gy, n_problems), block(kThreads);
+#define RKH_NN1_LAUNCH(QB) hipLaunchKernelGGL((nn1_sweep_kernel<DP, QB>), grid, block, 0, s, single, d_table, D, Bpad)
   if (ev0) (void)hipEventRecord(ev0, s);
   switch (qb) {
     case 8: RKH_NN1_LAUNCH(8); break;
@@ -227,22 +229,20 @@ static rkh_status launch_nn1_dp(hipStream_t s, const NnStore& st, uint64_t n, co
   }
 #undef RKH_NN1_LAUNCH
   if (ev1) (void)hipEventRecord(ev1, s);
-  hipLaunchKernelGGL(nn1_reduce_kernel, dim3((B + 3) / 4), dim3(256), 0, s, d_part_dist, d_part_idx, gx, Bpad, B,
-                     d_B, d_idx, d_dist);
+  hipLaunchKernelGGL(nn1_reduce_kernel, dim3((B + 3) / 4, n_problems), dim3(256), 0, s, single, d_table, gx, Bpad);
   RKH_HIP(hipGetLastError());
   return RKH_OK;
 }
 
-rkh_status launch_nn1(hipStream_t s, const NnStore& st, uint64_t n, const uint32_t* d_n, const double* d_q,
-                      const uint32_t* d_qoff, uint32_t B, const uint32_t* d_B, uint32_t* d_idx, double* d_dist, double* d_part_dist, uint32_t* d_part_idx,
-                      uint32_t part_capacity_blocks, hipEvent_t ev0, hipEvent_t ev1) {
-  if (B == 0) return RKH_OK;
+// 1-NN of up to B queries per problem.  single: one problem given by value; d_table: n_problems NnArgs in HBM.
+// n_upper (host bound on the vertex count) and B (host bound on the query count) only size the grid.
+rkh_status launch_nn1(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
+                      uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0, hipEvent_t ev1) {
+  if (B == 0 || n_problems == 0) return RKH_OK;
   g_last_kernel = "nn1_sweep_kernel";
-  switch (padded_dims(st.D)) {
-#define RKH_CASE(DP)                                                                                              \
-  case DP:                                                                                                        \
-    return launch_nn1_dp<DP>(s, st, n, d_n, d_q, d_qoff, B, d_B, d_idx, d_dist, d_part_dist, d_part_idx,          \
-                             part_capacity_blocks, ev0, ev1)
+  switch (padded_dims(D)) {
+#define RKH_CASE(DP) \
+  case DP: return launch_nn1_dp<DP>(s, D, single, d_table, n_problems, n_upper, B, part_capacity_blocks, ev0, ev1)
     RKH_CASE(2);
     RKH_CASE(4);
     RKH_CASE(6);

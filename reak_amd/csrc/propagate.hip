@@ -1,5 +1,5 @@
-// propagate.hip -- one wavefront per candidate edge: RK4 forward-dynamics propagation of a KTE
-// serial chain with a proximity (collision) test after every step (gfx950, wave64).
+// propagate.hip -- RK4 forward-dynamics propagation of a KTE serial chain with a proximity
+// (collision) test after every step, for batches of candidate edges (gfx950, wave64).
 //
 // What it replaces (paths relative to /root/reference/src/ReaK/):
 //   steer loop        examples/misc/MEAQR_topology.hpp:503-565 (steer_with_constant_control pattern)
@@ -11,14 +11,17 @@
 //   Cholesky solve    core/lin_alg/mat_cholesky.hpp:63-84,160-178,546-554
 //   is_free           ctrl/topologies/manip_free_workspace.hpp:79-99 + geometry/proximity (proximity_device.h)
 //
-// Mapping onto the wave (block = 1 wave = 1 edge):
-//   * state x, RK4 temporaries, bounds: lane d < 2N owns component d  (registers, 1 double each)
+// Mapping onto the wave.  A block is one wave; a wave carries 64/GL candidate edges, GL lanes each
+// (GL = 64: one wavefront per candidate, lowest latency; GL = 16: four candidates per wave, used when
+// many planners oversubscribe the chip).  Within an edge's lane group:
+//   * state x, RK4 temporaries, bounds: lane d < 2N owns component d (one register each)
 //   * sin/cos of the N joint angles (half- and full-angle): lanes 0..2N-1 in parallel
-//   * base->tip kinematic sweep and tip->base force sweep: serial by nature; every lane runs them on
-//     wave-uniform values (no cross-lane traffic), joints fully unrolled (template N)
+//   * base->tip kinematic sweep and tip->base force sweep: serial by nature; every lane of the group runs
+//     them on group-uniform values read by LDS broadcast (no cross-lane traffic), joints unrolled (template N)
 //   * Jacobian columns Tcm(body b, coord c<=b): one lane per (b,c) pair; M(i,j): one lane per entry
-//   * proximity pairs: one lane per (robot shape, obstacle) pair, ballot for "any distance < 0";
-//     obstacle table staged in LDS, chain parameters read as wave-uniform (scalar) loads.
+//   * Cholesky: lane i owns row i (divisions of a column run in parallel), same per-element operation order
+//   * proximity pairs: one lane per (robot shape, obstacle) pair, ballot for "any distance < 0"
+// Chain parameters, obstacle table and all per-edge intermediates live in LDS.
 // Compiled with -ffp-contract=off: products and sums round exactly as in the CPU reference; only
 // sin/cos (OCML vs glibc) differ by ulps (stated tolerance: 1e-10 relative on propagated states).
 #include <hip/hip_runtime.h>
@@ -31,45 +34,74 @@
 
 namespace rkh {
 
+struct __attribute__((aligned(16))) JointLds {  // chain parameters of one joint group, staged in LDS
+  double axis[3], joint_inertia;
+  double axis_n[3], mass;
+  double off_pos[3], pad0;
+  double off_quat[4];
+  double off_R[9], pad1;
+  double inertia[6];
+};
+
 template <int N>
-struct WaveWs {  // per-wave LDS workspace
-  double Epos[N][3], Equat[N][4];  // joint end frames (jacobian parents)
-  double Lpos[N][3], Lquat[N][4];  // link end frames (inertia frames)
-  double Tcm[N][N][6];             // [body][coord] jacobian column (v, w)
-  double M[N][N];
+struct __attribute__((aligned(16))) GroupWs {  // per-edge LDS workspace
+  double x[2 * N];                  // state being differentiated (q, qd interleaved)
+  double b[2 * N];                  // steer target
+  double u[N];                      // held input
+  double tmp[2 * N];                // lane-parallel -> sequential-sum staging
+  double cs[N][4];                  // c2, s2 (half angle), c1, s1 (full angle)
+  double Epos[N][3], Equat[N][4];   // joint end frames (jacobian parents)
+  double Lpos[N][3], Lquat[N][4];   // link end frames (inertia frames)
+  double FT[N][6];                  // inertia_3D d'Alembert force / torque (to be subtracted)
+  double Tcm[N][N][6];              // [body][coord] jacobian column (v, w)
+  double Mf[N][N];                  // Tcm^T (Mcm Tcm) before symmetrisation
+  double M[N][N];                   // symmetric M, overwritten by its Cholesky factor
   double Rpos[2 * N][3], Rquat[2 * N][4];  // robot shapes, global pose
 };
 
-template <int N>
-struct ChainRegs {  // wave-uniform per-joint values carried from the forward to the backward sweep
-  double c1[N], s1[N];  // cos/sin of the full joint angle
-  d3 Fi[N], Ti[N];      // inertia_3D d'Alembert force / torque (to be subtracted)
+template <int N, int GL>
+struct BlockLds {
+  JointLds joints[N];
+  double base[10];  // pos3, quat4, acc3
+  double sink[64][4];  // per-lane dummy store target: keeps the group-leader stores branch-free
+  GroupWs<N> g[64 / GL];
 };
 
-// revolute_joint_3D / rigid_link_3D kinematics of joint j (position + orientation only)
+RKH_DI d3 ld3(const double* p) { return d3{p[0], p[1], p[2]}; }
+RKH_DI d4 ld4(const double* p) { return d4{p[0], p[1], p[2], p[3]}; }
+RKH_DI void st3(double* p, d3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+RKH_DI void st4(double* p, d4 v) { p[0] = v.w; p[1] = v.x; p[2] = v.y; p[3] = v.z; }
+RKH_DI m33 ldm(const double* p) { return m33{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]}; }
+
+// Chain parameters are wave-uniform.  They are packed into R vector registers (lane l of register r
+// holds flat parameter r*64 + l, JointLds layout) and read back with v_readlane: no memory latency on
+// the serial sweeps' critical path and no long-lived scalar registers.
 template <int N>
-RKH_DI void fk_pose_chain(const SceneDev* __restrict__ sc, const double (&c2)[N], const double (&s2)[N], WaveWs<N>& ws,
-                          int lane) {
-  d3 pos = mk3(sc->base_pos[0], sc->base_pos[1], sc->base_pos[2]);
-  d4 Q = d4{sc->base_quat[0], sc->base_quat[1], sc->base_quat[2], sc->base_quat[3]};
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const JointDev& jd = sc->joints[j];
-    const d4 tq = d4{c2[j], jd.axis_n[0] * s2[j], jd.axis_n[1] * s2[j], jd.axis_n[2] * s2[j]};
-    const d4 EQ = qmul(Q, tq);
-    if (lane == 0) {
-      ws.Epos[j][0] = pos.x; ws.Epos[j][1] = pos.y; ws.Epos[j][2] = pos.z;
-      ws.Equat[j][0] = EQ.w; ws.Equat[j][1] = EQ.x; ws.Equat[j][2] = EQ.y; ws.Equat[j][3] = EQ.z;
-    }
-    const m33 R = rotmat(EQ);
-    pos = pos + mul(R, mk3(jd.off_pos[0], jd.off_pos[1], jd.off_pos[2]));
-    Q = qmul(EQ, d4{jd.off_quat[0], jd.off_quat[1], jd.off_quat[2], jd.off_quat[3]});
-    if (lane == 0) {
-      ws.Lpos[j][0] = pos.x; ws.Lpos[j][1] = pos.y; ws.Lpos[j][2] = pos.z;
-      ws.Lquat[j][0] = Q.w; ws.Lquat[j][1] = Q.x; ws.Lquat[j][2] = Q.y; ws.Lquat[j][3] = Q.z;
-    }
-  }
+struct CPack {
+  static constexpr int R = (N * 32 + 63) / 64;
+  double v[R];
+};
+RKH_DI double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
 }
+template <int N>
+RKH_DI double cget(const CPack<N>& cp, int idx) { return readlane_f64(cp.v[idx >> 6], idx & 63); }
+template <int N>
+RKH_DI d3 cget3(const CPack<N>& cp, int idx) { return d3{cget(cp, idx), cget(cp, idx + 1), cget(cp, idx + 2)}; }
+template <int N>
+RKH_DI CPack<N> load_cpack(const JointLds* jl, int lane) {
+  CPack<N> cp;
+#pragma unroll
+  for (int r = 0; r < CPack<N>::R; ++r) {
+    const int idx = r * 64 + lane;
+    cp.v[r] = idx < N * 32 ? reinterpret_cast<const double*>(jl)[idx] : 0.0;
+  }
+  return cp;
+}
+// field offsets inside JointLds (in doubles)
+enum : int { JC_AXIS = 0, JC_JIN = 3, JC_AXISN = 4, JC_MASS = 7, JC_OFFP = 8, JC_OFFQ = 12, JC_OFFR = 16, JC_INER = 26 };
 
 // axis_angle::getRotMat (rotations_3D.hpp:2160-2180) from cos/sin of the angle and the unit axis
 RKH_DI m33 axis_angle_rotmat(double ca, double sa, d3 ax) {
@@ -80,248 +112,327 @@ RKH_DI m33 axis_angle_rotmat(double ca, double sa, d3 ax) {
   return m33{t11, t12 - t03, t13 + t02, t12 + t03, t22, t23 - t01, t13 - t02, t23 + t01, t33};
 }
 
-// x' = f(x,u).  xv: lane d < 2N holds x[d]; uv: lane j < N holds u[j].
-// Returns dp for lane d (< 2N); sets *singular if a Cholesky pivot is < 1e-8.
-// If M_out/f_out (global, optional) are given, lane-parallel copies of M and the bias force are written.
 template <int N>
-__device__ double state_derivative(const SceneDev* __restrict__ sc, WaveWs<N>& ws, double xv, double uv, int lane,
-                                   bool* singular, double* M_out, double* f_out) {
-  // ---- sin/cos, lane-parallel: lane 2j -> half angle, lane 2j+1 -> full angle
-  const double q_here = __shfl(xv, lane & ~1, 64);
-  double sn, cs;
-  sincos((lane & 1) ? q_here : 0.5 * q_here, &sn, &cs);
-  double c2[N], s2[N], qd[N], u[N];
-  ChainRegs<N> cr;
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    c2[j] = __shfl(cs, 2 * j, 64);
-    s2[j] = __shfl(sn, 2 * j, 64);
-    cr.c1[j] = __shfl(cs, 2 * j + 1, 64);
-    cr.s1[j] = __shfl(sn, 2 * j + 1, 64);
-    qd[j] = __shfl(xv, 2 * j + 1, 64);
-    u[j] = __shfl(uv, j, 64);
+__device__ __forceinline__ void stage_chain(const SceneDev* __restrict__ sc, JointLds* jl, double* base, int lane) {
+  for (int i = lane; i < N * 32; i += 64) {
+    const int j = i >> 5, k = i & 31;
+    const JointDev& J = sc->joints[j];
+    double v = 0.0;
+    if (k < 3) v = J.axis[k];
+    else if (k == 3) v = J.joint_inertia;
+    else if (k < 7) v = J.axis_n[k - 4];
+    else if (k == 7) v = J.mass;
+    else if (k < 11) v = J.off_pos[k - 8];
+    else if (k == 11) v = 0.0;
+    else if (k < 16) v = J.off_quat[k - 12];
+    else if (k < 25) v = J.off_R[k - 16];
+    else if (k == 25) v = 0.0;
+    else v = J.inertia[k - 26];
+    reinterpret_cast<double*>(&jl[j])[k] = v;
   }
+  if (lane < 3) base[lane] = sc->base_pos[lane];
+  else if (lane < 7) base[lane] = sc->base_quat[lane - 3];
+  else if (lane < 10) base[lane] = sc->base_acc[lane - 7];
+}
 
-  // ---- base -> tip sweep (kte_map_chain::doMotion), wave-uniform
+__device__ __forceinline__ void stage_env(const SceneDev* __restrict__ sc, ShapeDev* env_lds, int lane) {
+  const int n_words = sc->n_env * int(sizeof(ShapeDev) / sizeof(double));
+  const double* src = reinterpret_cast<const double*>(sc->env);
+  double* dst = reinterpret_cast<double*>(env_lds);
+  for (int i = lane; i < n_words; i += 64) dst[i] = src[i];
+}
+
+// x' = f(x,u) for the lane group's edge.  ws.x / ws.u hold the state and the input (already staged).
+// Returns dp for lane gl (< 2N); sets *singular if a Cholesky pivot is < 1e-8.
+template <int N, int GL>
+__device__ double state_derivative(const CPack<N>& cp, const JointLds* __restrict__ jl,
+                                   const double* __restrict__ base, GroupWs<N>& ws, double* __restrict__ sink,
+                                   int gl, int gb, bool* singular, unsigned long long* stamps = nullptr) {
+  constexpr int D = 2 * N;
+  // diagnostic builds only (rkh_diag_feval_cycles): per-phase s_memtime deltas; null in the product path
+#define RKH_STAMP(i)                                        \
+  if (stamps) {                                             \
+    const unsigned long long t_now = __builtin_readcyclecounter(); \
+    stamps[i] += t_now - t_prev;                            \
+    t_prev = t_now;                                         \
+  }
+  unsigned long long t_prev = stamps ? __builtin_readcyclecounter() : 0ull;
+  const bool lead = (gl == 0);  // the group leader's stores land in ws, everyone else's in its private sink
+  // ---- sin/cos, lane-parallel: lane 2j -> half angle, lane 2j+1 -> full angle
+  if (gl < D) {
+    const double q = ws.x[gl & ~1];
+    double sn, cs;
+    sincos((gl & 1) ? q : 0.5 * q, &sn, &cs);
+    ws.cs[gl >> 1][(gl & 1) * 2 + 0] = cs;
+    ws.cs[gl >> 1][(gl & 1) * 2 + 1] = sn;
+  }
+  __syncthreads();
+  RKH_STAMP(0)
+
+  // ---- base -> tip sweep (kte_map_chain::doMotion), group-uniform
   {
-    d3 pos = mk3(sc->base_pos[0], sc->base_pos[1], sc->base_pos[2]);
-    d4 Q = d4{sc->base_quat[0], sc->base_quat[1], sc->base_quat[2], sc->base_quat[3]};
+    d3 pos = ld3(base);
+    d4 Q = ld4(base + 3);
     d3 w = mk3(0, 0, 0), alpha = mk3(0, 0, 0);
-    d3 acc = mk3(sc->base_acc[0], sc->base_acc[1], sc->base_acc[2]);
+    d3 acc = ld3(base + 7);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const JointDev& jd = sc->joints[j];
-      const d3 axis = mk3(jd.axis[0], jd.axis[1], jd.axis[2]);
+      const int jb = j * 32;
+      const d3 axis = cget3(cp, jb + JC_AXIS);
+      const d3 axis_n = cget3(cp, jb + JC_AXISN);
+      const double c2 = ws.cs[j][0], s2 = ws.cs[j][1];
+      const double qd = ws.x[2 * j + 1];
       // revolute_joint_3D::doMotion (revolute_joint.cpp:121-148)
-      const d4 tq = d4{c2[j], jd.axis_n[0] * s2[j], jd.axis_n[1] * s2[j], jd.axis_n[2] * s2[j]};
+      const d4 tq = d4{c2, axis_n.x * s2, axis_n.y * s2, axis_n.z * s2};
       const m33 R2 = rotmat(tq);
       const d4 EQ = qmul(Q, tq);
       const d3 wb = mulT(w, R2);
-      const d3 qa = qd[j] * axis;
+      const d3 qa = qd * axis;
       const d3 Ew = wb + qa;
       const d3 Ealpha = mulT(alpha, R2) + cross(wb, qa);
-      if (lane == 0) {
-        ws.Epos[j][0] = pos.x; ws.Epos[j][1] = pos.y; ws.Epos[j][2] = pos.z;
-        ws.Equat[j][0] = EQ.w; ws.Equat[j][1] = EQ.x; ws.Equat[j][2] = EQ.y; ws.Equat[j][3] = EQ.z;
-      }
+      st3(lead ? ws.Epos[j] : sink, pos);
+      st4(lead ? ws.Equat[j] : sink, EQ);
       // rigid_link_3D::doMotion = frame * pose (frame_3D.hpp:240-255)
-      const d3 op = mk3(jd.off_pos[0], jd.off_pos[1], jd.off_pos[2]);
+      const d3 op = cget3(cp, jb + JC_OFFP);
       const m33 R = rotmat(EQ);
       pos = pos + mul(R, op);
       acc = acc + mul(R, cross(Ew, cross(Ew, op)) + cross(Ealpha, op));
-      const m33 Ro = m33{jd.off_R[0], jd.off_R[1], jd.off_R[2], jd.off_R[3], jd.off_R[4],
-                         jd.off_R[5], jd.off_R[6], jd.off_R[7], jd.off_R[8]};
-      Q = qmul(EQ, d4{jd.off_quat[0], jd.off_quat[1], jd.off_quat[2], jd.off_quat[3]});
+      const m33 Ro = m33{cget(cp, jb + JC_OFFR + 0), cget(cp, jb + JC_OFFR + 1), cget(cp, jb + JC_OFFR + 2),
+                         cget(cp, jb + JC_OFFR + 3), cget(cp, jb + JC_OFFR + 4), cget(cp, jb + JC_OFFR + 5),
+                         cget(cp, jb + JC_OFFR + 6), cget(cp, jb + JC_OFFR + 7), cget(cp, jb + JC_OFFR + 8)};
+      Q = qmul(EQ, d4{cget(cp, jb + JC_OFFQ), cget(cp, jb + JC_OFFQ + 1), cget(cp, jb + JC_OFFQ + 2),
+                      cget(cp, jb + JC_OFFQ + 3)});
       alpha = mulT(Ealpha, Ro);
       w = mulT(Ew, Ro);
-      if (lane == 0) {
-        ws.Lpos[j][0] = pos.x; ws.Lpos[j][1] = pos.y; ws.Lpos[j][2] = pos.z;
-        ws.Lquat[j][0] = Q.w; ws.Lquat[j][1] = Q.x; ws.Lquat[j][2] = Q.y; ws.Lquat[j][3] = Q.z;
-      }
       // inertia_3D::doForce terms (inertia.cpp:111-122), applied in the backward sweep
-      cr.Fi[j] = jd.mass * qrot(qinv(Q), acc);
-      cr.Ti[j] = sym_mul(jd.inertia, alpha) + cross(w, sym_mul(jd.inertia, w));
+      const double inertia[6] = {cget(cp, jb + JC_INER), cget(cp, jb + JC_INER + 1), cget(cp, jb + JC_INER + 2),
+                                 cget(cp, jb + JC_INER + 3), cget(cp, jb + JC_INER + 4), cget(cp, jb + JC_INER + 5)};
+      const d3 Fi = cget(cp, jb + JC_MASS) * qrot(qinv(Q), acc);
+      const d3 Ti = sym_mul(inertia, alpha) + cross(w, sym_mul(inertia, w));
+      st3(lead ? ws.Lpos[j] : sink, pos);
+      st4(lead ? ws.Lquat[j] : sink, Q);
+      st3(lead ? ws.FT[j] : sink, Fi);
+      st3(lead ? ws.FT[j] + 3 : sink, Ti);
     }
   }
   __syncthreads();
+  RKH_STAMP(1)
 
   // ---- jacobian columns, one lane per (body b, coord c <= b): get_jac_relative_to
   //      (motion_jacobians.hpp:238-251) with f2 = (~F_c) * F_b (frame_3D.hpp:184-189,222-238,368-382)
-  {
-    int b = 0, c = lane;  // unrank lane -> (b, c), c <= b
+  for (int p = gl; p < N * (N + 1) / 2; p += GL) {
+    int b = 0, c = p;  // unrank p -> (b, c), c <= b
     while (c > b) {
       c -= b + 1;
       ++b;
     }
-    if (b < N) {
-      const d3 cp = mk3(ws.Epos[c][0], ws.Epos[c][1], ws.Epos[c][2]);
-      const d4 cq = d4{ws.Equat[c][0], ws.Equat[c][1], ws.Equat[c][2], ws.Equat[c][3]};
-      const d3 bp = mk3(ws.Lpos[b][0], ws.Lpos[b][1], ws.Lpos[b][2]);
-      const d4 bq = d4{ws.Lquat[b][0], ws.Lquat[b][1], ws.Lquat[b][2], ws.Lquat[b][3]};
-      const m33 R = rotmat(cq);
-      const d4 iq = qinv(cq);
-      const d3 ipos = mulT(-cp, R);
-      const m33 Ri = rotmat(iq);
-      const d3 f2pos = ipos + mul(Ri, bp);
-      const d4 f2q = qmul(iq, bq);
-      const m33 Rf = rotmat(f2q);
-      const d3 axis = mk3(sc->joints[c].axis[0], sc->joints[c].axis[1], sc->joints[c].axis[2]);
-      const d3 wt = mulT(axis, Rf);
-      const d3 vt = mulT(cross(axis, f2pos), Rf);
-      ws.Tcm[b][c][0] = vt.x; ws.Tcm[b][c][1] = vt.y; ws.Tcm[b][c][2] = vt.z;
-      ws.Tcm[b][c][3] = wt.x; ws.Tcm[b][c][4] = wt.y; ws.Tcm[b][c][5] = wt.z;
-    }
+    const d3 cp = ld3(ws.Epos[c]);
+    const d4 cq = ld4(ws.Equat[c]);
+    const d3 bp = ld3(ws.Lpos[b]);
+    const d4 bq = ld4(ws.Lquat[b]);
+    const m33 R = rotmat(cq);
+    const d4 iq = qinv(cq);
+    const d3 ipos = mulT(-cp, R);
+    const m33 Ri = rotmat(iq);
+    const d3 f2pos = ipos + mul(Ri, bp);
+    const d4 f2q = qmul(iq, bq);
+    const m33 Rf = rotmat(f2q);
+    const d3 axis = ld3(jl[c].axis);
+    const d3 wt = mulT(axis, Rf);
+    const d3 vt = mulT(cross(axis, f2pos), Rf);
+    st3(ws.Tcm[b][c], vt);
+    st3(ws.Tcm[b][c] + 3, wt);
   }
 
-  // ---- tip -> base sweep (kte_map_chain::doForce in reverse op order), wave-uniform
-  double f[N];
+  RKH_STAMP(2)
+  // ---- tip -> base sweep (kte_map_chain::doForce in reverse op order), group-uniform
+  double f_mine = 0.0;  // lane i < N keeps generalized force i
   {
     d3 LF = mk3(0, 0, 0), LT = mk3(0, 0, 0);
 #pragma unroll
     for (int j = N - 1; j >= 0; --j) {
-      const JointDev& jd = sc->joints[j];
-      const d3 axis = mk3(jd.axis[0], jd.axis[1], jd.axis[2]);
+      const int jb = j * 32;
+      const d3 axis = cget3(cp, jb + JC_AXIS);
       // inertia_3D::doForce on the link end frame
-      LF = LF - cr.Fi[j];
-      LT = LT - cr.Ti[j];
+      LF = LF - ld3(ws.FT[j]);
+      LT = LT - ld3(ws.FT[j] + 3);
       // rigid_link_3D::doForce (rigid_link.cpp:170-178)
-      const m33 Ro = m33{jd.off_R[0], jd.off_R[1], jd.off_R[2], jd.off_R[3], jd.off_R[4],
-                         jd.off_R[5], jd.off_R[6], jd.off_R[7], jd.off_R[8]};
-      const d3 op = mk3(jd.off_pos[0], jd.off_pos[1], jd.off_pos[2]);
+      const m33 Ro = m33{cget(cp, jb + JC_OFFR + 0), cget(cp, jb + JC_OFFR + 1), cget(cp, jb + JC_OFFR + 2),
+                         cget(cp, jb + JC_OFFR + 3), cget(cp, jb + JC_OFFR + 4), cget(cp, jb + JC_OFFR + 5),
+                         cget(cp, jb + JC_OFFR + 6), cget(cp, jb + JC_OFFR + 7), cget(cp, jb + JC_OFFR + 8)};
+      const d3 op = cget3(cp, jb + JC_OFFP);
       const d3 tmp_force = mul(Ro, LF);
-      const d3 EF = tmp_force;
       const d3 ET = mul(Ro, LT) + cross(op, tmp_force);
       // revolute_joint_3D::doForce (revolute_joint.cpp:170-181)
-      const m33 Ra = axis_angle_rotmat(cr.c1[j], cr.s1[j], mk3(jd.axis_n[0], jd.axis_n[1], jd.axis_n[2]));
+      const m33 Ra = axis_angle_rotmat(ws.cs[j][2], ws.cs[j][3], cget3(cp, jb + JC_AXISN));
       const double ta = dot(ET, axis);
-      LF = mul(Ra, EF);
+      LF = mul(Ra, tmp_force);
       LT = mul(Ra, ET - ta * axis);
       // inertia_gen::doForce: f -= q_ddot * mass with q_ddot = 0 ; driving_actuator_gen::doForce
-      f[j] = ta + u[j];
-      LT = LT - u[j] * axis;
+      const double uj = ws.u[j];
+      const double fj = ta + uj;
+      LT = LT - uj * axis;
+      f_mine = (gl == j) ? fj : f_mine;
     }
   }
+  if (gl < N) ws.tmp[gl] = f_mine;  // bias force, kept for the kernel-level parity export
   __syncthreads();
+  RKH_STAMP(3)
 
-  // ---- M = Tcm^T (Mcm Tcm), one lane per entry (i,j), summation order of
+  // ---- Mf = Tcm^T (Mcm Tcm), one lane per entry (i,j), summation order of
   //      mat_alg_symmetric.hpp:551-566 (Mcm*Tcm) and mat_operators.hpp:104-114 (dense product)
-  {
-    const int i = lane / N, jx = lane % N;
+  for (int e = gl; e < N * N; e += GL) {
+    const int i = e / N, jx = e % N;
     double s = 0.0;
-    if (lane < N * N) {
-      if (i == jx) s = s + sc->joints[i].joint_inertia;  // inertia_gen rows: Tcm = 1, Mcm = rotor inertia
+    if (i == jx) s = s + jl[i].joint_inertia;  // inertia_gen rows: Tcm = 1, Mcm = rotor inertia
 #pragma unroll
-      for (int b = 0; b < N; ++b) {
-        if (b >= i && b >= jx) {
-          const JointDev& jd = sc->joints[b];
-          const double* Ti = ws.Tcm[b][i];
-          const double* Tj = ws.Tcm[b][jx];
-          s = s + Ti[0] * (jd.mass * Tj[0]);
-          s = s + Ti[1] * (jd.mass * Tj[1]);
-          s = s + Ti[2] * (jd.mass * Tj[2]);
-          const d3 P = sym_mul(jd.inertia, mk3(Tj[3], Tj[4], Tj[5]));
-          s = s + Ti[3] * P.x;
-          s = s + Ti[4] * P.y;
-          s = s + Ti[5] * P.z;
-        }
+    for (int b = 0; b < N; ++b) {
+      if (b >= i && b >= jx) {
+        const int bb = b * 32;
+        const double mass = cget(cp, bb + JC_MASS);
+        const double inertia[6] = {cget(cp, bb + JC_INER), cget(cp, bb + JC_INER + 1), cget(cp, bb + JC_INER + 2),
+                                   cget(cp, bb + JC_INER + 3), cget(cp, bb + JC_INER + 4), cget(cp, bb + JC_INER + 5)};
+        const double* Ti = ws.Tcm[b][i];
+        const double* Tj = ws.Tcm[b][jx];
+        s = s + Ti[0] * (mass * Tj[0]);
+        s = s + Ti[1] * (mass * Tj[1]);
+        s = s + Ti[2] * (mass * Tj[2]);
+        const d3 P = sym_mul(inertia, mk3(Tj[3], Tj[4], Tj[5]));
+        s = s + Ti[3] * P.x;
+        s = s + Ti[4] * P.y;
+        s = s + Ti[5] * P.z;
       }
     }
-    // mat<symmetric>(general): 0.5 * (M(j,i) + M(i,j))  (mat_alg_symmetric.hpp:183-187)
-    const int tl = (lane < N * N) ? (jx * N + i) : lane;
-    const double st = __shfl(s, tl, 64);
-    if (lane < N * N) {
-      const double m = (i == jx) ? s : ((i > jx) ? 0.5 * (st + s) : 0.5 * (s + st));
-      ws.M[i][jx] = m;
-      if (M_out) M_out[lane] = m;
-    }
+    ws.Mf[i][jx] = s;
   }
-  if (f_out && lane < N) {
-    double fv = 0.0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) fv = (lane == j) ? f[j] : fv;
-    f_out[lane] = fv;
+  __syncthreads();
+  // mat<symmetric>(general): 0.5 * (M(j,i) + M(i,j)), j < i  (mat_alg_symmetric.hpp:183-187)
+  for (int e = gl; e < N * N; e += GL) {
+    const int i = e / N, jx = e % N;
+    const int lo = i < jx ? i : jx, hi = i < jx ? jx : i;
+    ws.M[i][jx] = (i == jx) ? ws.Mf[i][i] : 0.5 * (ws.Mf[lo][hi] + ws.Mf[hi][lo]);
   }
   __syncthreads();
 
-  // ---- linsolve_Cholesky (mat_cholesky.hpp:546-554), wave-uniform
-  double L[N][N];
+  RKH_STAMP(4)
+  // ---- linsolve_Cholesky (mat_cholesky.hpp:546-554): lane i owns row i; every L(i,j) is formed by the
+  //      reference's operation sequence (A(i,j), minus L(i,k) L(j,k) for k ascending, divided by L(j,j))
+  const int row = gl < N ? gl : N - 1;
+  double Lrow[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) Lrow[k] = 0.0;
   bool sing = false;
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
+  for (int j = 0; j < N; ++j) {
+    // pivot of column j, computed by every lane from row j (already final in LDS for k < j)
+    double dgl = ws.M[j][j];
 #pragma unroll
-    for (int j = 0; j < i; ++j) {
-      double v = ws.M[i][j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) v = v - L[i][k] * L[j][k];
-      L[i][j] = v / L[j][j];
+    for (int k = 0; k < j; ++k) {
+      const double ljk = ws.M[j][k];
+      dgl = dgl - ljk * ljk;
     }
-    double dgl = ws.M[i][i];
-#pragma unroll
-    for (int k = 0; k < i; ++k) dgl = dgl - L[i][k] * L[i][k];
     if (dgl < 1e-8) sing = true;
-    L[i][i] = sqrt(dgl);
+    const double ljj = sqrt(dgl);
+    double v = ws.M[row][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) v = v - Lrow[k] * ws.M[j][k];
+    v = v / ljj;
+    Lrow[j] = (row == j) ? ljj : v;
+    if (gl < N && row >= j) ws.M[row][j] = Lrow[j];
+    __syncthreads();
+  }
+  // backsub_Cholesky_impl (mat_cholesky.hpp:160-178): L y = f, then L^T x = y
+  double diag = 1.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) diag = (row == k) ? Lrow[k] : diag;
+  double accv = f_mine;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double yk = __shfl(accv / diag, gb + k, 64);
+    if (row == k) accv = yk;
+    else if (row > k) accv = accv - Lrow[k] * yk;
   }
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-#pragma unroll
-    for (int k = 0; k < i; ++k) f[i] = f[i] - L[i][k] * f[k];
-    f[i] = f[i] / L[i][i];
-  }
-#pragma unroll
-  for (int i = N - 1; i >= 0; --i) {
-#pragma unroll
-    for (int k = N - 1; k > i; --k) f[i] = f[i] - L[k][i] * f[k];
-    f[i] = f[i] / L[i][i];
+  for (int k = N - 1; k >= 0; --k) {
+    const double xk = __shfl(accv / diag, gb + k, 64);
+    if (row == k) accv = xk;
+    else if (row < k) accv = accv - ws.M[k][row] * xk;
   }
   if (sing) *singular = true;
 
   // pd[2j] = q_dot_j ; pd[2j+1] = qdd_j  (kte_nl_system.hpp:276-279)
-  double out = __shfl(xv, lane | 1, 64);
-  if (lane & 1) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) out = (lane == 2 * j + 1) ? f[j] : out;
-  }
+  const double qdd = __shfl(accv, gb + (gl >> 1), 64);
+  double out = 0.0;
+  if (gl < D) out = (gl & 1) ? qdd : ws.x[gl + 1];
+  RKH_STAMP(5)
+#undef RKH_STAMP
   return out;
 }
 
-// Proximity verdict for the configuration whose joint half-angle sin/cos are (c2, s2):
-// returns the minimum distance over computed pairs; with cull_positive, pairs whose bounding
-// spheres are apart are skipped (they cannot make the verdict "colliding",
-// proxy_query_model.cpp:386-389 culls the same way against the running minimum).
-template <int N>
-__device__ double proximity_min(const SceneDev* __restrict__ sc, const ShapeDev* __restrict__ env_lds,
-                                const PairDev* __restrict__ pairs, int n_pairs, WaveWs<N>& ws,
-                                const double (&c2)[N], const double (&s2)[N], int lane, bool cull_positive) {
-  fk_pose_chain<N>(sc, c2, s2, ws, lane);
+// Proximity of the configuration in ws.x (joint angles): minimum distance over computed pairs.
+// With cull_positive, pairs whose bounding spheres are apart are skipped (they cannot make the verdict
+// "colliding"; proxy_query_model.cpp:386-389 culls the same way against the running minimum) and the scan
+// stops once every edge of the wave has met a negative distance.
+template <int N, int GL>
+__device__ double proximity_min(const SceneDev* __restrict__ sc, const CPack<N>& cp,
+                                const double* __restrict__ base, const ShapeDev* __restrict__ env_lds,
+                                const PairDev* __restrict__ pairs, int n_pairs, GroupWs<N>& ws,
+                                double* __restrict__ sink, int gl, int gb, bool cull_positive, bool group_done) {
+  const bool lead = (gl == 0);
+  // half-angle sin/cos by lanes 2j
+  if (gl < 2 * N && !(gl & 1)) {
+    double sn, cs;
+    sincos(0.5 * ws.x[gl], &sn, &cs);
+    ws.cs[gl >> 1][0] = cs;
+    ws.cs[gl >> 1][1] = sn;
+  }
   __syncthreads();
-  // robot shapes -> global pose (pose_3D::getGlobalPose, pose_3D.hpp:102-110), lane r < n_robot
-  if (lane < sc->n_robot) {
-    const ShapeDev& sh = sc->robot[lane];
+  {  // revolute_joint_3D / rigid_link_3D kinematics, position + orientation only
+    d3 pos = ld3(base);
+    d4 Q = ld4(base + 3);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int jb = j * 32;
+      const d3 axis_n = cget3(cp, jb + JC_AXISN);
+      const double c2 = ws.cs[j][0], s2 = ws.cs[j][1];
+      const d4 tq = d4{c2, axis_n.x * s2, axis_n.y * s2, axis_n.z * s2};
+      const d4 EQ = qmul(Q, tq);
+      st3(lead ? ws.Epos[j] : sink, pos);
+      st4(lead ? ws.Equat[j] : sink, EQ);
+      const m33 R = rotmat(EQ);
+      pos = pos + mul(R, cget3(cp, jb + JC_OFFP));
+      Q = qmul(EQ, d4{cget(cp, jb + JC_OFFQ), cget(cp, jb + JC_OFFQ + 1), cget(cp, jb + JC_OFFQ + 2),
+                      cget(cp, jb + JC_OFFQ + 3)});
+    }
+  }
+  __syncthreads();
+  // robot shapes -> global pose (pose_3D::getGlobalPose, pose_3D.hpp:102-110)
+  for (int r = gl; r < sc->n_robot; r += GL) {
+    const ShapeDev& sh = sc->robot[r];
     const int j = sh.link;
-    const d3 pp = mk3(ws.Epos[j][0], ws.Epos[j][1], ws.Epos[j][2]);
-    const d4 pq = d4{ws.Equat[j][0], ws.Equat[j][1], ws.Equat[j][2], ws.Equat[j][3]};
-    const d3 gp = pp + qrot(pq, mk3(sh.pos[0], sh.pos[1], sh.pos[2]));
-    const d4 gq = qmul(pq, d4{sh.quat[0], sh.quat[1], sh.quat[2], sh.quat[3]});
-    ws.Rpos[lane][0] = gp.x; ws.Rpos[lane][1] = gp.y; ws.Rpos[lane][2] = gp.z;
-    ws.Rquat[lane][0] = gq.w; ws.Rquat[lane][1] = gq.x; ws.Rquat[lane][2] = gq.y; ws.Rquat[lane][3] = gq.z;
+    const d3 pp = ld3(ws.Epos[j]);
+    const d4 pq = ld4(ws.Equat[j]);
+    st3(ws.Rpos[r], pp + qrot(pq, ld3(sh.pos)));
+    st4(ws.Rquat[r], qmul(pq, ld4(sh.quat)));
   }
   __syncthreads();
   double dmin = INFINITY;
-  for (int p0 = 0; p0 < n_pairs; p0 += 64) {
-    const int p = p0 + lane;
+  bool hit = group_done;  // finished edges of the wave do not hold the scan open
+  for (int p0 = 0; p0 < n_pairs; p0 += GL) {
+    const int p = p0 + gl;
     double d = INFINITY;
-    if (p < n_pairs) {
+    if (p < n_pairs && !hit) {
       const PairDev pr = pairs[p];
       const ShapeDev& rs = sc->robot[pr.robot];
       const ShapeDev& es = env_lds[pr.env];
       ShapeG A, Bv;
       A.kind = rs.kind;
-      A.pos = mk3(ws.Rpos[pr.robot][0], ws.Rpos[pr.robot][1], ws.Rpos[pr.robot][2]);
-      A.q = d4{ws.Rquat[pr.robot][0], ws.Rquat[pr.robot][1], ws.Rquat[pr.robot][2], ws.Rquat[pr.robot][3]};
+      A.pos = ld3(ws.Rpos[pr.robot]);
+      A.q = ld4(ws.Rquat[pr.robot]);
       A.d0 = rs.dims[0]; A.d1 = rs.dims[1]; A.d2 = rs.dims[2];
       Bv.kind = es.kind;
-      Bv.pos = mk3(es.pos[0], es.pos[1], es.pos[2]);
-      Bv.q = d4{es.quat[0], es.quat[1], es.quat[2], es.quat[3]};
+      Bv.pos = ld3(es.pos);
+      Bv.q = ld4(es.quat);
       Bv.d0 = es.dims[0]; Bv.d1 = es.dims[1]; Bv.d2 = es.dims[2];
       bool skip = false;
       if (cull_positive) {
@@ -335,79 +446,100 @@ __device__ double proximity_min(const SceneDev* __restrict__ sc, const ShapeDev*
       if (!skip) d = pr.s1_is_robot ? pair_distance(pr.routine, A, Bv) : pair_distance(pr.routine, Bv, A);
     }
     if (d < dmin) dmin = d;
-    if (cull_positive && __ballot(d < 0.0) != 0ull) break;
+    if (cull_positive) {
+      // per-edge "any lane found a negative distance", then stop when every edge of the wave has one
+      const unsigned long long m = __ballot(d < 0.0);
+      const unsigned long long gm = (GL == 64) ? m : ((m >> gb) & ((1ull << (GL & 63)) - 1ull));
+      hit = hit || (gm != 0ull);
+      if (__all(hit)) break;
+    }
   }
-  // wave min
+  // group min
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
+  for (int off = GL / 2; off > 0; off >>= 1) {
     const double o = __shfl_xor(dmin, off, 64);
     if (o < dmin) dmin = o;
   }
   return dmin;
 }
 
-__device__ __forceinline__ void stage_env(const SceneDev* __restrict__ sc, ShapeDev* env_lds, int lane) {
-  const int n_words = sc->n_env * int(sizeof(ShapeDev) / sizeof(double));
-  const double* src = reinterpret_cast<const double*>(sc->env);
-  double* dst = reinterpret_cast<double*>(env_lds);
-  for (int i = lane; i < n_words; i += 64) dst[i] = src[i];
+// exact left-to-right euclidean metric of a lane-distributed difference vector
+// (vect_distance_metrics.hpp:126-137): stage the squares in LDS, every lane sums them in order
+template <int N>
+RKH_DI double group_norm(GroupWs<N>& ws, double diff, int gl) {
+  if (gl < 2 * N) ws.tmp[gl] = diff * diff;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int d = 0; d < 2 * N; ++d) s = s + ws.tmp[d];
+  __syncthreads();
+  return sqrt(s);
 }
 
+template <int N, int GL>
+struct SmemLayout {
+  static constexpr size_t block_bytes = (sizeof(BlockLds<N, GL>) + 15) / 16 * 16;
+  static size_t bytes(int n_env) { return block_bytes + size_t(n_env) * sizeof(ShapeDev); }
+};
+
 // ---------------------------------------------------------------------------------------------
-// Kernel: steer B edges. One block (= one wave) per edge.
-//   a: source state of edge e = src + src_idx[e] * src_stride (src_idx may be null -> e)
-//   tgt: [B][2N] target states
-// Outputs: x_out [B][2N] last free state, steps_free[B], record (optional) [B][n_steps+1][2N]
-template <int N>
-__global__ __launch_bounds__(64) void propagate_kernel(const SceneDev* __restrict__ sc, const PairDev* __restrict__ pairs,
-                                                        int n_pairs, DynDev dyn, EdgeIO io_a, EdgeIO io_b,
-                                                        uint32_t grid_a) {
-  // two edge groups per launch (planner: this round's steer candidates + the previous round's goal probes)
-  const bool group_b = blockIdx.x >= grid_a;
-  const EdgeIO& io = group_b ? io_b : io_a;
+// Kernel: steer edges.  Two edge groups per launch (planner: this round's steer candidates + the
+// previous round's goal probes); 64/GL edges per wave.
+template <int N, int GL>
+__global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __restrict__ sc,
+                                                           const PairDev* __restrict__ pairs, int n_pairs, DynDev dyn,
+                                                           EdgeIO io_a, EdgeIO io_b, const EdgeIO* __restrict__ tab_a,
+                                                           const EdgeIO* __restrict__ tab_b, uint32_t grid_a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  WaveWs<N>& ws = *reinterpret_cast<WaveWs<N>*>(smem_raw);
-  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + ((sizeof(WaveWs<N>) + 15) / 16) * 16);
+  constexpr int G = 64 / GL;
+  BlockLds<N, GL>& lds = *reinterpret_cast<BlockLds<N, GL>*>(smem_raw);
+  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayout<N, GL>::block_bytes);
+  // blockIdx.y selects the planning problem when per-problem EdgeIO tables are given
+  const bool group_b = blockIdx.x >= grid_a;
+  const EdgeIO io = tab_a ? (group_b ? tab_b[blockIdx.y] : tab_a[blockIdx.y]) : (group_b ? io_b : io_a);
   const uint32_t B = io.d_B ? *io.d_B : io.B;
-  const uint32_t e = group_b ? blockIdx.x - grid_a : blockIdx.x;
-  if (e >= B) return;
   const int lane = threadIdx.x;
+  const int g = lane / GL, gl = lane % GL, gb = g * GL;
+  const uint32_t e0 = (group_b ? blockIdx.x - grid_a : blockIdx.x) * G;
+  if (e0 >= B) return;
+  const uint32_t e = e0 + g;
+  const bool edge_valid = e < B;
+  const uint32_t ec = edge_valid ? e : e0;  // idle groups shadow the wave's first edge, results discarded
   constexpr int D = 2 * N;
+  stage_chain<N>(sc, lds.joints, lds.base, lane);
   stage_env(sc, env_lds, lane);
-  const uint32_t si = io.src_idx ? io.src_idx[e] : ((io.d_src_first ? *io.d_src_first : 0u) + e);
-  const uint64_t trow = (io.d_tgt_off ? uint64_t(*io.d_tgt_off) : 0ull) + e;
-  const double a_d = (lane < D) ? io.src[uint64_t(si) * io.src_stride + lane] : 0.0;
-  const double b_d = (lane < D) ? io.tgt[trow * io.tgt_stride + lane] : 0.0;
-  const double lo = (lane < D) ? dyn.lower[lane] : 0.0;
-  const double hi = (lane < D) ? dyn.upper[lane] : 0.0;
-  double* __restrict__ record = io.record;
+  GroupWs<N>& ws = lds.g[g];
+  const uint32_t si = io.src_idx ? io.src_idx[ec] : ((io.d_src_first ? *io.d_src_first : 0u) + ec);
+  const uint64_t trow = (io.d_tgt_off ? uint64_t(*io.d_tgt_off) : 0ull) + ec;
+  const double a_d = (gl < D) ? io.src[uint64_t(si) * io.src_stride + gl] : 0.0;
+  const double b_d = (gl < D) ? io.tgt[trow * io.tgt_stride + gl] : 0.0;
+  const double lo = (gl < D) ? dyn.lower[gl] : 0.0;
+  const double hi = (gl < D) ? dyn.upper[gl] : 0.0;
+  if (gl < D) ws.b[gl] = b_d;
+  double* __restrict__ record = edge_valid ? io.record : nullptr;
   const int record_stride = io.record_stride;
   __syncthreads();
+  const CPack<N> cp = load_cpack<N>(lds.joints, lane);
 
   double x = a_d;
   uint32_t n_free = 0;
-  bool singular = false;
-  if (record && lane < D) record[(uint64_t(e) * record_stride + 0) * D + lane] = x;
+  bool singular = false;   // a live edge met a singular mass matrix
+  bool alive = true;       // this edge is still stepping
+  if (record && gl < D) record[(uint64_t(e) * record_stride + 0) * D + gl] = x;
 
   for (int k = 0; k < dyn.n_steps; ++k) {
-    // distance(x_current, x_goal) > goal_proximity_threshold, exact left-to-right sum
-    {
-      double s = 0.0;
-      const double df = x - b_d;
-      const double sq = df * df;
-#pragma unroll
-      for (int d = 0; d < D; ++d) s = s + __shfl(sq, d, 64);
-      if (!(sqrt(s) > dyn.goal_tol)) break;
-    }
-    // PD law, zero-order hold over the step: lane j gets u_j
-    double uv;
-    {
-      const double eq = __shfl(b_d, 2 * (lane % N), 64) - __shfl(x, 2 * (lane % N), 64);
-      const double ev = __shfl(b_d, 2 * (lane % N) + 1, 64) - __shfl(x, 2 * (lane % N) + 1, 64);
-      double v = dyn.kp * eq + dyn.kd * ev;
+    // distance(x_current, x_goal) > goal_proximity_threshold
+    const double dist = group_norm<N>(ws, x - b_d, gl);
+    if (!(dist > dyn.goal_tol)) alive = false;
+    if (!__any(alive)) break;
+    // PD law, zero-order hold over the step
+    if (gl < D) ws.x[gl] = x;
+    __syncthreads();
+    if (gl < N) {
+      double v = dyn.kp * (ws.b[2 * gl] - ws.x[2 * gl]) + dyn.kd * (ws.b[2 * gl + 1] - ws.x[2 * gl + 1]);
       if (v > dyn.u_max) v = dyn.u_max;
       else if (v < -dyn.u_max) v = -dyn.u_max;
-      uv = v;
+      ws.u[gl] = v;
     }
     // runge_kutta4_integrate_impl (runge_kutta4_integrator_sys.hpp:53-97), time_step = dt.
     // One call site for f(x,u): each loop iteration of the reference evaluates f four times that
@@ -418,10 +550,13 @@ __global__ __launch_bounds__(64) void propagate_kernel(const SceneDev* __restric
     double xe = x;  // end_point
     {
       double w = xe, k1 = 0.0, k2 = 0.0, k3 = 0.0;
+      bool sing_now = false;
       const int n_evals = 4 * dyn.inner[k];
 #pragma unroll 1
       for (int ev = 0; ev < n_evals; ++ev) {
-        const double dp = state_derivative<N>(sc, ws, xe, uv, lane, &singular, nullptr, nullptr);
+        if (gl < D) ws.x[gl] = xe;
+        __syncthreads();
+        const double dp = state_derivative<N, GL>(cp, lds.joints, lds.base, ws, lds.sink[lane], gl, gb, &sing_now);
         const int stage = ev & 3;
         if (stage == 0) {
           w = xe;
@@ -437,57 +572,49 @@ __global__ __launch_bounds__(64) void propagate_kernel(const SceneDev* __restric
           xe = xe + ((((1.0 / 6.0) * k1 + (2.0 / 6.0) * k2) + (h / 6.0) * dp) - (2.0 / 3.0) * k3);
         }
       }
+      if (sing_now && alive) {
+        singular = true;
+        alive = false;
+      }
     }
-    if (singular) break;
     // is_free(x_next): hyperbox bounds (hyperbox_topology.hpp:178-189), then proximity
     bool oob = false;
-    if (lane < D) {
+    if (gl < D) {
       if (lo < hi) oob = (xe < lo) || (xe > hi);
       else oob = (xe > lo) || (xe < hi);
     }
-    if (__ballot(oob) != 0ull) break;
     {
-      double sn, cs;
-      sincos(0.5 * xe, &sn, &cs);
-      double c2[N], s2[N];
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        c2[j] = __shfl(cs, 2 * j, 64);
-        s2[j] = __shfl(sn, 2 * j, 64);
-      }
-      const double dmin = proximity_min<N>(sc, env_lds, pairs, n_pairs, ws, c2, s2, lane, true);
-      if (dmin < 0.0) break;
+      const unsigned long long m = __ballot(oob);
+      const unsigned long long gm = (GL == 64) ? m : ((m >> gb) & ((1ull << (GL & 63)) - 1ull));
+      if (gm != 0ull) alive = false;
     }
-    x = xe;
-    ++n_free;
-    if (record && lane < D) record[(uint64_t(e) * record_stride + n_free) * D + lane] = x;
+    if (!__any(alive)) break;
+    if (gl < D) ws.x[gl] = xe;
+    __syncthreads();
+    const double dmin = proximity_min<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true, !alive);
+    if (dmin < 0.0) alive = false;
+    if (alive) {
+      x = xe;
+      ++n_free;
+      if (record && gl < D) record[(uint64_t(e) * record_stride + n_free) * D + gl] = x;
+    }
   }
-  if (singular && lane == 0) atomicExch(io.err_flag, int(RKH_ERR_SINGULAR));
-  if (lane < D) io.x_out[uint64_t(e) * D + lane] = x;
-  if (lane == 0) io.steps_free[e] = n_free;
+  if (singular && gl == 0 && edge_valid) atomicExch(io.err_flag, int(RKH_ERR_SINGULAR));
+  if (edge_valid && gl < D) io.x_out[uint64_t(e) * D + gl] = x;
+  if (edge_valid && gl == 0) io.steps_free[e] = n_free;
   if (io.mode != EDGE_PLAIN) {
-    // exact left-to-right euclidean metrics (vect_distance_metrics.hpp:126-137)
-    double s_ar = 0.0, s_ab = 0.0, s_rb = 0.0;
-    {
-      const double d1 = a_d - x, d2 = a_d - b_d, d3v = x - b_d;
-      const double q1 = d1 * d1, q2 = d2 * d2, q3 = d3v * d3v;
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        s_ar = s_ar + __shfl(q1, d, 64);
-        s_ab = s_ab + __shfl(q2, d, 64);
-        s_rb = s_rb + __shfl(q3, d, 64);
-      }
-    }
+    const double n_ar = group_norm<N>(ws, a_d - x, gl);
+    const double n_ab = group_norm<N>(ws, a_d - b_d, gl);
+    const double n_rb = group_norm<N>(ws, x - b_d, gl);
     if (io.mode == EDGE_STEER_ACCEPT) {
       // planning_visitor_base::steer_towards_position (planning_visitors.hpp:349-360)
-      const double traveled = sqrt(s_ar);
-      const double best_case = io.best_case ? io.best_case[e] : sqrt(s_ab);
+      const double traveled = n_ar;
+      const double best_case = io.best_case ? io.best_case[ec] : n_ab;
       const bool ok = (!isinf(traveled)) && (traveled < 2.0 * best_case) && (traveled > io.steer_tol * best_case);
-      if (lane == 0) io.accept[e] = ok ? 1 : 0;
+      if (edge_valid && gl == 0) io.accept[e] = ok ? 1 : 0;
     } else {
       // C_free distance used by the goal probe (MEAQR_topology.hpp:995-1003)
-      const double dab = sqrt(s_ab), drb = sqrt(s_rb);
-      if (lane == 0) io.goal_dist[si - 1] = (dab * 0.05 > drb) ? dab : INFINITY;
+      if (edge_valid && gl == 0) io.goal_dist[si - 1] = (n_ab * 0.05 > n_rb) ? n_ab : INFINITY;
     }
   }
 }
@@ -498,18 +625,71 @@ __global__ __launch_bounds__(64) void state_derivative_kernel(const SceneDev* __
                                                                const double* __restrict__ u, uint32_t B,
                                                                double* __restrict__ pd, double* __restrict__ M,
                                                                double* __restrict__ f, int* __restrict__ err_flag) {
-  __shared__ WaveWs<N> ws;
+  __shared__ BlockLds<N, 64> lds;
   const uint32_t e = blockIdx.x;
   if (e >= B) return;
   const int lane = threadIdx.x;
   constexpr int D = 2 * N;
-  const double xv = (lane < D) ? x[uint64_t(e) * D + lane] : 0.0;
-  const double uv = (lane < N) ? u[uint64_t(e) * N + lane] : 0.0;
+  stage_chain<N>(sc, lds.joints, lds.base, lane);
+  GroupWs<N>& ws = lds.g[0];
+  if (lane < D) ws.x[lane] = x[uint64_t(e) * D + lane];
+  if (lane < N) ws.u[lane] = u[uint64_t(e) * N + lane];
+  __syncthreads();
+  const CPack<N> cp = load_cpack<N>(lds.joints, lane);
   bool singular = false;
-  const double dp = state_derivative<N>(sc, ws, xv, uv, lane, &singular, M ? M + uint64_t(e) * N * N : nullptr,
-                                        f ? f + uint64_t(e) * N : nullptr);
+  const double dp = state_derivative<N, 64>(cp, lds.joints, lds.base, ws, lds.sink[lane], lane, 0, &singular);
   if (lane < D) pd[uint64_t(e) * D + lane] = dp;
   if (singular && lane == 0) atomicExch(err_flag, int(RKH_ERR_SINGULAR));
+  // exports for the kernel-level parity tests: the symmetric M is rebuilt from Mf (ws.M now holds its
+  // Cholesky factor); the bias force was parked in ws.tmp by state_derivative.
+  if (M && lane < N * N) {
+    const int i = lane / N, j = lane % N;
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    M[uint64_t(e) * N * N + lane] = (i == j) ? ws.Mf[i][i] : 0.5 * (ws.Mf[lo][hi] + ws.Mf[hi][lo]);
+  }
+  if (f && lane < N) f[uint64_t(e) * N + lane] = ws.tmp[lane];
+}
+
+// Diagnostic kernel (not on the product path): `iters` back-to-back f-evals + proximity tests of one edge per
+// wave, with s_memtime deltas per phase: [sincos, forward sweep, jacobian columns, force sweep, mass matrix,
+// cholesky, proximity, total].
+template <int N>
+__global__ __launch_bounds__(64) void feval_cycles_kernel(const SceneDev* __restrict__ sc, const PairDev* __restrict__ pairs,
+                                                           int n_pairs, const double* __restrict__ x,
+                                                           const double* __restrict__ u, int iters,
+                                                           unsigned long long* __restrict__ out, double* __restrict__ sink_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  BlockLds<N, 64>& lds = *reinterpret_cast<BlockLds<N, 64>*>(smem_raw);
+  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayout<N, 64>::block_bytes);
+  const int lane = threadIdx.x;
+  constexpr int D = 2 * N;
+  stage_chain<N>(sc, lds.joints, lds.base, lane);
+  stage_env(sc, env_lds, lane);
+  GroupWs<N>& ws = lds.g[0];
+  double xv = (lane < D) ? x[uint64_t(blockIdx.x) * D + lane] : 0.0;
+  if (lane < N) ws.u[lane] = u[uint64_t(blockIdx.x) * N + lane];
+  __syncthreads();
+  const CPack<N> cp = load_cpack<N>(lds.joints, lane);
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool singular = false;
+  double acc = 0.0;
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    if (lane < D) ws.x[lane] = xv;
+    __syncthreads();
+    const double dp = state_derivative<N, 64>(cp, lds.joints, lds.base, ws, lds.sink[lane], lane, 0, &singular, st);
+    xv = xv + 1e-4 * dp;
+    if (lane < D) ws.x[lane] = xv;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    acc += proximity_min<N, 64>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], lane, 0, true, false);
+    st[6] += __builtin_readcyclecounter() - t0;
+  }
+  st[7] = __builtin_readcyclecounter() - t_begin;
+  if (lane == 0) {
+    for (int i = 0; i < 8; ++i) out[blockIdx.x * 8 + i] = st[i];
+    sink_out[blockIdx.x] = acc + xv + (singular ? 1.0 : 0.0);
+  }
 }
 
 // Kernel: exact minimum proxy-pair distance for B states (no culling).
@@ -518,24 +698,19 @@ __global__ __launch_bounds__(64) void min_distance_kernel(const SceneDev* __rest
                                                            int n_pairs, const double* __restrict__ x, uint32_t B,
                                                            double* __restrict__ dist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  WaveWs<N>& ws = *reinterpret_cast<WaveWs<N>*>(smem_raw);
-  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + ((sizeof(WaveWs<N>) + 15) / 16) * 16);
+  BlockLds<N, 64>& lds = *reinterpret_cast<BlockLds<N, 64>*>(smem_raw);
+  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayout<N, 64>::block_bytes);
   const uint32_t e = blockIdx.x;
   if (e >= B) return;
   const int lane = threadIdx.x;
   constexpr int D = 2 * N;
+  stage_chain<N>(sc, lds.joints, lds.base, lane);
   stage_env(sc, env_lds, lane);
-  const double xv = (lane < D) ? x[uint64_t(e) * D + lane] : 0.0;
-  double sn, cs;
-  sincos(0.5 * xv, &sn, &cs);
-  double c2[N], s2[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    c2[j] = __shfl(cs, 2 * j, 64);
-    s2[j] = __shfl(sn, 2 * j, 64);
-  }
+  GroupWs<N>& ws = lds.g[0];
+  if (lane < D) ws.x[lane] = x[uint64_t(e) * D + lane];
   __syncthreads();
-  const double dmin = proximity_min<N>(sc, env_lds, pairs, n_pairs, ws, c2, s2, lane, false);
+  const CPack<N> cp = load_cpack<N>(lds.joints, lane);
+  const double dmin = proximity_min<N, 64>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], lane, 0, false, false);
   if (lane == 0) dist[e] = dmin;
 }
 
@@ -551,19 +726,33 @@ __global__ __launch_bounds__(64) void min_distance_kernel(const SceneDev* __rest
       return RKH_ERR_UNSUPPORTED;    \
   }
 
-template <int N>
-static size_t smem_bytes(int n_env) {
-  return ((sizeof(WaveWs<N>) + 15) / 16) * 16 + size_t(n_env) * sizeof(ShapeDev);
+template <int N, int GL>
+static void launch_propagate_t(hipStream_t s, int n_env, const SceneDev* d_scene, const PairDev* d_pairs, int n_pairs,
+                               const DynDev& dyn, const EdgeIO& io, uint32_t edges_a, const EdgeIO& io_b,
+                               uint32_t edges_b, const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems) {
+  constexpr uint32_t G = 64 / GL;
+  const uint32_t ga = (edges_a + G - 1) / G, gbk = (edges_b + G - 1) / G;
+  hipLaunchKernelGGL((propagate_kernel<N, GL>), dim3(ga + gbk, n_problems), dim3(64), (SmemLayout<N, GL>::bytes(n_env)),
+                     s, d_scene, d_pairs, n_pairs, dyn, io, io_b, tab_a, tab_b, ga);
 }
 
+// Steer `grid_edges` (+ `grid_b` of a second group) edges per problem.  Either the two EdgeIO are given by value
+// (n_problems = 1) or as device tables of n_problems entries each.
 rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                             int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges, const EdgeIO* io_b,
-                            uint32_t grid_b) {
-  if (grid_edges + grid_b == 0) return RKH_OK;
+                            uint32_t grid_b, int lanes_per_edge, const EdgeIO* tab_a, const EdgeIO* tab_b,
+                            uint32_t n_problems) {
+  const uint32_t eb = (io_b || tab_b) ? grid_b : 0u;
+  if (grid_edges + eb == 0 || n_problems == 0) return RKH_OK;
   const EdgeIO second = io_b ? *io_b : EdgeIO();
-  RKH_DISPATCH_N(n_dof, hipLaunchKernelGGL((propagate_kernel<N>), dim3(grid_edges + (io_b ? grid_b : 0u)), dim3(64),
-                                           smem_bytes<N>(n_env), s, d_scene, static_cast<const PairDev*>(d_pairs),
-                                           n_pairs, dyn, io, second, grid_edges));
+  const PairDev* pp = static_cast<const PairDev*>(d_pairs);
+  if (lanes_per_edge == 16) {
+    RKH_DISPATCH_N(n_dof, (launch_propagate_t<N, 16>(s, n_env, d_scene, pp, n_pairs, dyn, io, grid_edges, second, eb, tab_a,
+                                                     tab_b, n_problems)));
+  } else {
+    RKH_DISPATCH_N(n_dof, (launch_propagate_t<N, 64>(s, n_env, d_scene, pp, n_pairs, dyn, io, grid_edges, second, eb, tab_a,
+                                                     tab_b, n_problems)));
+  }
   RKH_HIP(hipGetLastError());
   return RKH_OK;
 }
@@ -577,11 +766,21 @@ rkh_status launch_state_derivative(hipStream_t s, int n_dof, const SceneDev* d_s
   return RKH_OK;
 }
 
+rkh_status launch_feval_cycles(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
+                               int n_pairs, const double* d_x, const double* d_u, uint32_t B, int iters,
+                               unsigned long long* d_out, double* d_sink) {
+  RKH_DISPATCH_N(n_dof, hipLaunchKernelGGL((feval_cycles_kernel<N>), dim3(B), dim3(64), (SmemLayout<N, 64>::bytes(n_env)),
+                                           s, d_scene, static_cast<const PairDev*>(d_pairs), n_pairs, d_x, d_u, iters, d_out,
+                                           d_sink));
+  RKH_HIP(hipGetLastError());
+  return RKH_OK;
+}
+
 rkh_status launch_min_distance(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs, int n_pairs,
                                const double* d_x, uint32_t B, double* d_dist) {
   if (B == 0) return RKH_OK;
-  RKH_DISPATCH_N(n_dof, hipLaunchKernelGGL((min_distance_kernel<N>), dim3(B), dim3(64), smem_bytes<N>(n_env), s, d_scene,
-                                           static_cast<const PairDev*>(d_pairs), n_pairs, d_x, B, d_dist));
+  RKH_DISPATCH_N(n_dof, hipLaunchKernelGGL((min_distance_kernel<N>), dim3(B), dim3(64), (SmemLayout<N, 64>::bytes(n_env)), s,
+                                           d_scene, static_cast<const PairDev*>(d_pairs), n_pairs, d_x, B, d_dist));
   RKH_HIP(hipGetLastError());
   return RKH_OK;
 }

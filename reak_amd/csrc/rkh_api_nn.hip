@@ -149,8 +149,16 @@ rkh_status rkh_nn_query1_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32
   if (B == 0) return RKH_OK;
   rkh_status st = ensure_partials(nn, B);
   if (st != RKH_OK) return st;
-  return launch_nn1(nn->ctx->stream, nn->st, nn->n, nullptr, d_q, nullptr, B, nullptr, d_idx, d_dist, nn->d_part_dist,
-                    nn->d_part_idx, nn->part_blocks);
+  NnArgs a;
+  a.pos = nn->st.d_pos;
+  a.n = nn->n;
+  a.q = d_q;
+  a.B = B;
+  a.part_dist = nn->d_part_dist;
+  a.part_idx = nn->d_part_idx;
+  a.idx = d_idx;
+  a.dist = d_dist;
+  return launch_nn1(nn->ctx->stream, nn->st.D, a, nullptr, 1, nn->n, B, nn->part_blocks);
 }
 
 rkh_status rkh_nn_query1(rkh_nn* nn, const double* q, uint32_t B, uint32_t* idx, double* dist) {

@@ -35,13 +35,23 @@ struct NnStore {
   int D = 0;
 };
 
-// 1-NN of B queries over the first n rows. If d_n != nullptr the vertex count is read on the device
-// (planner rounds enqueued without host sync) and n is only the host-side upper bound used to size the grid.
-rkh_status launch_nn1(hipStream_t s, const NnStore& st, uint64_t n, const uint32_t* d_n, const double* d_q,
-                      const uint32_t* d_qoff, uint32_t B, const uint32_t* d_B, uint32_t* d_idx, double* d_dist, double* d_part_dist,
-                      uint32_t* d_part_idx, uint32_t part_capacity_blocks, hipEvent_t ev0 = nullptr,
+struct NnArgs {  // one 1-NN problem: tree rows, queries, outputs (device pointers)
+  const double* pos = nullptr;        // [n][DP] vertex rows
+  uint64_t n = 0;                      // vertex count (used if d_n == nullptr)
+  const uint32_t* d_n = nullptr;       // vertex count read on the device (planner rounds enqueued without host sync)
+  const double* q = nullptr;           // [B][D] queries
+  const uint32_t* d_qoff = nullptr;    // optional row offset of the query block, read on the device
+  uint32_t B = 0;
+  const uint32_t* d_B = nullptr;       // query count read on the device
+  double* part_dist = nullptr;         // [blocks][Bpad] per-block partial minima
+  uint32_t* part_idx = nullptr;
+  uint32_t* idx = nullptr;             // [B] results
+  double* dist = nullptr;
+};
+rkh_status launch_nn1(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
+                      uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0 = nullptr,
                       hipEvent_t ev1 = nullptr);
-uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B);
+uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B, uint32_t n_problems = 1);
 rkh_status launch_nnk(hipStream_t s, const NnStore& st, uint64_t n, const double* d_q, uint32_t B, uint32_t k,
                       double radius, uint32_t* d_idx, double* d_dist, uint32_t* d_count);
 rkh_status launch_fill_uniform(hipStream_t s, const NnStore& st, uint64_t n, uint64_t seed);
@@ -153,10 +163,14 @@ struct EdgeIO {  // inputs / outputs of one propagate launch (all device pointer
 
 rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                             int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges,
-                            const EdgeIO* io_b = nullptr, uint32_t grid_b = 0);
+                            const EdgeIO* io_b = nullptr, uint32_t grid_b = 0, int lanes_per_edge = 64,
+                            const EdgeIO* tab_a = nullptr, const EdgeIO* tab_b = nullptr, uint32_t n_problems = 1);
 rkh_status launch_state_derivative(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x,
                                    const double* d_u, uint32_t B, double* d_pd, double* d_M, double* d_f, int* d_err);
 rkh_status launch_min_distance(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                                int n_pairs, const double* d_x, uint32_t B, double* d_dist);
+rkh_status launch_feval_cycles(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
+                               int n_pairs, const double* d_x, const double* d_u, uint32_t B, int iters,
+                               unsigned long long* d_out, double* d_sink);
 rkh_status build_dyn_dev(const rkh_dyn_space& sp, double fraction, DynDev* out);
 }  // namespace rkh

@@ -325,6 +325,27 @@ rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const dou
   return check_err_flag(scene);
 }
 
+rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double* u, uint32_t B, int iters,
+                                 uint64_t* cycles) {
+  if (!scene || !x || !u || !cycles || B == 0) return RKH_ERR_BAD_ARG;
+  const int n = scene->host.n_dof;
+  hipStream_t s = scene->ctx->stream;
+  DevBuf dx, du, dout, dsink;
+  RKH_HIP(hipMalloc(&dx.p, size_t(B) * 2 * n * 8));
+  RKH_HIP(hipMalloc(&du.p, size_t(B) * n * 8));
+  RKH_HIP(hipMalloc(&dout.p, size_t(B) * 8 * 8));
+  RKH_HIP(hipMalloc(&dsink.p, size_t(B) * 8));
+  RKH_HIP(hipMemcpyAsync(dx.p, x, size_t(B) * 2 * n * 8, hipMemcpyHostToDevice, s));
+  RKH_HIP(hipMemcpyAsync(du.p, u, size_t(B) * n * 8, hipMemcpyHostToDevice, s));
+  rkh_status st = launch_feval_cycles(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs,
+                                      dx.as<double>(), du.as<double>(), B, iters, dout.as<unsigned long long>(),
+                                      dsink.as<double>());
+  if (st != RKH_OK) return st;
+  RKH_HIP(hipMemcpyAsync(cycles, dout.p, size_t(B) * 8 * 8, hipMemcpyDeviceToHost, s));
+  RKH_HIP(hipStreamSynchronize(s));
+  return RKH_OK;
+}
+
 rkh_status rkh_edge_check(rkh_scene*, const double*, const double*, double, const double*, const double*, uint32_t,
                           double, double*, uint32_t*) {
   set_error("rkh_edge_check: quasi-static edge kernel not built yet");

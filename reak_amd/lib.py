@@ -52,7 +52,7 @@ EXPORTS = [
     "rkh_scene_create", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
-    "rkh_planner_nn_profile",
+    "rkh_planner_nn_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems",
 ]
 
 
@@ -102,13 +102,17 @@ def load():
     lib.rkh_state_derivative.argtypes = [vp, dp, dp, u32, dp, dp, dp]
     lib.rkh_min_distance.argtypes = [vp, dp, u32, dp]
     lib.rkh_propagate.argtypes = [vp, C.POINTER(T.DynSpace), dp, dp, u32, d, dp, u32p, dp]
+    lib.rkh_diag_feval_cycles.argtypes = [vp, dp, dp, u32, C.c_int, C.POINTER(C.c_uint64)]
     lib.rkh_edge_check.argtypes = [vp, dp, dp, d, dp, dp, u32, d, dp, u32p]
     lib.rkh_planner_create.argtypes = [vp, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), C.POINTER(vp)]
+    lib.rkh_planner_create_batch.argtypes = [vp, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), u32, C.POINTER(vp)]
+    lib.rkh_planner_num_problems.restype = u32
+    lib.rkh_planner_num_problems.argtypes = [vp]
     lib.rkh_planner_destroy.argtypes = [vp]
     lib.rkh_planner_enqueue.argtypes = [vp, u32]
     lib.rkh_planner_sync.argtypes = [vp, C.POINTER(PlannerStats)]
     lib.rkh_planner_solve.argtypes = [vp, C.POINTER(PlannerStats)]
-    lib.rkh_planner_get_tree.argtypes = [vp, dp, u32p, u32p, C.POINTER(C.c_uint8), dp]
+    lib.rkh_planner_get_tree.argtypes = [vp, u32, dp, u32p, u32p, C.POINTER(C.c_uint8), dp]
     lib.rkh_planner_stream.restype = vp
     lib.rkh_planner_stream.argtypes = [vp]
     lib.rkh_planner_nn_profile.argtypes = [vp, dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -225,6 +229,14 @@ class Scene:
         _check(self.lib.rkh_state_derivative(self.h, T.dptr(x), T.dptr(u), B, T.dptr(pd), T.dptr(M), T.dptr(f)))
         return pd, M, f
 
+    def diag_feval_cycles(self, x, u, iters=100):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.D)
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(-1, self.n)
+        out = np.zeros((x.shape[0], 8), dtype=np.uint64)
+        _check(self.lib.rkh_diag_feval_cycles(self.h, T.dptr(x), T.dptr(u), x.shape[0], iters,
+                                              out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
     def min_distance(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.D)
         d = np.zeros(x.shape[0])
@@ -256,13 +268,26 @@ class Scene:
 
 
 class RrtPlanner:
+    """rrt_planner over the steerable dynamic space.  `prm` is one rkh_rrt_params or a list of them (a batch of
+    independent problems sharing every kernel launch); `stats` is the first problem's, `all_stats` the array."""
+
     def __init__(self, scene, prm, dyn=None):
         self.scene, self.lib = scene, scene.lib
         self.dyn = dyn if dyn is not None else scene.scn.dyn
-        self.prm = prm
+        self.prms = list(prm) if isinstance(prm, (list, tuple)) else [prm]
+        self.P = len(self.prms)
+        self._prm_arr = T.as_array(self.prms, T.RrtParams)
         self.h = C.c_void_p()
-        _check(self.lib.rkh_planner_create(scene.h, C.byref(self.dyn), C.byref(prm), C.byref(self.h)))
-        self.stats = PlannerStats()
+        _check(self.lib.rkh_planner_create_batch(scene.h, C.byref(self.dyn), self._prm_arr, self.P, C.byref(self.h)))
+        self.all_stats = (PlannerStats * self.P)()
+
+    @property
+    def stats(self):
+        return self.all_stats[0]
+
+    @property
+    def done(self):
+        return all(s.done for s in self.all_stats)
 
     @property
     def stream(self):
@@ -272,26 +297,27 @@ class RrtPlanner:
         _check(self.lib.rkh_planner_enqueue(self.h, rounds))
 
     def sync(self):
-        _check(self.lib.rkh_planner_sync(self.h, C.byref(self.stats)))
-        return self.stats
+        _check(self.lib.rkh_planner_sync(self.h, self.all_stats))
+        return self.all_stats[0]
 
     def solve_planning_query(self):
-        _check(self.lib.rkh_planner_solve(self.h, C.byref(self.stats)))
-        return self.stats
+        _check(self.lib.rkh_planner_solve(self.h, self.all_stats))
+        return self.all_stats[0]
 
     def nn_profile(self):
         ms, by, ln = C.c_double(), C.c_uint64(), C.c_uint64()
         _check(self.lib.rkh_planner_nn_profile(self.h, C.byref(ms), C.byref(by), C.byref(ln)))
         return ms.value, by.value, ln.value
 
-    def tree(self):
-        nv, it, D = int(self.stats.num_vertices), int(self.stats.iterations), self.scene.D
+    def tree(self, problem=0):
+        st = self.all_stats[problem]
+        nv, it, D = int(st.num_vertices), int(st.iterations), self.scene.D
         pos = np.zeros((nv, D))
         parent = np.zeros(nv, dtype=np.uint32)
         nn_seq = np.zeros(max(it, 1), dtype=np.uint32)
         accept = np.zeros(max(it, 1), dtype=np.uint8)
         gd = np.zeros(max(nv - 1, 1))
-        _check(self.lib.rkh_planner_get_tree(self.h, T.dptr(pos), T.u32ptr(parent), T.u32ptr(nn_seq),
+        _check(self.lib.rkh_planner_get_tree(self.h, problem, T.dptr(pos), T.u32ptr(parent), T.u32ptr(nn_seq),
                                              accept.ctypes.data_as(C.POINTER(C.c_uint8)), T.dptr(gd)))
         return {"pos": pos, "parent": parent, "nn_seq": nn_seq[:it], "accept": accept[:it], "goal_dist": gd[: nv - 1]}
 
