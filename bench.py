@@ -136,7 +136,7 @@ def main():
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from reak_amd import lib, scenarios
+    from reak_amd import dist_utils, lib, scenarios
 
     os.environ.setdefault("RKH_PROFILE_NN", "1")
     ctx = lib.Context(local_rank)
@@ -146,7 +146,7 @@ def main():
     P = args.problems
 
     def run_step(step_index, timed):
-        seeds = [1 + (step_index * world + rank) * P + i for i in range(P)]
+        seeds = dist_utils.seeds_for_rank(step_index, rank, world, P)
         pl = lib.RrtPlanner(scene, [scn.rrt_params(seed=s, max_vertices=args.max_vertices) for s in seeds])
         pl.enqueue(0)  # sample chunks resident before the clock starts
         torch.cuda.synchronize()
@@ -189,17 +189,9 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_begin
 
-    nodes_all, edges_all, spec_all = tot["nodes"], tot["edges"], tot["spec"]
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([nodes_all, edges_all, spec_all], dtype=torch.int64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)  # tree-size / edge counters
-        nodes_all, edges_all, spec_all = (int(v) for v in c.tolist())
-        bc = torch.tensor([best], dtype=torch.float64, device="cuda")
-        dist.all_reduce(bc, op=dist.ReduceOp.MIN)  # best solution cost over all seeds
-        best = float(bc.item())
+    # tree-size / edge counters (sum) and best solution cost (min) over all seeds: the only collectives
+    elapsed, nodes_all, edges_all, spec_all, best = dist_utils.reduce_results(
+        dist, elapsed, tot["nodes"], tot["edges"], tot["spec"], best, torch.device("cuda", local_rank))
 
     if rank == 0:
         nn_gbps = (tot["nn_bytes"] / (tot["nn_ms"] * 1e-3) / 1e9) if tot["nn_ms"] > 0 else 0.0

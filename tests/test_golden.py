@@ -1,0 +1,77 @@
+"""Committed golden vectors (tests/golden/c2_golden.npz, written by tests/make_golden.py from the oracle).
+CPU: the oracle still reproduces them.  GPU: the HIP path reproduces them (same bars as test_gpu_parity.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from reak_amd import scenarios
+from reak_amd import types as T
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD, allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def c2():
+    return scenarios.make_c2(world_seed=1)
+
+
+def test_oracle_reproduces_golden(oracle, gold, c2):
+    osc = oracle.OracleScene(c2)
+    lib = oracle.load()
+    lo = np.array([c2.dyn.lower[i] for i in range(12)])
+    hi = np.array([c2.dyn.upper[i] for i in range(12)])
+    for seed in (1, 2, 3):
+        s = np.zeros((64, 12))
+        lib.orc_sample_hyperbox(seed, T.dptr(lo), T.dptr(hi), 12, 64, T.dptr(s))
+        assert np.array_equal(s, gold[f"samples_seed{seed}"])
+    rc, pd, M, f = osc.state_derivative(gold["fe_x"], gold["fe_u"])
+    assert rc == 0 and np.allclose(pd, gold["fe_pd"], rtol=1e-12, atol=1e-12) and np.allclose(M, gold["fe_M"], rtol=1e-13)
+    assert np.allclose(osc.min_distance(gold["prox_x"]), gold["prox_d"], atol=1e-13)
+    rc, xo, steps, _ = osc.steer(gold["steer_a"], gold["steer_b"])
+    assert np.array_equal(steps, gold["steer_steps"]) and np.allclose(xo, gold["steer_x"], rtol=1e-11, atol=1e-12)
+    idx, dist = oracle.nn1(gold["nn_q"], gold["nn_pts"])
+    assert np.array_equal(idx, gold["nn_idx"]) and np.array_equal(dist, gold["nn_dist"])
+    prm = c2.rrt_params(seed=2, max_vertices=1500)
+    rc, o, tree = osc.rrt_dyn(prm)
+    assert list(gold["rrt2_counts"]) == [o.num_vertices, o.iterations, o.edges_checked, o.num_solutions]
+    assert np.array_equal(tree["parent"], gold["rrt2_parent"]) and np.array_equal(tree["accept"], gold["rrt2_accept"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden(gold, c2):
+    from reak_amd import lib as L
+
+    ctx = L.Context(0)
+    sc = L.Scene(ctx, c2)
+    pd, M, f = sc.state_derivative(gold["fe_x"], gold["fe_u"])
+    assert np.allclose(pd, gold["fe_pd"], rtol=1e-10, atol=1e-10)
+    assert np.max(np.abs(M - gold["fe_M"])) <= 1e-13 * np.abs(gold["fe_M"]).max()
+    assert np.allclose(f, gold["fe_f"], rtol=1e-11, atol=1e-11)
+    d = sc.min_distance(gold["prox_x"])
+    assert np.allclose(d, gold["prox_d"], atol=1e-12)
+    far = np.abs(gold["prox_d"]) > 1e-12
+    assert np.array_equal((d < 0)[far], (gold["prox_d"] < 0)[far])
+    xo, steps, _ = sc.steer_position_toward(gold["steer_a"], gold["steer_b"])
+    assert np.array_equal(steps, gold["steer_steps"])
+    assert np.allclose(xo, gold["steer_x"], rtol=1e-10, atol=1e-12)
+    nn = L.HipNeighborSearch(ctx, 12, 3000)
+    nn.added_vertices(gold["nn_pts"])
+    idx, dist = nn.nearest(gold["nn_q"])
+    assert np.array_equal(idx, gold["nn_idx"]) and np.array_equal(dist, gold["nn_dist"])
+    # planner level: three seeds in ONE batch (one launch per kernel per round for all of them)
+    pl = L.RrtPlanner(sc, [c2.rrt_params(seed=s, max_vertices=1500) for s in (1, 2, 3)])
+    pl.solve_planning_query()
+    for i, seed in enumerate((1, 2, 3)):
+        st = pl.all_stats[i]
+        tree = pl.tree(i)
+        assert [st.num_vertices, st.iterations, st.edges_checked, st.num_solutions] == list(gold[f"rrt{seed}_counts"])
+        assert np.array_equal(tree["nn_seq"], gold[f"rrt{seed}_nn_seq"])
+        assert np.array_equal(tree["accept"], gold[f"rrt{seed}_accept"])
+        assert np.array_equal(tree["parent"], gold[f"rrt{seed}_parent"])
+        assert np.allclose(tree["pos"], gold[f"rrt{seed}_pos"], rtol=1e-10, atol=1e-12)
