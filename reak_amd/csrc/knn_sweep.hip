@@ -1,0 +1,260 @@
+// knn_sweep.hip -- exact batched k-nearest-neighbour (with radius) sweeps over the tree (gfx950).
+//
+// Replaces min_dist_linear_search k-NN (ctrl/path_planning/topological_search.hpp:244-274: bounded max-heap,
+// candidates need d < radius strictly, output ascending) with euclidean_distance_metric
+// (ctrl/topologies/vect_distance_metrics.hpp:113-150), as used by star_neighborhood
+// (ctrl/graph_alg/neighborhood_functors.hpp:95-102) for RRT* / PRM.
+//
+// A per-thread top-k does not fit registers (k = 4(floor(log2 n)+1) = 84 at n = 1M), so the search is
+//   A. bound sweep   : every thread keeps only the minimum of its own row subset; the k-th smallest of those
+//                      M = blocks x R subset minima is an upper bound tau on the k-th smallest distance overall
+//                      (k disjoint subsets each hold a vertex at least that close)
+//   B. collect sweep : every vertex with d <= tau and d < radius is appended to the query's candidate list
+//                      (about 1.2 k entries when M >= 4k); exact: the true k nearest are all in the list
+//   C. select        : one block per query sorts its candidates by (distance, index) and writes the first k.
+// Distances are the reference's left-to-right fp64 sums with a correctly rounded sqrt, so the returned set and
+// its order equal the CPU search's (among exactly equal distances the reference order is std::heap-defined; here
+// it is ascending index).  Same tile / broadcast structure as nn_sweep.hip; traffic is two passes over the rows.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+#include "rkh_internal.h"
+
+namespace rkh {
+
+int nn_padded_dims(int D);
+
+static constexpr int kTileRows = 256;
+static constexpr int kThreads = 256;
+static constexpr int kQB = 32;               // queries per block
+static constexpr int kR = kThreads / kQB;    // row subsets per block
+
+// MODE 0: bound sweep (writes per-thread subset minima).  MODE 1: collect sweep (appends candidates).
+template <int DP, int MODE>
+__global__ __launch_bounds__(kThreads) void knn_sweep_kernel(const double* __restrict__ pos, uint64_t n,
+                                                              const double* __restrict__ q, int D, uint32_t B,
+                                                              uint32_t Bpad, double radius, double* __restrict__ sub,
+                                                              const double* __restrict__ tau, uint32_t* __restrict__ cnt,
+                                                              double* __restrict__ cand_d, uint32_t* __restrict__ cand_i,
+                                                              uint32_t cmax, uint32_t* __restrict__ overflow) {
+  constexpr int ROWS_PER_THREAD = kTileRows / kR;
+  __shared__ __attribute__((aligned(16))) double tile[kTileRows * DP];
+  const int tid = threadIdx.x;
+  const int ql = tid % kQB;
+  const int r = tid / kQB;
+  const uint32_t qi = blockIdx.y * kQB + ql;
+  const bool q_valid = qi < B;
+  double qv[DP];
+  {
+    const uint64_t qsrc = q_valid ? qi : (B - 1);
+#pragma unroll
+    for (int d = 0; d < DP; ++d) qv[d] = d < D ? q[qsrc * D + d] : 0.0;
+  }
+  const uint64_t tiles_total = (n + kTileRows - 1) / kTileRows;
+  const uint64_t tiles_per_block = (tiles_total + gridDim.x - 1) / gridDim.x;
+  const uint64_t tile0 = uint64_t(blockIdx.x) * tiles_per_block;
+  uint64_t tile1 = tile0 + tiles_per_block;
+  if (tile1 > tiles_total) tile1 = tiles_total;
+
+  double best_s = INFINITY;  // MODE 0: smallest square of this thread's subset
+  double t_q = INFINITY, thr_s = INFINITY;
+  if (MODE == 1) {
+    t_q = tau[q_valid ? qi : 0];
+    // squares above this cannot give sqrt(s) <= tau (4 ulp of slack for the rounding of tau*tau and of sqrt)
+    thr_s = (t_q == INFINITY) ? INFINITY : (t_q * t_q) * (1.0 + 8.0 * DBL_EPSILON);
+  }
+  for (uint64_t t = tile0; t < tile1; ++t) {
+    const uint64_t row_base = t * kTileRows;
+    {
+      const double2* src = reinterpret_cast<const double2*>(pos + row_base * DP);
+      double2* dst = reinterpret_cast<double2*>(tile);
+      constexpr int N2 = kTileRows * DP / 2;
+      const uint64_t valid2 = (n - row_base >= uint64_t(kTileRows)) ? uint64_t(N2) : (n - row_base) * DP / 2;
+#pragma unroll 4
+      for (int i = tid; i < N2; i += kThreads) {
+        double2 v;
+        if (uint64_t(i) < valid2) v = src[i];
+        else v = make_double2(INFINITY, INFINITY);
+        dst[i] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int k = 0; k < ROWS_PER_THREAD; ++k) {
+      const int row = k * kR + r;
+      const double* p = tile + row * DP;
+      double df = qv[0] - p[0];
+      double s = df * df;
+#pragma unroll
+      for (int d = 1; d < DP; ++d) {
+        df = qv[d] - p[d];
+        s = s + df * df;
+      }
+      if (MODE == 0) {
+        if (s < best_s) best_s = s;
+      } else if (s <= thr_s && q_valid) {
+        const double dd = sqrt(s);
+        if (dd <= t_q && dd < radius) {
+          const uint32_t slot = atomicAdd(&cnt[qi], 1u);
+          if (slot < cmax) {
+            cand_d[uint64_t(qi) * cmax + slot] = dd;
+            cand_i[uint64_t(qi) * cmax + slot] = uint32_t(row_base + row);
+          } else {
+            *overflow = 1u;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (MODE == 0 && q_valid) sub[(uint64_t(blockIdx.x) * kR + r) * Bpad + qi] = sqrt(best_s);
+}
+
+// bitonic sort of (key, idx) pairs in LDS, ascending lexicographic; n_pow2 elements, blockDim.x threads
+__device__ __forceinline__ void bitonic_sort_lds(double* key, uint32_t* idx, uint32_t n_pow2) {
+  for (uint32_t size = 2; size <= n_pow2; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (uint32_t t = threadIdx.x; t < n_pow2 / 2; t += blockDim.x) {
+        const uint32_t lo = 2 * t - (t & (stride - 1));
+        const uint32_t hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const double ka = key[lo], kb = key[hi];
+        const uint32_t ia = idx[lo], ib = idx[hi];
+        const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
+        if (a_gt_b == up) {
+          key[lo] = kb; key[hi] = ka;
+          idx[lo] = ib; idx[hi] = ia;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// one block per query: tau = k-th smallest subset minimum (or +inf if there are fewer than k subsets)
+__global__ __launch_bounds__(256) void knn_tau_kernel(const double* __restrict__ sub, uint32_t m_sub, uint32_t m_pow2,
+                                                       uint32_t Bpad, uint32_t k, double* __restrict__ tau,
+                                                       uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* key = reinterpret_cast<double*>(smem);
+  uint32_t* idx = reinterpret_cast<uint32_t*>(key + m_pow2);
+  const uint32_t qi = blockIdx.x;
+  for (uint32_t i = threadIdx.x; i < m_pow2; i += blockDim.x) {
+    key[i] = i < m_sub ? sub[uint64_t(i) * Bpad + qi] : INFINITY;
+    idx[i] = i;
+  }
+  bitonic_sort_lds(key, idx, m_pow2);
+  if (threadIdx.x == 0) {
+    tau[qi] = (m_sub >= k) ? key[k - 1] : INFINITY;
+    cnt[qi] = 0;
+    if (qi == 0) *overflow = 0;
+  }
+}
+
+// one block per query: sort the candidates, write the first k (nearest first), pad the rest
+__global__ __launch_bounds__(256) void knn_select_kernel(const double* __restrict__ cand_d, const uint32_t* __restrict__ cand_i,
+                                                          const uint32_t* __restrict__ cnt, uint32_t cmax, uint32_t c_pow2,
+                                                          uint32_t k, uint32_t* __restrict__ out_idx,
+                                                          double* __restrict__ out_dist, uint32_t* __restrict__ out_cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* key = reinterpret_cast<double*>(smem);
+  uint32_t* idx = reinterpret_cast<uint32_t*>(key + c_pow2);
+  const uint32_t qi = blockIdx.x;
+  uint32_t nc = cnt[qi];
+  if (nc > cmax) nc = cmax;
+  for (uint32_t i = threadIdx.x; i < c_pow2; i += blockDim.x) {
+    key[i] = i < nc ? cand_d[uint64_t(qi) * cmax + i] : INFINITY;
+    idx[i] = i < nc ? cand_i[uint64_t(qi) * cmax + i] : 0xFFFFFFFFu;
+  }
+  bitonic_sort_lds(key, idx, c_pow2);
+  const uint32_t found = nc < k ? nc : k;
+  for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+    out_idx[uint64_t(qi) * k + i] = i < found ? idx[i] : 0xFFFFFFFFu;
+    out_dist[uint64_t(qi) * k + i] = i < found ? key[i] : INFINITY;
+  }
+  if (threadIdx.x == 0) out_cnt[qi] = found;
+}
+
+static uint32_t next_pow2(uint32_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+rkh_status knn_plan(uint64_t n, uint32_t B, uint32_t k, KnnWorkspace* ws, size_t* bytes) {
+  if (k == 0 || k > 1024) {
+    set_error("k-NN: k must be in [1, 1024]");
+    return RKH_ERR_BAD_ARG;
+  }
+  const uint32_t gy = (B + kQB - 1) / kQB;
+  uint64_t tiles = (n + kTileRows - 1) / kTileRows;
+  if (tiles < 1) tiles = 1;
+  // enough subsets for a tight bound (M >= 4k) and enough blocks to fill the chip, but M <= 4096 (LDS sort)
+  uint64_t gx = std::max<uint64_t>((4ull * k + kR - 1) / kR, 2048 / gy);
+  if (gx > tiles) gx = tiles;
+  if (gx > 4096 / kR) gx = 4096 / kR;
+  ws->gx = uint32_t(gx);
+  ws->m_sub = uint32_t(gx) * kR;
+  ws->cmax = std::max<uint32_t>(2048, next_pow2(8 * k));
+  if (ws->cmax > 4096) ws->cmax = 4096;
+  *bytes = 256 + size_t(ws->m_sub) * B * 8 + size_t(B) * 8 + size_t(B) * 4 + size_t(B) * ws->cmax * 12 + 64;
+  return RKH_OK;
+}
+
+void knn_carve(void* base, uint32_t B, KnnWorkspace* ws) {
+  unsigned char* p = static_cast<unsigned char*>(base);
+  ws->overflow = reinterpret_cast<uint32_t*>(p);
+  p += 256;
+  ws->sub = reinterpret_cast<double*>(p);
+  p += size_t(ws->m_sub) * B * 8;
+  ws->tau = reinterpret_cast<double*>(p);
+  p += size_t(B) * 8;
+  ws->cand_d = reinterpret_cast<double*>(p);
+  p += size_t(B) * ws->cmax * 8;
+  ws->cand_i = reinterpret_cast<uint32_t*>(p);
+  p += size_t(B) * ws->cmax * 4;
+  ws->cnt = reinterpret_cast<uint32_t*>(p);
+}
+
+template <int DP>
+static void launch_nnk_dp(hipStream_t s, const NnStore& st, uint64_t n, const double* d_q, uint32_t B, uint32_t k,
+                          double radius, uint32_t* d_idx, double* d_dist, uint32_t* d_count, const KnnWorkspace& ws) {
+  const uint32_t gy = (B + kQB - 1) / kQB;
+  dim3 grid(ws.gx, gy), block(kThreads);
+  hipLaunchKernelGGL((knn_sweep_kernel<DP, 0>), grid, block, 0, s, st.d_pos, n, d_q, st.D, B, B, radius, ws.sub, nullptr,
+                     nullptr, nullptr, nullptr, ws.cmax, ws.overflow);
+  const uint32_t m_pow2 = next_pow2(ws.m_sub);
+  hipLaunchKernelGGL(knn_tau_kernel, dim3(B), dim3(256), size_t(m_pow2) * 12, s, ws.sub, ws.m_sub, m_pow2, B, k, ws.tau,
+                     ws.cnt, ws.overflow);
+  hipLaunchKernelGGL((knn_sweep_kernel<DP, 1>), grid, block, 0, s, st.d_pos, n, d_q, st.D, B, B, radius, nullptr, ws.tau,
+                     ws.cnt, ws.cand_d, ws.cand_i, ws.cmax, ws.overflow);
+  hipLaunchKernelGGL(knn_select_kernel, dim3(B), dim3(256), size_t(ws.cmax) * 12, s, ws.cand_d, ws.cand_i, ws.cnt, ws.cmax,
+                     ws.cmax, k, d_idx, d_dist, d_count);
+}
+
+rkh_status launch_nnk(hipStream_t s, const NnStore& st, uint64_t n, const double* d_q, uint32_t B, uint32_t k,
+                      double radius, uint32_t* d_idx, double* d_dist, uint32_t* d_count, const KnnWorkspace& ws) {
+  if (B == 0) return RKH_OK;
+  switch (nn_padded_dims(st.D)) {
+#define RKH_CASE(DP) \
+  case DP: launch_nnk_dp<DP>(s, st, n, d_q, B, k, radius, d_idx, d_dist, d_count, ws); break
+    RKH_CASE(2);
+    RKH_CASE(4);
+    RKH_CASE(6);
+    RKH_CASE(8);
+    RKH_CASE(12);
+    RKH_CASE(16);
+    RKH_CASE(24);
+    RKH_CASE(32);
+#undef RKH_CASE
+    default: set_error("k-NN: unsupported dimension"); return RKH_ERR_BAD_ARG;
+  }
+  RKH_HIP(hipGetLastError());
+  return RKH_OK;
+}
+
+}  // namespace rkh

@@ -281,10 +281,4 @@ rkh_status launch_fill_uniform(hipStream_t s, const NnStore& st, uint64_t n, uin
   return RKH_OK;
 }
 
-rkh_status launch_nnk(hipStream_t, const NnStore&, uint64_t, const double*, uint32_t, uint32_t, double, uint32_t*,
-                      double*, uint32_t*) {
-  set_error("k-NN sweep kernel not built yet");
-  return RKH_ERR_UNSUPPORTED;
-}
-
 }  // namespace rkh

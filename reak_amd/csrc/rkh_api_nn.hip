@@ -74,6 +74,7 @@ rkh_status rkh_nn_destroy(rkh_nn* nn) {
   hipFree(nn->d_count);
   hipFree(nn->d_part_dist);
   hipFree(nn->d_part_idx);
+  hipFree(nn->d_knn_ws);
   delete nn;
   return RKH_OK;
 }
@@ -180,7 +181,20 @@ rkh_status rkh_nn_queryk_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32
                                double* d_dist, uint32_t* d_count) {
   if (!nn || !d_q || !d_idx || !d_dist || !d_count || k == 0) return RKH_ERR_BAD_ARG;
   if (B == 0) return RKH_OK;
-  return launch_nnk(nn->ctx->stream, nn->st, nn->n, d_q, B, k, radius, d_idx, d_dist, d_count);
+  KnnWorkspace ws;
+  size_t bytes = 0;
+  rkh_status st = knn_plan(nn->n, B, k, &ws, &bytes);
+  if (st != RKH_OK) return st;
+  if (bytes > nn->knn_ws_bytes) {
+    (void)hipFree(nn->d_knn_ws);
+    nn->d_knn_ws = nullptr;
+    RKH_HIP(hipMalloc(&nn->d_knn_ws, bytes));
+    nn->knn_ws_bytes = bytes;
+  }
+  knn_carve(nn->d_knn_ws, B, &ws);
+  st = launch_nnk(nn->ctx->stream, nn->st, nn->n, d_q, B, k, radius, d_idx, d_dist, d_count, ws);
+  if (st != RKH_OK) return st;
+  return RKH_OK;
 }
 
 rkh_status rkh_nn_queryk(rkh_nn* nn, const double* q, uint32_t B, uint32_t k, double radius, uint32_t* idx,
@@ -196,7 +210,13 @@ rkh_status rkh_nn_queryk(rkh_nn* nn, const double* q, uint32_t B, uint32_t k, do
   RKH_HIP(hipMemcpyAsync(idx, nn->d_idx, uint64_t(B) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RKH_HIP(hipMemcpyAsync(dist, nn->d_dist, uint64_t(B) * k * sizeof(double), hipMemcpyDeviceToHost, s));
   RKH_HIP(hipMemcpyAsync(count, nn->d_count, B * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  uint32_t overflow = 0;  // first word of the k-NN workspace
+  RKH_HIP(hipMemcpyAsync(&overflow, nn->d_knn_ws, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RKH_HIP(hipStreamSynchronize(s));
+  if (overflow) {
+    set_error("rkh_nn_queryk: candidate capacity exceeded (too many vertices within the bound; shrink the radius)");
+    return RKH_ERR_CAPACITY;
+  }
   return RKH_OK;
 }
 

@@ -52,8 +52,21 @@ rkh_status launch_nn1(hipStream_t s, int D, const NnArgs& single, const NnArgs* 
                       uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0 = nullptr,
                       hipEvent_t ev1 = nullptr);
 uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B, uint32_t n_problems = 1);
+// k-NN with radius (knn_sweep.hip).  ws: device workspace from knn_workspace_bytes(); *d_overflow is set (non-zero)
+// if a query met more than the candidate capacity (pathological ties).
+struct KnnWorkspace {
+  double* sub = nullptr;       // [M][Bpad] per-subrange minima (phase A)
+  double* tau = nullptr;       // [B] inclusive bound on the k-th smallest distance
+  uint32_t* cnt = nullptr;     // [B] candidates collected
+  double* cand_d = nullptr;    // [B][cmax]
+  uint32_t* cand_i = nullptr;  // [B][cmax]
+  uint32_t* overflow = nullptr;
+  uint32_t cmax = 0, m_sub = 0, gx = 0;
+};
+rkh_status knn_plan(uint64_t n, uint32_t B, uint32_t k, KnnWorkspace* ws, size_t* bytes);
+void knn_carve(void* base, uint32_t B, KnnWorkspace* ws);
 rkh_status launch_nnk(hipStream_t s, const NnStore& st, uint64_t n, const double* d_q, uint32_t B, uint32_t k,
-                      double radius, uint32_t* d_idx, double* d_dist, uint32_t* d_count);
+                      double radius, uint32_t* d_idx, double* d_dist, uint32_t* d_count, const KnnWorkspace& ws);
 rkh_status launch_fill_uniform(hipStream_t s, const NnStore& st, uint64_t n, uint64_t seed);
 
 // ---- scene (propagate.hip) ---------------------------------------------------------------------
@@ -109,6 +122,8 @@ struct rkh_nn {
   uint32_t* d_part_idx = nullptr;
   uint64_t part_cap = 0;
   uint32_t part_blocks = 0;
+  void* d_knn_ws = nullptr;  // k-NN workspace
+  size_t knn_ws_bytes = 0;
 };
 
 struct rkh_scene {

@@ -74,6 +74,33 @@ def test_nn1_empty_and_growth(L, ctx, oracle):
         nn.added_vertices(pts[:100])  # capacity exceeded -> error, not silent truncation
 
 
+@pytest.mark.parametrize("D,n,B,k,radius", [(12, 5000, 33, 52, np.inf), (12, 40, 7, 52, np.inf), (12, 70000, 64, 68, 2.5),
+                                               (3, 3000, 5, 8, 0.4), (6, 1, 3, 4, np.inf), (12, 300000, 16, 76, np.inf)])
+def test_knn_matches_linear_search(L, ctx, oracle, D, n, B, k, radius):
+    rng = np.random.default_rng(500 + n + k)
+    pts = rng.uniform(-3, 3, size=(n, D))
+    q = rng.uniform(-3, 3, size=(B, D))
+    nn = L.HipNeighborSearch(ctx, D, n)
+    nn.added_vertices(pts)
+    idx, dist, cnt = nn.k_nearest(q, k, radius)
+    ridx, rdist, rcnt = oracle.knn(q, pts, k, radius)
+    assert np.array_equal(cnt, rcnt)
+    assert np.array_equal(dist, rdist)   # bit-exact distances, ascending
+    assert np.array_equal(idx, ridx)     # random data: no exact ties, so the order is fully determined
+
+
+def test_knn_ties_and_star_neighborhood(L, ctx, oracle):
+    base = np.random.default_rng(1).uniform(-1, 1, size=(400, 12))
+    pts = np.concatenate([base, base])  # every vertex twice: ties at every rank
+    q = base[:9] + 1e-3
+    nn = L.HipNeighborSearch(ctx, 12, pts.shape[0])
+    nn.added_vertices(pts)
+    idx, dist, cnt = nn.k_nearest(q, 10)
+    ridx, rdist, rcnt = oracle.knn(q, pts, 10)
+    assert np.array_equal(cnt, rcnt) and np.array_equal(dist, rdist)  # same distance multiset
+    assert np.array_equal(np.sort(idx % 400, axis=1), np.sort(ridx % 400, axis=1))  # same vertices up to the duplicate
+
+
 def test_sqrt_and_divide_are_correctly_rounded(L, ctx, oracle):
     """The NN distance is sqrt(sum of squares): device sqrt must equal IEEE sqrt bit for bit."""
     rng = np.random.default_rng(11)
