@@ -74,22 +74,32 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_kernel(NnArgs single, cons
   double best_thr = INFINITY;   // squares above this cannot tie or beat best_d
   uint32_t best_i = 0xFFFFFFFFu;
 
+  // Software pipeline: the rows of tile t+1 are fetched into registers (16 B/lane, contiguous) while tile t is
+  // being scanned out of LDS, so every CU keeps HBM requests in flight during its compute phase.
+  constexpr int N2 = kTileRows * DP / 2;          // double2 per tile
+  constexpr int PF = N2 / kThreads;               // double2 per thread per tile
+  static_assert(N2 % kThreads == 0, "tile must split evenly");
+  double2 pf[PF];
+  auto fetch = [&](uint64_t t) {
+    const uint64_t row_base = t * kTileRows;
+    const double2* src = reinterpret_cast<const double2*>(pos + row_base * DP);
+    const uint64_t valid2 = (n - row_base >= uint64_t(kTileRows)) ? uint64_t(N2) : (n - row_base) * DP / 2;
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int i = tid + j * kThreads;
+      // rows beyond n become +inf so they never win
+      pf[j] = (uint64_t(i) < valid2) ? src[i] : make_double2(INFINITY, INFINITY);
+    }
+  };
+  if (tile0 < tile1) fetch(tile0);
   for (uint64_t t = tile0; t < tile1; ++t) {
     const uint64_t row_base = t * kTileRows;
-    // contiguous copy HBM -> LDS (rows beyond n become +inf so they never win)
     {
-      const double2* src = reinterpret_cast<const double2*>(pos + row_base * DP);
       double2* dst = reinterpret_cast<double2*>(tile);
-      constexpr int N2 = kTileRows * DP / 2;
-      const uint64_t valid2 = (n - row_base >= uint64_t(kTileRows)) ? uint64_t(N2) : (n - row_base) * DP / 2;
-#pragma unroll 4
-      for (int i = tid; i < N2; i += kThreads) {
-        double2 v;
-        if (uint64_t(i) < valid2) v = src[i];
-        else v = make_double2(INFINITY, INFINITY);
-        dst[i] = v;
-      }
+#pragma unroll
+      for (int j = 0; j < PF; ++j) dst[tid + j * kThreads] = pf[j];
     }
+    if (t + 1 < tile1) fetch(t + 1);
     __syncthreads();
 #pragma unroll 2
     for (int k = 0; k < ROWS_PER_THREAD; ++k) {
@@ -187,6 +197,7 @@ int nn_padded_dims(int D) { return padded_dims(D); }
 
 static uint32_t pick_qb(uint32_t B) {
   if (B <= 8) return 8;
+  if (B <= 16) return 16;
   if (B <= 32) return 32;
   if (B <= 128) return 128;
   return 256;
@@ -223,6 +234,7 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
   if (ev0) (void)hipEventRecord(ev0, s);
   switch (qb) {
     case 8: RKH_NN1_LAUNCH(8); break;
+    case 16: RKH_NN1_LAUNCH(16); break;
     case 32: RKH_NN1_LAUNCH(32); break;
     case 128: RKH_NN1_LAUNCH(128); break;
     default: RKH_NN1_LAUNCH(256); break;
