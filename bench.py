@@ -81,17 +81,23 @@ def nn_sweep_microbench(lib, ctx, events, n_rows, B, reps):
     for _ in range(3):
         nn.nearest_async(q.data_ptr(), B, idx.data_ptr(), dist.data_ptr())
     ctx.synchronize()
-    a, b = events.create(), events.create()
-    events.record(a, ctx.stream)
-    for _ in range(reps):
-        nn.nearest_async(q.data_ptr(), B, idx.data_ptr(), dist.data_ptr())
-    events.record(b, ctx.stream)
-    ms = events.elapsed_ms(a, b) / reps  # sweep + its tiny reduce kernel
+    pairs = [(events.create(), events.create()) for _ in range(reps)]
+    for a, b in pairs:  # each sweep kernel is bracketed by its own event pair on the launch stream
+        nn.nearest_async(q.data_ptr(), B, idx.data_ptr(), dist.data_ptr(), events=(a, b))
+    ctx.synchronize()
+    ms = sum(events.elapsed_ms(a, b) for a, b in pairs) / reps
     bytes_per_sweep = n_rows * D * 8
     gbps = bytes_per_sweep / (ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_nn_sweep_pmc.json")
+    if os.path.exists(pmc):  # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (same kernel, same n)
+        rec = json.load(open(pmc))
+        if rec.get("n_rows") == n_rows and rec.get("queries_per_sweep") == B:
+            traffic = rec["hbm_bytes_per_launch"]
     nn.close()
     return {"bound": "hbm", "n": n_rows, "dims": D, "queries_per_sweep": B, "ms_per_sweep": ms, "achieved": gbps,
-            "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "queries_per_s": B / (ms * 1e-3)}
+            "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "queries_per_s": B / (ms * 1e-3),
+            "algorithmic_bytes": bytes_per_sweep, "traffic": traffic}
 
 
 def cpu_baseline(scn, seconds_target=15.0):

@@ -77,6 +77,9 @@ rkh_status rkh_nn_queryk_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32
 /* Fill the set with n uniform points of the unit hypercube directly on the device (synthetic
  * trees for the sweep microbenchmark); deterministic in seed. */
 rkh_status rkh_nn_fill_uniform(rkh_nn* nn, uint64_t n, uint64_t seed);
+/* One-shot: the next rkh_nn_query1_async records the two hipEvent_t (passed as void*) immediately before and after
+ * its sweep kernel on the context stream (bench.py times the kernel itself, not the launch sequence). */
+rkh_status rkh_nn_set_events(rkh_nn* nn, void* ev_start, void* ev_stop);
 /* Name and grid of the sweep kernel the last query launched (for profile bookkeeping). */
 const char* rkh_nn_kernel_name(void);
 

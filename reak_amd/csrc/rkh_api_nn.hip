@@ -159,7 +159,9 @@ rkh_status rkh_nn_query1_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32
   a.part_idx = nn->d_part_idx;
   a.idx = d_idx;
   a.dist = d_dist;
-  return launch_nn1(nn->ctx->stream, nn->st.D, a, nullptr, 1, nn->n, B, nn->part_blocks);
+  hipEvent_t e0 = nn->ev0, e1 = nn->ev1;
+  nn->ev0 = nn->ev1 = nullptr;
+  return launch_nn1(nn->ctx->stream, nn->st.D, a, nullptr, 1, nn->n, B, nn->part_blocks, e0, e1);
 }
 
 rkh_status rkh_nn_query1(rkh_nn* nn, const double* q, uint32_t B, uint32_t* idx, double* dist) {
@@ -230,6 +232,13 @@ rkh_status rkh_nn_fill_uniform(rkh_nn* nn, uint64_t n, uint64_t seed) {
   if (st != RKH_OK) return st;
   RKH_HIP(hipStreamSynchronize(nn->ctx->stream));
   nn->n = n;
+  return RKH_OK;
+}
+
+rkh_status rkh_nn_set_events(rkh_nn* nn, void* ev_start, void* ev_stop) {
+  if (!nn) return RKH_ERR_BAD_ARG;
+  nn->ev0 = static_cast<hipEvent_t>(ev_start);
+  nn->ev1 = static_cast<hipEvent_t>(ev_stop);
   return RKH_OK;
 }
 

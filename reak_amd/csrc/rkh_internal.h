@@ -122,6 +122,7 @@ struct rkh_nn {
   uint32_t* d_part_idx = nullptr;
   uint64_t part_cap = 0;
   uint32_t part_blocks = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;  // one-shot: bracket the next sweep kernel
   void* d_knn_ws = nullptr;  // k-NN workspace
   size_t knn_ws_bytes = 0;
 };

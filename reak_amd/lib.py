@@ -52,7 +52,7 @@ EXPORTS = [
     "rkh_scene_create", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
-    "rkh_planner_nn_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems",
+    "rkh_planner_nn_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events",
 ]
 
 
@@ -93,6 +93,7 @@ def load():
     lib.rkh_nn_query1_async.argtypes = [vp, vp, u32, vp, vp]
     lib.rkh_nn_queryk_async.argtypes = [vp, vp, u32, u32, d, vp, vp, vp]
     lib.rkh_nn_fill_uniform.argtypes = [vp, u64, u64]
+    lib.rkh_nn_set_events.argtypes = [vp, vp, vp]
     lib.rkh_nn_kernel_name.restype = C.c_char_p
     lib.rkh_scene_create.argtypes = [vp, C.POINTER(T.KteOp), C.c_int, C.POINTER(T.ChainBase), C.POINTER(T.Shape), C.c_int,
                                      C.POINTER(vp)]
@@ -183,7 +184,9 @@ class HipNeighborSearch:
         _check(self.lib.rkh_nn_query1(self.h, T.dptr(q), B, T.u32ptr(idx), T.dptr(dist)))
         return idx, dist
 
-    def nearest_async(self, d_q, B, d_idx, d_dist):
+    def nearest_async(self, d_q, B, d_idx, d_dist, events=None):
+        if events is not None:
+            _check(self.lib.rkh_nn_set_events(self.h, events[0], events[1]))
         _check(self.lib.rkh_nn_query1_async(self.h, d_q, B, d_idx, d_dist))
 
     def k_nearest(self, q, k, radius=np.inf):
