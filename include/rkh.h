@@ -150,6 +150,10 @@ rkh_status rkh_planner_create(rkh_scene* scene, const rkh_dyn_space* space, cons
 rkh_status rkh_planner_create_batch(rkh_scene* scene, const rkh_dyn_space* space, const rkh_rrt_params* prms,
                                     uint32_t n_problems, rkh_planner** out);
 uint32_t rkh_planner_num_problems(const rkh_planner* p);
+/* The same planner over the quasi-static free space manip_quasi_static_env (points = joint positions, steering =
+ * move_position_toward with the min_interval collision walk, goal probe = interp_topo_get_distance_pred). */
+rkh_status rkh_planner_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_rrt_params* prms,
+                                       uint32_t n_problems, rkh_planner** out);
 rkh_status rkh_planner_destroy(rkh_planner* p);
 /* Enqueue `rounds` speculative batches on the planner's stream (no host sync). */
 rkh_status rkh_planner_enqueue(rkh_planner* p, uint32_t rounds);

@@ -82,6 +82,16 @@ typedef struct rkh_dyn_space {
   double upper[RKH_MAX_STATE]; /* hyperbox_topology upper_corner */
 } rkh_dyn_space;
 
+/* manip_quasi_static_env (ctrl/topologies/manip_free_workspace.hpp:113-300) over a hyperbox joint space with linear
+ * interpolation: points are joint positions (D = n_dof), edges are walked in min_interval steps. */
+typedef struct rkh_qs_space {
+  int32_t n_dof;
+  int32_t pad;
+  double min_interval;
+  double lower[RKH_MAX_DOF];
+  double upper[RKH_MAX_DOF];
+} rkh_qs_space;
+
 /* sample_based_planner options (ctrl/path_planning/motion_planner_base.hpp:400-422) and the
  * point-to-point query (ctrl/path_planning/p2p_planning_query.hpp:74-229). */
 typedef struct rkh_rrt_params {

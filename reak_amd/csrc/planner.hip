@@ -237,8 +237,10 @@ struct Problem {  // host view of one planning problem
 struct rkh_planner {
   rkh_scene* scene = nullptr;
   hipStream_t stream = nullptr;
-  rkh_dyn_space space;
+  bool quasi_static = false;  // false: steerable dynamic space (propagate kernel); true: manip_quasi_static_env (edge_check)
+  double lower[RKH_MAX_STATE], upper[RKH_MAX_STATE];  // hyperbox the samples are drawn from
   DynDev dyn;
+  QsDev qs;
   int n_dof = 0, D = 0, DP = 0;
   uint32_t P = 0;
   std::vector<Problem> prob;
@@ -276,7 +278,7 @@ rkh_status upload_samples(rkh_planner* p, Problem& q, uint32_t index, uint64_t u
       do {
         u = double(q.eng()) * (1.0 / 4294967296.0);
       } while (!(u < 1.0));
-      p->h_chunk[i * D + d] = p->space.lower[d] + u * (p->space.upper[d] - p->space.lower[d]);
+      p->h_chunk[i * D + d] = p->lower[d] + u * (p->upper[d] - p->lower[d]);
     }
   RKH_HIP(hipMemcpyAsync(q.d_samples + q.samples_ready * D, p->h_chunk.data(), cnt * D * sizeof(double),
                          hipMemcpyHostToDevice, p->stream));
@@ -292,11 +294,19 @@ void launch_fixup(rkh_planner* p) {
   hipLaunchKernelGGL((fixup_kernel<DP>), dim3((p->b_max + 3) / 4, p->P), dim3(256), 0, p->stream, p->d_probs, p->D);
 }
 
+// steer / probe edges of all problems: RK4 propagation (dynamic space) or the min_interval walk (quasi-static space)
+rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const EdgeIO* tab_a, const EdgeIO* tab_b) {
+  if (p->quasi_static)
+    return launch_edge_check(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
+                             p->scene->n_pairs, p->qs, EdgeIO(), grid_a, nullptr, grid_b, tab_a, tab_b, p->P);
+  return launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
+                          p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lanes_per_edge, tab_a, tab_b,
+                          p->P);
+}
+
 // goal probes still pending after the last enqueued round
 rkh_status flush_probes(rkh_planner* p) {
-  rkh_status st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                                   p->scene->n_pairs, p->dyn, EdgeIO(), p->b_max, nullptr, 0, p->lanes_per_edge,
-                                   p->d_io_probe, nullptr, p->P);
+  rkh_status st = launch_edges(p, p->b_max, 0, p->d_io_probe, nullptr);
   if (st != RKH_OK) return st;
   hipLaunchKernelGGL(probes_flushed_kernel, dim3(p->P), dim3(64), 0, p->stream, p->d_probs);
   RKH_HIP(hipGetLastError());
@@ -324,9 +334,7 @@ rkh_status enqueue_round(rkh_planner* p) {
   rkh_status st = launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, p->b_max, p->part_blocks, ev0, ev1);
   if (st != RKH_OK) return st;
   // 2. speculative steer of all candidates + the goal probes of the vertices the previous round committed
-  st = launch_propagate(s, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs, p->scene->n_pairs,
-                        p->dyn, EdgeIO(), p->b_max, nullptr, p->b_max, p->lanes_per_edge, p->d_io_steer, p->d_io_probe,
-                        p->P);
+  st = launch_edges(p, p->b_max, p->b_max, p->d_io_steer, p->d_io_probe);
   if (st != RKH_OK) return st;
   // 3. fix-up against the vertices this round itself would add
   switch (p->DP) {
@@ -363,11 +371,12 @@ rkh_status read_states(rkh_planner* p) {
 
 extern "C" {
 
-rkh_status rkh_planner_create_batch(rkh_scene* scene, const rkh_dyn_space* space, const rkh_rrt_params* prms,
-                                    uint32_t n_problems, rkh_planner** out) {
-  if (!scene || !space || !prms || !out || n_problems < 1) return RKH_ERR_BAD_ARG;
-  if (space->n_dof != scene->host.n_dof) {
-    set_error("rkh_planner_create: rkh_dyn_space.n_dof does not match the scene");
+static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* space, const rkh_qs_space* qspace,
+                                        const rkh_rrt_params* prms, uint32_t n_problems, rkh_planner** out) {
+  if (!scene || (!space && !qspace) || !prms || !out || n_problems < 1) return RKH_ERR_BAD_ARG;
+  const int space_dof = space ? space->n_dof : qspace->n_dof;
+  if (space_dof != scene->host.n_dof) {
+    set_error("rkh_planner_create: the space's n_dof does not match the scene");
     return RKH_ERR_BAD_ARG;
   }
   for (uint32_t i = 0; i < n_problems; ++i)
@@ -377,13 +386,34 @@ rkh_status rkh_planner_create_batch(rkh_scene* scene, const rkh_dyn_space* space
     }
   rkh_planner* p = new rkh_planner();
   p->scene = scene;
-  p->space = *space;
-  p->n_dof = space->n_dof;
-  p->D = 2 * space->n_dof;
-  p->DP = nn_padded_dims(p->D);
+  p->n_dof = space_dof;
   p->P = n_problems;
-  rkh_status st = build_dyn_dev(*space, 1.0, &p->dyn);
-  if (st != RKH_OK) { delete p; return st; }
+  rkh_status st = RKH_OK;
+  if (space) {
+    p->D = 2 * space->n_dof;
+    for (int d = 0; d < p->D; ++d) {
+      p->lower[d] = space->lower[d];
+      p->upper[d] = space->upper[d];
+    }
+    st = build_dyn_dev(*space, 1.0, &p->dyn);
+    if (st != RKH_OK) { delete p; return st; }
+  } else {
+    if (!(qspace->min_interval > 0.0) || qspace->n_dof > kMaxDof) {
+      delete p;
+      set_error("rkh_qs_space: min_interval must be positive");
+      return RKH_ERR_BAD_ARG;
+    }
+    p->quasi_static = true;
+    p->D = qspace->n_dof;
+    std::memset(&p->qs, 0, sizeof(p->qs));
+    p->qs.min_interval = qspace->min_interval;
+    p->qs.fraction = 1.0;
+    for (int d = 0; d < p->D; ++d) {
+      p->lower[d] = p->qs.lower[d] = qspace->lower[d];
+      p->upper[d] = p->qs.upper[d] = qspace->upper[d];
+    }
+  }
+  p->DP = nn_padded_dims(p->D);
   RKH_HIP(hipSetDevice(scene->ctx->device));
   RKH_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   if (const char* e = getenv("RKH_BATCH_MAX")) p->b_max = std::max(8, atoi(e));
@@ -522,6 +552,18 @@ rkh_status rkh_planner_create_batch(rkh_scene* scene, const rkh_dyn_space* space
   RKH_HIP(hipMemcpy(p->d_io_probe, hgp.data(), P * sizeof(EdgeIO), hipMemcpyHostToDevice));
   *out = p;
   return RKH_OK;
+}
+
+rkh_status rkh_planner_create_batch(rkh_scene* scene, const rkh_dyn_space* space, const rkh_rrt_params* prms,
+                                    uint32_t n_problems, rkh_planner** out) {
+  if (!space) return RKH_ERR_BAD_ARG;
+  return planner_create_common(scene, space, nullptr, prms, n_problems, out);
+}
+
+rkh_status rkh_planner_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_rrt_params* prms,
+                                       uint32_t n_problems, rkh_planner** out) {
+  if (!space) return RKH_ERR_BAD_ARG;
+  return planner_create_common(scene, nullptr, space, prms, n_problems, out);
 }
 
 rkh_status rkh_planner_create(rkh_scene* scene, const rkh_dyn_space* space, const rkh_rrt_params* prm,

@@ -26,6 +26,7 @@
 // sin/cos (OCML vs glibc) differ by ulps (stated tolerance: 1e-10 relative on propagated states).
 #include <hip/hip_runtime.h>
 
+#include <cfloat>
 #include <cmath>
 
 #include "device_math.h"
@@ -650,6 +651,134 @@ __global__ __launch_bounds__(64) void state_derivative_kernel(const SceneDev* __
   if (f && lane < N) f[uint64_t(e) * N + lane] = ws.tmp[lane];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Kernel: quasi-static edge walk interp_topo_move_position_toward_pred
+// (ctrl/interpolation/interpolated_topologies.hpp:137-163) over joint positions (D = N), with
+// manip_quasi_static_env::is_free (manip_free_workspace.hpp:154-156) as the predicate.
+// One wave per edge; its four 16-lane groups test four consecutive interpolation points at a time
+// (the points of a straight edge are independent), and a ballot finds the first colliding one.
+// dist_cur is accumulated by repeated addition exactly like the reference loop (":157 dist_cur += min_interval"),
+// so the number of tested points is the same integer.
+template <int N>
+__global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __restrict__ sc,
+                                                            const PairDev* __restrict__ pairs, int n_pairs, QsDev qs,
+                                                            EdgeIO io_a, EdgeIO io_b, const EdgeIO* __restrict__ tab_a,
+                                                            const EdgeIO* __restrict__ tab_b, uint32_t grid_a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int GL = 16, G = 4;
+  BlockLds<N, GL>& lds = *reinterpret_cast<BlockLds<N, GL>*>(smem_raw);
+  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayout<N, GL>::block_bytes);
+  const bool group_b = blockIdx.x >= grid_a;
+  const EdgeIO io = tab_a ? (group_b ? tab_b[blockIdx.y] : tab_a[blockIdx.y]) : (group_b ? io_b : io_a);
+  const uint32_t B = io.d_B ? *io.d_B : io.B;
+  const uint32_t e = group_b ? blockIdx.x - grid_a : blockIdx.x;
+  if (e >= B) return;
+  const int lane = threadIdx.x;
+  const int g = lane / GL, gl = lane % GL, gb = g * GL;
+  stage_chain<N>(sc, lds.joints, lds.base, lane);
+  stage_env(sc, env_lds, lane);
+  GroupWs<N>& ws = lds.g[g];
+  const uint32_t si = io.src_idx ? io.src_idx[e] : ((io.d_src_first ? *io.d_src_first : 0u) + e);
+  const uint64_t trow = (io.d_tgt_off ? uint64_t(*io.d_tgt_off) : 0ull) + e;
+  const double a_d = (gl < N) ? io.src[uint64_t(si) * io.src_stride + gl] : 0.0;
+  const double b_d = (gl < N) ? io.tgt[trow * io.tgt_stride + gl] : 0.0;
+  const double lo = (gl < N) ? qs.lower[gl] : 0.0;
+  const double hi = (gl < N) ? qs.upper[gl] : 0.0;
+  if (gl < 2 * N) ws.x[gl] = 0.0;  // velocities stay zero (apply_to_model writes positions only)
+  __syncthreads();
+  const CPack<N> cp = load_cpack<N>(lds.joints, lane);
+
+  // exact left-to-right euclidean norm of an N-vector held by lanes gl < N of every group
+  auto norm_n = [&](double diff) {
+    if (gl < N) ws.tmp[gl] = diff * diff;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int d = 0; d < N; ++d) s = s + ws.tmp[d];
+    __syncthreads();
+    return sqrt(s);
+  };
+  const double dist_tot = norm_n(a_d - b_d);
+  const double fraction = qs.fraction;
+  double result = a_d;       // component gl of the returned point
+  uint32_t n_checked = 0;
+  if (dist_tot == INFINITY) {
+    result = a_d;
+  } else if (dist_tot < qs.min_interval) {
+    result = a_d + (b_d - a_d) * fraction;  // vector_topology::move_position_toward, no predicate call
+  } else {
+    const double dist_inter = dist_tot * fraction;
+    double cur = 0.0;          // dist_cur of the last tested point (0 + min_interval == min_interval exactly)
+    double last_result = a_d;  // last point that passed the predicate
+    bool collided = false;
+    for (;;) {
+      double my = cur;
+#pragma unroll
+      for (int t = 0; t < G; ++t)
+        if (t <= g) my = my + qs.min_interval;
+      const bool valid = my < dist_inter;
+      if (!__any(valid)) break;
+      const double pt = a_d + (b_d - a_d) * (my / dist_tot);
+      if (gl < N) ws.x[2 * gl] = pt;
+      bool oob = false;
+      if (gl < N) {
+        if (lo < hi) oob = (pt < lo) || (pt > hi);
+        else oob = (pt > lo) || (pt < hi);
+      }
+      const unsigned long long mo = __ballot(oob);
+      const bool group_oob = ((mo >> gb) & 0xFFFFull) != 0ull;
+      __syncthreads();
+      const double dmin = proximity_min<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true,
+                                               !valid || group_oob);
+      const bool is_free = valid && !group_oob && !(dmin < 0.0);
+      // group masks (bit g): valid / free
+      const unsigned long long mv = __ballot(valid && gl == 0), mf = __ballot(is_free && gl == 0);
+      int first_bad = G;  // first valid group whose point fails the predicate
+      int n_valid = 0;
+#pragma unroll
+      for (int t = G - 1; t >= 0; --t) {
+        const bool v = (mv >> (t * GL)) & 1ull, f = (mf >> (t * GL)) & 1ull;
+        if (v && !f) first_bad = t;
+        if (v) n_valid = n_valid > t + 1 ? n_valid : t + 1;
+      }
+      if (first_bad < G) {
+        n_checked += uint32_t(first_bad + 1);
+        if (first_bad > 0) last_result = __shfl(pt, (first_bad - 1) * GL + gl, 64);
+        collided = true;
+        break;
+      }
+      n_checked += uint32_t(n_valid);
+      last_result = __shfl(pt, (n_valid - 1) * GL + gl, 64);
+      if (n_valid < G) break;  // reached dist_inter without a collision
+      cur = __shfl(my, (G - 1) * GL + gl, 64);
+    }
+    if (collided) result = last_result;
+    else if (fraction == 1.0) result = b_d;  // exact end fractions (:159-162)
+    else if (fraction == 0.0) result = a_d;
+    else result = a_d + (b_d - a_d) * fraction;
+  }
+  if (g == 0 && gl < N) io.x_out[uint64_t(e) * N + gl] = result;
+  if (lane == 0) io.steps_free[e] = n_checked;
+  if (io.mode != EDGE_PLAIN) {
+    const double n_ar = norm_n(a_d - result);
+    const double n_ab = dist_tot;
+    const double n_rb = norm_n(result - b_d);
+    if (io.mode == EDGE_STEER_ACCEPT) {
+      // planning_visitor_base::steer_towards_position (planning_visitors.hpp:349-360)
+      const double best_case = io.best_case ? io.best_case[e] : n_ab;
+      const bool ok = (!isinf(n_ar)) && (n_ar < 2.0 * best_case) && (n_ar > io.steer_tol * best_case);
+      if (lane == 0) io.accept[e] = ok ? 1 : 0;
+    } else if (io.mode == EDGE_GOAL_PROBE) {
+      // interp_topo_get_distance_pred (interpolated_topologies.hpp:193-199)
+      if (lane == 0) io.goal_dist[si - 1] = (n_rb < DBL_EPSILON) ? n_ab : INFINITY;
+    } else if (io.mode == EDGE_CONNECT) {
+      // planning_visitor_base::can_be_connected (planning_visitors.hpp:385-395)
+      const bool ok = (!isinf(n_ar)) && (n_rb < io.steer_tol * n_ar);  // steer_tol carries the connection tolerance
+      if (lane == 0) io.accept[e] = ok ? 1 : 0;
+    }
+  }
+}
+
 // Diagnostic kernel (not on the product path): `iters` back-to-back f-evals + proximity tests of one edge per
 // wave, with s_memtime deltas per phase: [sincos, forward sweep, jacobian columns, force sweep, mass matrix,
 // cholesky, proximity, total].
@@ -762,6 +891,20 @@ rkh_status launch_state_derivative(hipStream_t s, int n_dof, const SceneDev* d_s
   if (B == 0) return RKH_OK;
   RKH_DISPATCH_N(n_dof, hipLaunchKernelGGL((state_derivative_kernel<N>), dim3(B), dim3(64), 0, s, d_scene, d_x, d_u, B,
                                            d_pd, d_M, d_f, d_err));
+  RKH_HIP(hipGetLastError());
+  return RKH_OK;
+}
+
+rkh_status launch_edge_check(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
+                             int n_pairs, const QsDev& qs, const EdgeIO& io, uint32_t grid_edges, const EdgeIO* io_b,
+                             uint32_t grid_b, const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems) {
+  const uint32_t eb = (io_b || tab_b) ? grid_b : 0u;
+  if (grid_edges + eb == 0 || n_problems == 0) return RKH_OK;
+  const EdgeIO second = io_b ? *io_b : EdgeIO();
+  const PairDev* pp = static_cast<const PairDev*>(d_pairs);
+  RKH_DISPATCH_N(n_dof, hipLaunchKernelGGL((edge_check_kernel<N>), dim3(grid_edges + eb, n_problems), dim3(64),
+                                           (SmemLayout<N, 16>::bytes(n_env)), s, d_scene, pp, n_pairs, qs, io, second, tab_a,
+                                           tab_b, grid_edges));
   RKH_HIP(hipGetLastError());
   return RKH_OK;
 }

@@ -153,7 +153,12 @@ struct DynDev {  // rkh_dyn_space on the device (passed by value)
   int8_t inner[kMaxSteps];  // runge_kutta4_integrate_impl loop iterations of step k (normally 1)
 };
 
-enum EdgeMode : int { EDGE_PLAIN = 0, EDGE_STEER_ACCEPT = 1, EDGE_GOAL_PROBE = 2 };
+enum EdgeMode : int { EDGE_PLAIN = 0, EDGE_STEER_ACCEPT = 1, EDGE_GOAL_PROBE = 2, EDGE_CONNECT = 3 };
+
+struct QsDev {  // manip_quasi_static_env on the device (passed by value)
+  double min_interval, fraction;
+  double lower[kMaxDof], upper[kMaxDof];
+};
 
 struct EdgeIO {  // inputs / outputs of one propagate launch (all device pointers)
   const double* src = nullptr;         // source rows
@@ -185,6 +190,10 @@ rkh_status launch_state_derivative(hipStream_t s, int n_dof, const SceneDev* d_s
                                    const double* d_u, uint32_t B, double* d_pd, double* d_M, double* d_f, int* d_err);
 rkh_status launch_min_distance(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                                int n_pairs, const double* d_x, uint32_t B, double* d_dist);
+rkh_status launch_edge_check(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
+                             int n_pairs, const QsDev& qs, const EdgeIO& io, uint32_t grid_edges,
+                             const EdgeIO* io_b = nullptr, uint32_t grid_b = 0, const EdgeIO* tab_a = nullptr,
+                             const EdgeIO* tab_b = nullptr, uint32_t n_problems = 1);
 rkh_status launch_feval_cycles(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                                int n_pairs, const double* d_x, const double* d_u, uint32_t B, int iters,
                                unsigned long long* d_out, double* d_sink);

@@ -346,10 +346,43 @@ rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double
   return RKH_OK;
 }
 
-rkh_status rkh_edge_check(rkh_scene*, const double*, const double*, double, const double*, const double*, uint32_t,
-                          double, double*, uint32_t*) {
-  set_error("rkh_edge_check: quasi-static edge kernel not built yet");
-  return RKH_ERR_UNSUPPORTED;
+rkh_status rkh_edge_check(rkh_scene* scene, const double* lower, const double* upper, double min_interval,
+                          const double* a, const double* b, uint32_t B, double fraction, double* out,
+                          uint32_t* n_checked) {
+  if (!scene || !lower || !upper || !a || !b || !out || !n_checked || !(min_interval > 0.0)) return RKH_ERR_BAD_ARG;
+  if (B == 0) return RKH_OK;
+  const int n = scene->host.n_dof;
+  QsDev qs;
+  std::memset(&qs, 0, sizeof(qs));
+  qs.min_interval = min_interval;
+  qs.fraction = fraction;
+  for (int i = 0; i < n; ++i) {
+    qs.lower[i] = lower[i];
+    qs.upper[i] = upper[i];
+  }
+  hipStream_t s = scene->ctx->stream;
+  DevBuf da, db, dxo, dnc;
+  RKH_HIP(hipMalloc(&da.p, size_t(B) * n * 8));
+  RKH_HIP(hipMalloc(&db.p, size_t(B) * n * 8));
+  RKH_HIP(hipMalloc(&dxo.p, size_t(B) * n * 8));
+  RKH_HIP(hipMalloc(&dnc.p, size_t(B) * 4));
+  RKH_HIP(hipMemcpyAsync(da.p, a, size_t(B) * n * 8, hipMemcpyHostToDevice, s));
+  RKH_HIP(hipMemcpyAsync(db.p, b, size_t(B) * n * 8, hipMemcpyHostToDevice, s));
+  EdgeIO io;
+  io.src = da.as<double>();
+  io.src_stride = n;
+  io.tgt = db.as<double>();
+  io.tgt_stride = n;
+  io.B = B;
+  io.x_out = dxo.as<double>();
+  io.steps_free = dnc.as<uint32_t>();
+  io.err_flag = scene->d_err;
+  rkh_status st = launch_edge_check(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, qs, io, B);
+  if (st != RKH_OK) return st;
+  RKH_HIP(hipMemcpyAsync(out, dxo.p, size_t(B) * n * 8, hipMemcpyDeviceToHost, s));
+  RKH_HIP(hipMemcpyAsync(n_checked, dnc.p, size_t(B) * 4, hipMemcpyDeviceToHost, s));
+  RKH_HIP(hipStreamSynchronize(s));
+  return RKH_OK;
 }
 
 }  // extern "C"

@@ -52,7 +52,7 @@ EXPORTS = [
     "rkh_scene_create", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
-    "rkh_planner_nn_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events",
+    "rkh_planner_nn_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch",
 ]
 
 
@@ -107,6 +107,7 @@ def load():
     lib.rkh_edge_check.argtypes = [vp, dp, dp, d, dp, dp, u32, d, dp, u32p]
     lib.rkh_planner_create.argtypes = [vp, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), C.POINTER(vp)]
     lib.rkh_planner_create_batch.argtypes = [vp, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), u32, C.POINTER(vp)]
+    lib.rkh_planner_create_qs_batch.argtypes = [vp, C.POINTER(T.QsSpace), C.POINTER(T.RrtParams), u32, C.POINTER(vp)]
     lib.rkh_planner_num_problems.restype = u32
     lib.rkh_planner_num_problems.argtypes = [vp]
     lib.rkh_planner_destroy.argtypes = [vp]
@@ -246,6 +247,18 @@ class Scene:
         _check(self.lib.rkh_min_distance(self.h, T.dptr(x), x.shape[0], T.dptr(d)))
         return d
 
+    def move_position_toward(self, lower, upper, min_interval, a, b, fraction=1.0):
+        """manip_quasi_static_env::move_position_toward for B (a,b) joint-position pairs (rkh_edge_check)."""
+        lower = np.ascontiguousarray(lower, dtype=np.float64)
+        upper = np.ascontiguousarray(upper, dtype=np.float64)
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, self.n)
+        b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1, self.n)
+        out = np.zeros_like(a)
+        nchk = np.zeros(a.shape[0], dtype=np.uint32)
+        _check(self.lib.rkh_edge_check(self.h, T.dptr(lower), T.dptr(upper), float(min_interval), T.dptr(a), T.dptr(b),
+                                       a.shape[0], float(fraction), T.dptr(out), T.u32ptr(nchk)))
+        return out, nchk
+
     def steer_position_toward(self, a, b, fraction=1.0, record=False, dyn=None):
         a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, self.D)
         b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1, self.D)
@@ -270,18 +283,34 @@ class Scene:
             pass
 
 
+def make_qs_space(n_dof, lower, upper, min_interval):
+    q = T.QsSpace()
+    q.n_dof = n_dof
+    q.min_interval = float(min_interval)
+    for i in range(n_dof):
+        q.lower[i] = float(lower[i])
+        q.upper[i] = float(upper[i])
+    return q
+
+
 class RrtPlanner:
     """rrt_planner over the steerable dynamic space.  `prm` is one rkh_rrt_params or a list of them (a batch of
     independent problems sharing every kernel launch); `stats` is the first problem's, `all_stats` the array."""
 
-    def __init__(self, scene, prm, dyn=None):
+    def __init__(self, scene, prm, dyn=None, qs=None):
         self.scene, self.lib = scene, scene.lib
         self.dyn = dyn if dyn is not None else scene.scn.dyn
         self.prms = list(prm) if isinstance(prm, (list, tuple)) else [prm]
         self.P = len(self.prms)
         self._prm_arr = T.as_array(self.prms, T.RrtParams)
         self.h = C.c_void_p()
-        _check(self.lib.rkh_planner_create_batch(scene.h, C.byref(self.dyn), self._prm_arr, self.P, C.byref(self.h)))
+        self.qs = qs
+        if qs is not None:  # quasi-static free space (points = joint positions)
+            self.D = qs.n_dof
+            _check(self.lib.rkh_planner_create_qs_batch(scene.h, C.byref(qs), self._prm_arr, self.P, C.byref(self.h)))
+        else:
+            self.D = scene.D
+            _check(self.lib.rkh_planner_create_batch(scene.h, C.byref(self.dyn), self._prm_arr, self.P, C.byref(self.h)))
         self.all_stats = (PlannerStats * self.P)()
 
     @property
@@ -314,7 +343,7 @@ class RrtPlanner:
 
     def tree(self, problem=0):
         st = self.all_stats[problem]
-        nv, it, D = int(st.num_vertices), int(st.iterations), self.scene.D
+        nv, it, D = int(st.num_vertices), int(st.iterations), self.D
         pos = np.zeros((nv, D))
         parent = np.zeros(nv, dtype=np.uint32)
         nn_seq = np.zeros(max(it, 1), dtype=np.uint32)

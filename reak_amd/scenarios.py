@@ -42,7 +42,7 @@ class Scenario:
         p.max_results = max_results
         p.steer_tol = steer_tol
         p.conn_tol = conn_tol
-        for i in range(self.D):
+        for i in range(len(self.start)):
             p.start[i] = float(self.start[i])
             p.goal[i] = float(self.goal[i])
         return p
@@ -174,3 +174,48 @@ def make_pendulum(length=0.5, mass=1.0):
     dyn.lower[0], dyn.upper[0], dyn.lower[1], dyn.upper[1] = -1e9, 1e9, -1e9, 1e9
     return Scenario(name="pendulum", ops=ops, base=base, shapes=[], dyn=dyn, n_dof=1, n_frames=3,
                     start=np.zeros(2), goal=np.zeros(2))
+
+
+def make_c1(world_seed=1, n_obstacles=10, min_interval=0.05):
+    """BASELINE config C1: 3-DOF planar arm, quasi-static RRT, 10 box obstacles, 5k nodes.
+    The planar 3R arm of ctrl/kte_models/manip_3R_arm.cpp:45-152 (link lengths 0.5, 0.5, 0.3) is realised with the 3D
+    KTEs (three revolute joints about z, links along x) so that it runs on the same kernels; links are capped cylinders
+    of radius 0.04, obstacles are boxes extruded along z.  (The reference's 2D shapes / prox_crect_rectangle are not
+    restated yet -- DESIGN.md section 7.)"""
+    rng = np.random.Generator(np.random.PCG64(1000 + world_seed))
+    lengths = [0.5, 0.5, 0.3]
+    axes = [(0, 0, 1)] * 3
+    offsets = [(L, 0.0, 0.0) for L in lengths]
+    ops = serial_chain_ops(axes, offsets, [2.0, 1.5, 1.0], [(0.01, 0, 0, 0.05, 0, 0.05)] * 3, [0.1] * 3)
+    base = T.ChainBase()
+    base.pose = T.make_pose()
+    n = 3
+    shapes = []
+    qy90 = (np.cos(np.pi / 4), 0.0, np.sin(np.pi / 4), 0.0)  # capsule axis z -> link direction x
+    for j in range(n):
+        s = T.Shape(kind=T.SHAPE_CCYLINDER, anchor=2 * j + 1)
+        s.pose = T.make_pose((0.5 * lengths[j], 0.0, 0.0), qy90)
+        s.dims[:] = [lengths[j], 0.04, 0.0]
+        shapes.append(s)
+    placed = 0
+    while placed < n_obstacles:
+        c = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.5, 1.5), 0.0])
+        d = np.array([rng.uniform(0.2, 0.5), rng.uniform(0.2, 0.5), 1.0])
+        yaw = rng.uniform(-np.pi, np.pi)
+        # keep the start pose (arm stretched along +x) and the goal pose (stretched along +y) clear
+        brad = 0.5 * np.hypot(d[0], d[1])
+        if _dist_point_segment(c, np.zeros(3), np.array([1.3, 0, 0])) < brad + 0.1:
+            continue
+        if _dist_point_segment(c, np.zeros(3), np.array([0, 1.3, 0])) < brad + 0.1:
+            continue
+        s = T.Shape(kind=T.SHAPE_BOX, anchor=-1)
+        s.pose = T.make_pose(c, (np.cos(yaw / 2), 0.0, 0.0, np.sin(yaw / 2)))
+        s.dims[:] = [float(v) for v in d]
+        shapes.append(s)
+        placed += 1
+    dyn = T.DynSpace()
+    dyn.n_dof = n
+    scn = Scenario(name="C1", ops=ops, base=base, shapes=shapes, dyn=dyn, n_dof=n, n_frames=2 * n + 1,
+                   start=np.zeros(n), goal=np.array([np.pi / 2, 0.0, 0.0]),
+                   meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi), "min_interval": min_interval})
+    return scn

@@ -60,6 +60,11 @@ class DynSpace(C.Structure):
     ]
 
 
+class QsSpace(C.Structure):
+    _fields_ = [("n_dof", C.c_int32), ("pad", C.c_int32), ("min_interval", C.c_double),
+                ("lower", C.c_double * RKH_MAX_DOF), ("upper", C.c_double * RKH_MAX_DOF)]
+
+
 class RrtParams(C.Structure):
     _fields_ = [
         ("seed", C.c_uint32),

@@ -198,6 +198,27 @@ def test_propagate_fraction_and_goal_tolerance(L, ctx, oracle, c2):
     assert np.all(steps == 0) and np.array_equal(out, a)
 
 
+# ------------------------------------------------------------------ quasi-static edge walk (a9)
+def test_edge_check_matches_interp_topo_walk(L, ctx, oracle):
+    c1 = scenarios.make_c1(world_seed=1)
+    sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    rng = np.random.default_rng(12)
+    a = rng.uniform(lo, hi, size=(600, 3))
+    x = np.zeros((600, 6)); x[:, 0::2] = a
+    a = a[osc.min_distance(x) > 0.0][:256]
+    b = rng.uniform(lo, hi, size=(a.shape[0], 3))
+    b[:8] = a[:8] + 0.01          # shorter than min_interval: no predicate call at all
+    for fr in (0.0, 0.5, 1.0):
+        out, nchk = sc.move_position_toward(lo, hi, mi, a, b, fraction=fr)
+        rout, rnchk = osc.qs_move(lo, hi, mi, a, b, fraction=fr)
+        assert np.array_equal(nchk, rnchk)       # same number of is_free calls (integer loop count)
+        assert np.array_equal(out, rout)         # interpolation is pure IEEE arithmetic: bit-exact
+    assert (nchk == 0).sum() >= 8 and nchk.max() > 50
+    full = np.all(rout == b, axis=1)
+    assert 0.1 < full.mean() < 0.95              # both blocked and complete edges occur
+
+
 # ------------------------------------------------------------------ planner
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_rrt_tree_identical_to_sequential_planner(L, ctx, oracle, c2, seed):
@@ -235,3 +256,38 @@ def test_rrt_stops_on_max_results(L, ctx, oracle, c2):
     assert np.array_equal(tree["parent"], rtree["parent"])
     if rout.num_solutions:
         assert st.best_cost == pytest.approx(rout.best_cost, rel=1e-10)
+
+
+def test_c1_quasi_static_rrt_identical_to_sequential_planner(L, ctx, oracle):
+    """BASELINE config C1: 3-DOF planar arm, quasi-static RRT, 10 box obstacles, 5k nodes, single seed."""
+    c1 = scenarios.make_c1(world_seed=1)
+    sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    prm = c1.rrt_params(seed=1, max_vertices=5000)
+    rc, rout, rtree = osc.rrt_qs(lo, hi, mi, prm)
+    pl = L.RrtPlanner(sc, prm, qs=L.make_qs_space(3, lo, hi, mi))
+    st = pl.solve_planning_query()
+    tree = pl.tree()
+    assert (st.num_vertices, st.iterations, st.edges_checked) == (rout.num_vertices, rout.iterations, rout.edges_checked)
+    assert st.num_vertices == 5001
+    assert np.array_equal(tree["nn_seq"], rtree["nn_seq"])
+    assert np.array_equal(tree["accept"], rtree["accept"])
+    assert np.array_equal(tree["parent"], rtree["parent"])
+    assert np.array_equal(tree["pos"], rtree["pos"])              # straight-line edges: pure IEEE arithmetic, bit-exact
+    assert np.array_equal(tree["goal_dist"], rtree["goal_dist"])  # goal probes, incl. which vertices see the goal
+    assert st.num_solutions == rout.num_solutions and rout.num_solutions > 0
+    assert st.best_cost == rout.best_cost
+
+
+def test_c1_stops_at_first_solution(L, ctx, oracle):
+    c1 = scenarios.make_c1(world_seed=1)
+    sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    prm = c1.rrt_params(seed=3, max_vertices=5000, max_results=1)
+    rc, rout, rtree = osc.rrt_qs(lo, hi, mi, prm)
+    pl = L.RrtPlanner(sc, prm, qs=L.make_qs_space(3, lo, hi, mi))
+    st = pl.solve_planning_query()
+    assert rout.num_solutions == 1 and rout.num_vertices < 5001
+    assert (st.num_vertices, st.iterations, st.num_solutions) == (rout.num_vertices, rout.iterations, 1)
+    assert st.best_cost == rout.best_cost
+    assert np.array_equal(pl.tree()["parent"], rtree["parent"])
