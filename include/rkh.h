@@ -37,6 +37,7 @@ typedef struct rkh_ctx rkh_ctx;         /* one device + stream */
 typedef struct rkh_nn rkh_nn;           /* device-resident vertex set for NN queries */
 typedef struct rkh_scene rkh_scene;     /* KTE chain + proxy environment on the device */
 typedef struct rkh_planner rkh_planner; /* batched RRT driver over a scene */
+typedef struct rkh_rrtstar rkh_rrtstar; /* batched RRT* driver over a scene */
 
 const char* rkh_last_error(void);
 const char* rkh_version(void);
@@ -166,6 +167,26 @@ rkh_status rkh_planner_solve(rkh_planner* p, rkh_planner_stats* stats);
 rkh_status rkh_planner_get_tree(rkh_planner* p, uint32_t problem, double* pos, uint32_t* parent, uint32_t* nn_seq,
                                 uint8_t* accept, double* goal_dist);
 void* rkh_planner_stream(rkh_planner* p);
+
+/* ---- RRT*: rrtstar_planner::solve_planning_query (LINEAR_SEARCH_KNN, UNIDIRECTIONAL, undirected motion graph) ----
+ * (ctrl/path_planning/rrtstar_path_planner.tpp:298- -> generate_rrt_star, ctrl/graph_alg/rrt_star.hpp:169-190,530-570;
+ * rrg_node_generator node_generators.hpp:137-172; star_neighborhood neighborhood_functors.hpp:95-102;
+ * lazy_node_connector lazy_connector.hpp:79-123,230-275,332-372) over the quasi-static free space.
+ * Iterations are sequential (rewiring); the two k-NN sweeps and all candidate edges of an iteration run batched on
+ * the device, for all problems of the batch at once.  Vertex 0 = start, vertex 1 = goal. */
+typedef struct rkh_rrtstar_stats {
+  uint64_t num_vertices, samples, loop_iterations, num_solutions, rewires, edges_checked;
+  double best_cost;
+} rkh_rrtstar_stats;
+rkh_status rkh_rrtstar_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_rrt_params* prms,
+                                       uint32_t n_problems, rkh_rrtstar** out);
+rkh_status rkh_rrtstar_destroy(rkh_rrtstar* p);
+/* stats: array of n_problems entries.  max_loop_iterations < 0: run until keep_going() is false. */
+rkh_status rkh_rrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_rrtstar_stats* stats);
+/* pos [num_vertices][n_dof], pred[num_vertices] (0xFFFFFFFF = unconnected), dist[num_vertices] (distance_accum),
+ * near_seq[loop_iterations] (x_near returned by the node generator).  Any pointer may be NULL. */
+rkh_status rkh_rrtstar_get_graph(rkh_rrtstar* p, uint32_t problem, double* pos, uint32_t* pred, double* dist,
+                                 uint32_t* near_seq);
 /* With RKH_PROFILE_NN=1 in the environment at rkh_planner_create, every round brackets its NN sweep kernel with
  * HIP events on the planner stream: total kernel time, algorithmic bytes (n*D*8 per sweep) and launch count. */
 rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* total_bytes, uint64_t* launches);

@@ -320,6 +320,42 @@ void orc_qs_move(void* h, int D, const double* lower, const double* upper, doubl
     n_checked[i] = uint32_t(sp.cnt.states_checked - before);
   }
 }
+// RRT* over the quasi-static joint space
+struct OrcRrtStarOut {
+  uint64_t num_vertices, samples, loop_iterations, num_solutions, rewires, edges_checked, states_checked;
+  double best_cost, seconds;
+};
+static RrtStarResult g_last_star;
+int orc_rrtstar_qs(void* h, int D, const double* lower, const double* upper, double min_interval,
+                   const rkh_rrt_params* prm, int64_t max_loop_iterations, OrcRrtStarOut* out) {
+  Scene* s = static_cast<Scene*>(h);
+  QuasiStaticSpace sp;
+  sp.D = D;
+  sp.lower.assign(lower, lower + D);
+  sp.upper.assign(upper, upper + D);
+  sp.min_interval = min_interval;
+  sp.chain = s->chain;
+  sp.env = s->env;
+  auto t0 = std::chrono::steady_clock::now();
+  generate_rrt_star(sp, *prm, long(max_loop_iterations), g_last_star);
+  out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  out->num_vertices = g_last_star.pred.size();
+  out->samples = g_last_star.samples;
+  out->loop_iterations = g_last_star.loop_iterations;
+  out->num_solutions = g_last_star.num_solutions;
+  out->rewires = g_last_star.rewires;
+  out->edges_checked = g_last_star.cnt.edges_checked;
+  out->states_checked = g_last_star.cnt.states_checked;
+  out->best_cost = g_last_star.best_cost;
+  return 0;
+}
+void orc_rrtstar_copy(double* pos, uint32_t* pred, double* dist, uint32_t* near_seq) {
+  if (pos) std::memcpy(pos, g_last_star.pos.data(), g_last_star.pos.size() * sizeof(double));
+  if (pred) std::memcpy(pred, g_last_star.pred.data(), g_last_star.pred.size() * sizeof(uint32_t));
+  if (dist) std::memcpy(dist, g_last_star.dist.data(), g_last_star.dist.size() * sizeof(double));
+  if (near_seq) std::memcpy(near_seq, g_last_star.near_seq.data(), g_last_star.near_seq.size() * sizeof(uint32_t));
+}
+
 // copy the arrays of the last RRT run
 void orc_rrt_copy(double* pos, uint32_t* parent, uint32_t* nn_seq, uint8_t* accept, double* goal_dist) {
   if (pos) std::memcpy(pos, g_last.pos.data(), g_last.pos.size() * sizeof(double));

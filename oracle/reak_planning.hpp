@@ -380,3 +380,173 @@ void generate_rrt(Space& space, const rkh_rrt_params& prm, long max_iterations, 
 
 }  // namespace oracle
 #endif
+
+// --------------------------------------------------------------------------------------------
+// RRT* (unidirectional, linear-search k-NN, undirected motion graph = symmetric metric space):
+// rrtstar_planner::solve_planning_query_impl (ctrl/path_planning/rrtstar_path_planner.tpp:298-)
+//  -> generate_rrt_star (ctrl/graph_alg/rrt_star.hpp:530-570) -> generate_rrt_star_loop (:169-190)
+// with rrg_node_generator (node_generators.hpp:137-172), star_neighborhood
+// (neighborhood_functors.hpp:95-102) and lazy_node_connector (lazy_connector.hpp:332-372).
+namespace oracle {
+
+struct RrtStarResult {
+  int D = 0;
+  std::vector<double> pos;        // vertex 0 = start, vertex 1 = goal (init_motion_graph, rrtstar_path_planner.tpp:188-203)
+  std::vector<uint32_t> pred;     // predecessor (start: itself; unconnected: 0xFFFFFFFF)
+  std::vector<double> dist;       // distance_accum
+  std::vector<double> weight;     // weight of the edge (pred -> v)
+  std::vector<uint32_t> near_seq; // per loop iteration: x_near returned by the node generator (0xFFFFFFFF = none)
+  long samples = 0;               // samples drawn (node generator retries included)
+  long loop_iterations = 0;
+  long num_solutions = 0;
+  long rewires = 0;
+  double best_cost = std::numeric_limits<double>::infinity();
+  SpaceCounters cnt;
+};
+
+template <typename Space>
+void generate_rrt_star(Space& space, const rkh_rrt_params& prm, long max_loop_iterations, RrtStarResult& res) {
+  const int D = space.D;
+  const uint32_t NIL = 0xFFFFFFFFu;
+  GlobalRng rng(prm.seed);
+  res = RrtStarResult();
+  res.D = D;
+  Point start(prm.start, prm.start + D), goal(prm.goal, prm.goal + D);
+  auto add_vertex = [&](const Point& p, double d, uint32_t pr) {
+    res.pos.insert(res.pos.end(), p.begin(), p.end());
+    res.dist.push_back(d);
+    res.pred.push_back(pr);
+    res.weight.push_back(0.0);
+    return uint32_t(res.pred.size() - 1);
+  };
+  auto P = [&](uint32_t v) { return Point(res.pos.begin() + std::size_t(v) * D, res.pos.begin() + std::size_t(v + 1) * D); };
+  const double inf = std::numeric_limits<double>::infinity();
+  add_vertex(start, 0.0, 0);   // put(distance, start, 0.0); put(predecessor, start, start)  (rrt_star.hpp:563-564)
+  add_vertex(goal, inf, NIL);  // initialize_vertex (planning_visitors.hpp:136-140)
+  std::vector<std::vector<uint32_t>> children(2);
+  const double space_dim = double(D);                 // get_space_dimensionality()
+  const double gamma = 3.0 * space.metric(start, goal);  // 3 * heuristic(start -> goal), rrtstar_path_planner.tpp:303,322
+  unsigned long m_iteration_count = 0;
+  auto keep_going = [&]() {
+    return (m_iteration_count < prm.max_vertices) && (prm.max_results > (unsigned long)res.num_solutions);
+  };
+  std::vector<std::pair<double, std::size_t>> nc;
+  auto select_neighborhood = [&](const Point& p, std::vector<uint32_t>& out) {  // star_neighborhood::operator()
+    std::size_t k;
+    double radius;
+    star_neighborhood(res.pred.size(), space_dim, gamma, &k, &radius);
+    linear_knn(p.data(), res.pos.data(), res.pred.size(), D, k, radius, nc);
+    out.clear();
+    for (auto& e : nc) out.push_back(uint32_t(e.second));
+  };
+  // planning_visitor_base::can_be_connected (planning_visitors.hpp:385-395)
+  auto can_be_connected = [&](uint32_t u, uint32_t v, double* w) {
+    Point p_result;
+    Point pu = P(u), pv = P(v);
+    double traveled = space.steer(pu, pv, 1.0, p_result);
+    double remaining = space.metric(p_result, pv);
+    *w = traveled;
+    return (!std::isinf(traveled)) && (remaining < prm.conn_tol * traveled);
+  };
+  std::vector<uint32_t> Nc;
+  while (keep_going() && (max_loop_iterations < 0 || res.loop_iterations < max_loop_iterations)) {
+    ++res.loop_iterations;
+    // ---- rrg_node_generator (node_generators.hpp:137-172)
+    Point p_new;
+    uint32_t x_near = NIL;
+    double eweight = 0.0;
+    for (std::size_t i = 0;; ++i) {
+      p_new = space.random_point(rng);
+      ++res.samples;
+      select_neighborhood(p_new, Nc);
+      bool was_expanded = false;
+      for (uint32_t u : Nc) {  // rrg_node_puller::expand_to_nearest (:61-77)
+        Point pu = P(u), p_tmp;
+        double traveled = space.steer(pu, p_new, 1.0, p_tmp);
+        double best_case = space.metric(pu, p_new);
+        bool ok = (!std::isinf(traveled)) && (traveled < 2.0 * best_case) && (traveled > prm.steer_tol * best_case);
+        if (ok) {
+          p_new = p_tmp;
+          x_near = u;
+          eweight = traveled;
+          was_expanded = true;
+          break;
+        }
+      }
+      if (was_expanded) break;
+      if (i >= 10) { x_near = NIL; break; }
+    }
+    res.near_seq.push_back(x_near);
+    if (x_near == NIL || res.dist[x_near] == inf) continue;  // rrt_star.hpp:181-182
+    // ---- lazy_node_connector::operator() (lazy_connector.hpp:332-372)
+    select_neighborhood(p_new, Nc);
+    uint32_t v = add_vertex(p_new, inf, NIL);  // rrt_conn_visitor::create_vertex (rrt_star.hpp:112-128)
+    children.emplace_back();
+    ++m_iteration_count;  // vis.vertex_added -> report_progress
+    // vertex_added: dispatched_register_solution for optimal graphs (planning_visitors.hpp:108-116,176-182)
+    if (res.pred[1] != NIL && res.dist[1] < res.best_cost) {
+      res.best_cost = res.dist[1];  // register_optimal_solution_path_impl (solution_path_factories.hpp:226-270)
+      ++res.num_solutions;
+    }
+    // connect_best_predecessor (:79-123)
+    {
+      const uint32_t x_near_original = x_near;
+      double d_near = res.dist[x_near] + eweight;
+      for (uint32_t u : Nc) {
+        if (u == x_near_original || res.pred[u] == NIL) continue;
+        double tentative_weight = space.metric(P(u), P(v));
+        double d_out = tentative_weight + res.dist[u];
+        if (d_out < d_near) {
+          double w;
+          if (can_be_connected(u, v, &w)) {
+            x_near = u;
+            d_near = d_out;
+            eweight = w;
+          }
+        }
+      }
+    }
+    // pruned_node_connector::create_pred_edge (pruned_connector.hpp:366-382); edge_added returns early (goal node exists)
+    res.dist[v] = eweight + res.dist[x_near];
+    res.pred[v] = x_near;
+    res.weight[v] = eweight;
+    children[x_near].push_back(v);
+    // connect_successors (:230-275)
+    for (uint32_t u : Nc) {
+      if (u == x_near) continue;
+      double tentative_weight = space.metric(P(v), P(u));
+      double d_in = tentative_weight + res.dist[v];
+      if (d_in < res.dist[u]) {
+        double w;
+        if (can_be_connected(v, u, &w)) {
+          res.dist[u] = d_in;
+          uint32_t old_pred = res.pred[u];
+          res.pred[u] = v;
+          res.weight[u] = w;
+          children[v].push_back(u);
+          if (old_pred != u && old_pred != NIL) {  // remove_edge(old_pred, u)
+            auto& ch = children[old_pred];
+            ch.erase(std::find(ch.begin(), ch.end(), u));
+          }
+          ++res.rewires;
+        }
+      }
+    }
+    // pruned_node_connector::update_successors (pruned_connector.hpp:310-332)
+    {
+      std::vector<uint32_t> incons(1, v);
+      while (!incons.empty()) {
+        uint32_t s = incons.back();
+        incons.pop_back();
+        for (uint32_t t : children[s]) {
+          if (res.pred[t] != s) continue;
+          res.dist[t] = res.dist[s] + res.weight[t];
+          incons.push_back(t);
+        }
+      }
+    }
+  }
+  res.cnt = space.cnt;
+}
+
+}  // namespace oracle

@@ -679,7 +679,7 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
   stage_env(sc, env_lds, lane);
   GroupWs<N>& ws = lds.g[g];
   const uint32_t si = io.src_idx ? io.src_idx[e] : ((io.d_src_first ? *io.d_src_first : 0u) + e);
-  const uint64_t trow = (io.d_tgt_off ? uint64_t(*io.d_tgt_off) : 0ull) + e;
+  const uint64_t trow = io.tgt_idx ? uint64_t(io.tgt_idx[e]) : ((io.d_tgt_off ? uint64_t(*io.d_tgt_off) : 0ull) + e);
   const double a_d = (gl < N) ? io.src[uint64_t(si) * io.src_stride + gl] : 0.0;
   const double b_d = (gl < N) ? io.tgt[trow * io.tgt_stride + gl] : 0.0;
   const double lo = (gl < N) ? qs.lower[gl] : 0.0;

@@ -167,6 +167,7 @@ struct EdgeIO {  // inputs / outputs of one propagate launch (all device pointer
   uint32_t src_stride = 0;
   const double* tgt = nullptr;         // target rows
   const uint32_t* d_tgt_off = nullptr; // row offset read on the device
+  const uint32_t* tgt_idx = nullptr;   // optional: target row of edge e (quasi-static edge kernel)
   uint32_t tgt_stride = 0;             // 0: one target for all edges
   uint32_t B = 0;
   const uint32_t* d_B = nullptr;

@@ -32,6 +32,12 @@ class SingularityError(RkhError):
     """singularity_error of the reference (core/lin_alg/mat_num_exceptions.hpp), status RKH_ERR_SINGULAR."""
 
 
+class RrtStarStats(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint64), ("samples", C.c_uint64), ("loop_iterations", C.c_uint64),
+                ("num_solutions", C.c_uint64), ("rewires", C.c_uint64), ("edges_checked", C.c_uint64),
+                ("best_cost", C.c_double)]
+
+
 class PlannerStats(C.Structure):
     _fields_ = [
         ("num_vertices", C.c_uint64),
@@ -52,7 +58,8 @@ EXPORTS = [
     "rkh_scene_create", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
-    "rkh_planner_nn_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch",
+    "rkh_planner_nn_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
+    "rkh_rrtstar_get_graph",
 ]
 
 
@@ -108,6 +115,10 @@ def load():
     lib.rkh_planner_create.argtypes = [vp, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), C.POINTER(vp)]
     lib.rkh_planner_create_batch.argtypes = [vp, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), u32, C.POINTER(vp)]
     lib.rkh_planner_create_qs_batch.argtypes = [vp, C.POINTER(T.QsSpace), C.POINTER(T.RrtParams), u32, C.POINTER(vp)]
+    lib.rkh_rrtstar_create_qs_batch.argtypes = [vp, C.POINTER(T.QsSpace), C.POINTER(T.RrtParams), u32, C.POINTER(vp)]
+    lib.rkh_rrtstar_destroy.argtypes = [vp]
+    lib.rkh_rrtstar_solve.argtypes = [vp, C.c_int64, C.POINTER(RrtStarStats)]
+    lib.rkh_rrtstar_get_graph.argtypes = [vp, u32, dp, u32p, dp, u32p]
     lib.rkh_planner_num_problems.restype = u32
     lib.rkh_planner_num_problems.argtypes = [vp]
     lib.rkh_planner_destroy.argtypes = [vp]
@@ -356,6 +367,48 @@ class RrtPlanner:
     def close(self):
         if self.h:
             self.lib.rkh_planner_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RrtStarPlanner:
+    """rrtstar_planner (unidirectional, linear-search k-NN) over the quasi-static free space, batch of problems."""
+
+    def __init__(self, scene, prm, qs):
+        self.scene, self.lib, self.qs = scene, scene.lib, qs
+        self.prms = list(prm) if isinstance(prm, (list, tuple)) else [prm]
+        self.P, self.D = len(self.prms), qs.n_dof
+        self._prm_arr = T.as_array(self.prms, T.RrtParams)
+        self.h = C.c_void_p()
+        _check(self.lib.rkh_rrtstar_create_qs_batch(scene.h, C.byref(qs), self._prm_arr, self.P, C.byref(self.h)))
+        self.all_stats = (RrtStarStats * self.P)()
+
+    @property
+    def stats(self):
+        return self.all_stats[0]
+
+    def solve_planning_query(self, max_loop_iterations=-1):
+        _check(self.lib.rkh_rrtstar_solve(self.h, int(max_loop_iterations), self.all_stats))
+        return self.all_stats[0]
+
+    def graph(self, problem=0):
+        st = self.all_stats[problem]
+        nv, it = int(st.num_vertices), int(st.loop_iterations)
+        pos = np.zeros((nv, self.D))
+        pred = np.zeros(nv, dtype=np.uint32)
+        dist = np.zeros(nv)
+        near = np.zeros(max(it, 1), dtype=np.uint32)
+        _check(self.lib.rkh_rrtstar_get_graph(self.h, problem, T.dptr(pos), T.u32ptr(pred), T.dptr(dist), T.u32ptr(near)))
+        return {"pos": pos, "pred": pred, "dist": dist, "near_seq": near[:it]}
+
+    def close(self):
+        if self.h:
+            self.lib.rkh_rrtstar_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

@@ -26,6 +26,12 @@ class RrtOut(C.Structure):
     ]
 
 
+class RrtStarOut(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint64), ("samples", C.c_uint64), ("loop_iterations", C.c_uint64),
+                ("num_solutions", C.c_uint64), ("rewires", C.c_uint64), ("edges_checked", C.c_uint64),
+                ("states_checked", C.c_uint64), ("best_cost", C.c_double), ("seconds", C.c_double)]
+
+
 def build():
     subprocess.run(["make", "-s", "-C", _ORACLE_DIR], check=True)
 
@@ -76,6 +82,8 @@ def load(fast=False):
     lib.orc_rrt_dyn.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtOut)]
     lib.orc_rrt_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtOut)]
     lib.orc_qs_move.argtypes = [C.c_void_p, C.c_int, dp, dp, d, dp, dp, C.c_int, d, dp, u32p]
+    lib.orc_rrtstar_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtStarOut)]
+    lib.orc_rrtstar_copy.argtypes = [dp, u32p, dp, u32p]
     lib.orc_rrt_copy.argtypes = [dp, u32p, u32p, C.POINTER(C.c_uint8), dp]
     _libs[name] = lib
     return lib
@@ -152,6 +160,18 @@ class OracleScene:
         rc = self.lib.orc_rrt_qs(self.h, len(lower), T.dptr(lower), T.dptr(upper), float(min_interval), C.byref(prm),
                                  int(max_iterations), C.byref(out))
         return rc, out, self._copy_rrt(out, len(lower))
+
+    def rrtstar_qs(self, lower, upper, min_interval, prm, max_loop_iterations=-1):
+        lower = np.ascontiguousarray(lower, dtype=np.float64)
+        upper = np.ascontiguousarray(upper, dtype=np.float64)
+        out = RrtStarOut()
+        rc = self.lib.orc_rrtstar_qs(self.h, len(lower), T.dptr(lower), T.dptr(upper), float(min_interval), C.byref(prm),
+                                     int(max_loop_iterations), C.byref(out))
+        nv, D = int(out.num_vertices), len(lower)
+        pos = np.zeros((nv, D)); pred = np.zeros(nv, dtype=np.uint32); dist = np.zeros(nv)
+        near = np.zeros(max(int(out.loop_iterations), 1), dtype=np.uint32)
+        self.lib.orc_rrtstar_copy(T.dptr(pos), T.u32ptr(pred), T.dptr(dist), T.u32ptr(near))
+        return rc, out, {"pos": pos, "pred": pred, "dist": dist, "near_seq": near[: int(out.loop_iterations)]}
 
     def qs_move(self, lower, upper, min_interval, a, b, fraction=1.0):
         lower = np.ascontiguousarray(lower, dtype=np.float64)

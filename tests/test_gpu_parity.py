@@ -291,3 +291,38 @@ def test_c1_stops_at_first_solution(L, ctx, oracle):
     assert (st.num_vertices, st.iterations, st.num_solutions) == (rout.num_vertices, rout.iterations, 1)
     assert st.best_cost == rout.best_cost
     assert np.array_equal(pl.tree()["parent"], rtree["parent"])
+
+
+# ------------------------------------------------------------------ RRT* (a24)
+@pytest.mark.parametrize("seed", [1, 2])
+def test_rrtstar_graph_identical_to_sequential_planner(L, ctx, oracle, seed):
+    """RRT* with k-NN rewiring over the quasi-static space: same vertices, predecessors, accumulated costs, rewires."""
+    c1 = scenarios.make_c1(world_seed=1)
+    sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    prm = c1.rrt_params(seed=seed, max_vertices=1200)
+    rc, rout, rg = osc.rrtstar_qs(lo, hi, mi, prm)
+    pl = L.RrtStarPlanner(sc, prm, L.make_qs_space(3, lo, hi, mi))
+    st = pl.solve_planning_query()
+    g = pl.graph()
+    assert (st.num_vertices, st.samples, st.loop_iterations, st.num_solutions, st.rewires, st.edges_checked) == (
+        rout.num_vertices, rout.samples, rout.loop_iterations, rout.num_solutions, rout.rewires, rout.edges_checked)
+    assert st.rewires > 100 and st.num_solutions > 0
+    assert np.array_equal(g["near_seq"], rg["near_seq"])
+    assert np.array_equal(g["pred"], rg["pred"])
+    assert np.array_equal(g["pos"], rg["pos"])    # straight-line edges: bit-exact
+    assert np.array_equal(g["dist"], rg["dist"])  # accumulated costs after rewiring and cost propagation
+    assert st.best_cost == rout.best_cost
+
+
+def test_rrtstar_batch_of_seeds(L, ctx, oracle):
+    c1 = scenarios.make_c1(world_seed=1)
+    sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    prms = [c1.rrt_params(seed=s, max_vertices=300) for s in (5, 6, 7, 8)]
+    pl = L.RrtStarPlanner(sc, prms, L.make_qs_space(3, lo, hi, mi))
+    pl.solve_planning_query()
+    for i, prm in enumerate(prms):
+        rc, rout, rg = osc.rrtstar_qs(lo, hi, mi, prm)
+        assert pl.all_stats[i].num_vertices == rout.num_vertices and pl.all_stats[i].rewires == rout.rewires
+        assert np.array_equal(pl.graph(i)["pred"], rg["pred"]) and np.array_equal(pl.graph(i)["dist"], rg["dist"])
