@@ -219,3 +219,14 @@ def make_c1(world_seed=1, n_obstacles=10, min_interval=0.05):
                    start=np.zeros(n), goal=np.array([np.pi / 2, 0.0, 0.0]),
                    meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi), "min_interval": min_interval})
     return scn
+
+
+def make_c3(world_seed=1, min_interval=0.05):
+    """BASELINE config C3/C5: the 6-DOF chain and 50-obstacle world of C2, planned in the quasi-static joint space
+    (manip_quasi_static_env) with RRT* and star_neighborhood k-NN rewiring."""
+    c2 = make_c2(world_seed=world_seed)
+    n = c2.n_dof
+    scn = Scenario(name="C3", ops=c2.ops, base=c2.base, shapes=c2.shapes, dyn=c2.dyn, n_dof=n, n_frames=c2.n_frames,
+                   start=np.zeros(n), goal=np.array([1.5, 0.9, -0.8, 0.5, 0.7, -0.3]),
+                   meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi), "min_interval": min_interval})
+    return scn
