@@ -1,0 +1,316 @@
+// graph_batch.h -- device plumbing shared by the motion-graph planners whose loop iterations are sequential
+// (RRT*, PRM): P independent problems, each a small state machine on the host; one "step" of every problem
+// (append a vertex row -> k-NN of one point -> candidate edge list from the k-NN result -> quasi-static edge
+// walk of every candidate) runs as ONE set of launches for all problems (device tables, blockIdx.z / .y =
+// problem) with one command upload and one result download -- the cost of a step does not grow with P until
+// the chip is full.  The sequential rules of the reference (neighbour order, strict comparisons, running
+// minima) are applied by the host to the downloaded, mutually independent verdicts.
+//
+// Reference pieces served: star_neighborhood + min_dist_linear_search k-NN (ctrl/graph_alg/neighborhood_functors.hpp:95-102,
+// ctrl/path_planning/topological_search.hpp:244-274); steer_towards_position / can_be_connected over the
+// quasi-static free space (ctrl/path_planning/planning_visitors.hpp:349-360,385-395 ->
+// ctrl/interpolation/interpolated_topologies.hpp:137-163 -> manip_free_workspace.hpp:154-156).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "rkh_internal.h"
+
+namespace rkh {
+
+int nn_padded_dims(int D);
+
+enum GbListMode : uint32_t {
+  GB_LIST_NONE = 0,          // no edges this step
+  GB_LIST_KNN_TO_QUERY = 1,  // (u -> query point) for every k-NN result u, in k-NN order
+  GB_LIST_KNN_BIDIR = 2,     // (u -> v) for every u, then (v -> u) for every u
+  GB_LIST_KNN_TO_VERTEX = 3, // (u -> v) for every u
+  GB_LIST_POINT = 4,         // one edge (v -> query point)
+};
+
+struct GbAux {  // per-problem command fields read by the prep / list kernels
+  double query[RKH_MAX_DOF];
+  double append_row[RKH_MAX_DOF];
+  double* append_dst;      // null: nothing to append
+  uint32_t list_mode;
+  uint32_t v;              // vertex id used by the list modes
+  const uint32_t* kidx;    // k-NN result (device)
+  const uint32_t* kcnt;
+  uint32_t* src_idx;       // edge lists (device)
+  uint32_t* tgt_idx;
+  uint32_t* n_edges;       // device-side edge count (read by the edge kernel)
+};
+
+static __global__ void gb_prep_kernel(const GbAux* __restrict__ aux, int DP) {
+  const GbAux& a = aux[blockIdx.x];
+  if (a.append_dst && int(threadIdx.x) < DP) a.append_dst[threadIdx.x] = threadIdx.x < RKH_MAX_DOF ? a.append_row[threadIdx.x] : 0.0;
+}
+
+static __global__ void gb_list_kernel(const GbAux* __restrict__ aux) {
+  const GbAux& a = aux[blockIdx.x];
+  const uint32_t K = (a.list_mode == GB_LIST_NONE || a.list_mode == GB_LIST_POINT) ? 0u : *a.kcnt;
+  uint32_t E = 0;
+  switch (a.list_mode) {
+    case GB_LIST_KNN_TO_QUERY:
+      E = K;
+      for (uint32_t e = threadIdx.x; e < K; e += blockDim.x) a.src_idx[e] = a.kidx[e];
+      break;
+    case GB_LIST_KNN_BIDIR:
+      E = 2 * K;
+      for (uint32_t e = threadIdx.x; e < K; e += blockDim.x) {
+        a.src_idx[e] = a.kidx[e];
+        a.tgt_idx[e] = a.v;
+        a.src_idx[K + e] = a.v;
+        a.tgt_idx[K + e] = a.kidx[e];
+      }
+      break;
+    case GB_LIST_KNN_TO_VERTEX:
+      E = K;
+      for (uint32_t e = threadIdx.x; e < K; e += blockDim.x) {
+        a.src_idx[e] = a.kidx[e];
+        a.tgt_idx[e] = a.v;
+      }
+      break;
+    case GB_LIST_POINT:
+      E = 1;
+      if (threadIdx.x == 0) a.src_idx[0] = a.v;
+      break;
+    default: break;
+  }
+  if (threadIdx.x == 0) *a.n_edges = E;
+}
+
+struct GbProblem {
+  NnStore tree;
+  uint64_t n_dev = 0;            // rows on the device
+  void* d_knn_ws = nullptr;
+  uint32_t* d_src_idx = nullptr;
+  uint32_t* d_tgt_idx = nullptr;
+};
+
+struct GraphBatch {
+  rkh_scene* scene = nullptr;
+  hipStream_t stream = nullptr;
+  QsDev qs;
+  int n_dof = 0, D = 0, DP = 0;
+  uint32_t P = 0, kmax = 0, emax = 0;
+  std::vector<GbProblem> prob;
+  static constexpr size_t kKnnWsBytes = 128 * 1024;
+  // command block: [KnnArgs x P][EdgeIO x P][GbAux x P], pinned host copy + device copy
+  unsigned char *h_cmd = nullptr, *d_cmd = nullptr;
+  size_t cmd_bytes = 0;
+  KnnArgs *h_knn = nullptr, *d_knn = nullptr;
+  EdgeIO *h_io = nullptr, *d_io = nullptr;
+  GbAux *h_aux = nullptr, *d_aux = nullptr;
+  // result block per problem: {kcnt, overflow, n_edges, pad} kidx[kmax] kdist[kmax] nchk[emax] accept[emax] x_out[emax][D]
+  unsigned char *h_res = nullptr, *d_res = nullptr;
+  size_t res_stride = 0, off_kidx = 0, off_kdist = 0, off_nchk = 0, off_accept = 0, off_xout = 0;
+  bool any_knn = false, any_edges = false, any_append = false;
+  uint64_t steps = 0;
+
+  rkh_status init(rkh_scene* sc, const rkh_qs_space* space, uint32_t n_problems, const uint64_t* capacities,
+                  uint32_t kmax_) {
+    scene = sc;
+    n_dof = space->n_dof;
+    D = space->n_dof;
+    DP = nn_padded_dims(D);
+    P = n_problems;
+    kmax = kmax_;
+    emax = 2 * kmax_;
+    std::memset(&qs, 0, sizeof(qs));
+    qs.min_interval = space->min_interval;
+    qs.fraction = 1.0;
+    for (int d = 0; d < D; ++d) {
+      qs.lower[d] = space->lower[d];
+      qs.upper[d] = space->upper[d];
+    }
+    RKH_HIP(hipSetDevice(sc->ctx->device));
+    RKH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    cmd_bytes = size_t(P) * (sizeof(KnnArgs) + sizeof(EdgeIO) + sizeof(GbAux));
+    RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_cmd), cmd_bytes, hipHostMallocDefault));
+    RKH_HIP(hipMalloc(reinterpret_cast<void**>(&d_cmd), cmd_bytes));
+    auto carve = [&](unsigned char* base, KnnArgs** k, EdgeIO** io, GbAux** ax) {
+      *k = reinterpret_cast<KnnArgs*>(base);
+      *io = reinterpret_cast<EdgeIO*>(base + size_t(P) * sizeof(KnnArgs));
+      *ax = reinterpret_cast<GbAux*>(base + size_t(P) * (sizeof(KnnArgs) + sizeof(EdgeIO)));
+    };
+    carve(h_cmd, &h_knn, &h_io, &h_aux);
+    carve(d_cmd, &d_knn, &d_io, &d_aux);
+    auto up8 = [](size_t v) { return (v + 7) / 8 * 8; };
+    off_kidx = 16;
+    off_kdist = up8(off_kidx + size_t(kmax) * 4);
+    off_nchk = off_kdist + size_t(kmax) * 8;
+    off_accept = off_nchk + size_t(emax) * 4;
+    off_xout = up8(off_accept + emax);
+    res_stride = up8(off_xout + size_t(emax) * D * 8);
+    RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_res), res_stride * P, hipHostMallocDefault));
+    RKH_HIP(hipMalloc(reinterpret_cast<void**>(&d_res), res_stride * P));
+    RKH_HIP(hipMemset(d_res, 0, res_stride * P));
+    std::memset(h_res, 0, res_stride * P);
+    prob.resize(P);
+    for (uint32_t i = 0; i < P; ++i) {
+      GbProblem& q = prob[i];
+      q.tree.D = D;
+      q.tree.capacity = (capacities[i] + 255) / 256 * 256;
+      RKH_HIP(hipMalloc(&q.tree.d_pos, q.tree.capacity * DP * sizeof(double)));
+      RKH_HIP(hipMalloc(&q.d_knn_ws, kKnnWsBytes));
+      RKH_HIP(hipMalloc(&q.d_src_idx, emax * sizeof(uint32_t)));
+      RKH_HIP(hipMalloc(&q.d_tgt_idx, emax * sizeof(uint32_t)));
+    }
+    begin();
+    return RKH_OK;
+  }
+
+  void destroy() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (GbProblem& q : prob) {
+      (void)hipFree(q.tree.d_pos);
+      (void)hipFree(q.d_knn_ws);
+      (void)hipFree(q.d_src_idx);
+      (void)hipFree(q.d_tgt_idx);
+    }
+    prob.clear();
+    (void)hipHostFree(h_cmd);
+    (void)hipFree(d_cmd);
+    (void)hipHostFree(h_res);
+    (void)hipFree(d_res);
+    if (stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+  }
+
+  unsigned char* dres(uint32_t i) const { return d_res + size_t(i) * res_stride; }
+  const unsigned char* hres(uint32_t i) const { return h_res + size_t(i) * res_stride; }
+  // ---- results of the last run()
+  uint32_t kcnt(uint32_t i) const { return reinterpret_cast<const uint32_t*>(hres(i))[0]; }
+  uint32_t overflow(uint32_t i) const { return reinterpret_cast<const uint32_t*>(hres(i))[1]; }
+  uint32_t n_edges(uint32_t i) const { return reinterpret_cast<const uint32_t*>(hres(i))[2]; }
+  const uint32_t* kidx(uint32_t i) const { return reinterpret_cast<const uint32_t*>(hres(i) + off_kidx); }
+  const double* kdist(uint32_t i) const { return reinterpret_cast<const double*>(hres(i) + off_kdist); }
+  const uint32_t* nchk(uint32_t i) const { return reinterpret_cast<const uint32_t*>(hres(i) + off_nchk); }
+  const uint8_t* accept(uint32_t i) const { return hres(i) + off_accept; }
+  const double* x_out(uint32_t i) const { return reinterpret_cast<const double*>(hres(i) + off_xout); }
+
+  // ---- command building
+  void begin() {
+    for (uint32_t i = 0; i < P; ++i) {
+      h_knn[i] = KnnArgs();
+      h_io[i] = EdgeIO();
+      GbAux& a = h_aux[i];
+      a.append_dst = nullptr;
+      a.list_mode = GB_LIST_NONE;
+      a.v = 0;
+      a.kidx = reinterpret_cast<const uint32_t*>(dres(i) + off_kidx);
+      a.kcnt = reinterpret_cast<const uint32_t*>(dres(i));
+      a.src_idx = prob[i].d_src_idx;
+      a.tgt_idx = prob[i].d_tgt_idx;
+      a.n_edges = reinterpret_cast<uint32_t*>(dres(i)) + 2;
+    }
+    any_knn = any_edges = any_append = false;
+  }
+  // vertex row n_dev of problem i (the caller's vertex ids are row numbers)
+  rkh_status cmd_append(uint32_t i, const double* row) {
+    GbProblem& q = prob[i];
+    if (q.n_dev >= q.tree.capacity || h_aux[i].append_dst) {
+      set_error("graph batch: vertex capacity exceeded (or two appends in one step)");
+      return RKH_ERR_CAPACITY;
+    }
+    GbAux& a = h_aux[i];
+    for (int d = 0; d < RKH_MAX_DOF; ++d) a.append_row[d] = d < D ? row[d] : 0.0;
+    a.append_dst = q.tree.d_pos + q.n_dev * DP;
+    ++q.n_dev;
+    any_append = true;
+    return RKH_OK;
+  }
+  // k nearest of `query` among the first n rows, strictly inside `radius`
+  rkh_status cmd_knn(uint32_t i, const double* query, uint64_t n, uint32_t k, double radius) {
+    GbProblem& q = prob[i];
+    if (k > kmax) {
+      set_error("graph batch: k exceeds the planned maximum");
+      return RKH_ERR_CAPACITY;
+    }
+    for (int d = 0; d < RKH_MAX_DOF; ++d) h_aux[i].query[d] = d < D ? query[d] : 0.0;
+    KnnArgs& a = h_knn[i];
+    size_t bytes = 0;
+    rkh_status st = knn_plan(n, 1, k, &a.ws, &bytes);
+    if (st != RKH_OK) return st;
+    if (bytes > kKnnWsBytes) {
+      set_error("graph batch: k-NN workspace too small");
+      return RKH_ERR_CAPACITY;
+    }
+    knn_carve(q.d_knn_ws, 1, &a.ws);
+    a.ws.overflow = reinterpret_cast<uint32_t*>(dres(i)) + 1;
+    a.pos = q.tree.d_pos;
+    a.n = n;
+    a.q = d_aux[i].query;
+    a.D = D;
+    a.B = 1;
+    a.k = k;
+    a.radius = radius;
+    a.m_pow2 = next_pow2(a.ws.m_sub);
+    a.out_idx = reinterpret_cast<uint32_t*>(dres(i) + off_kidx);
+    a.out_dist = reinterpret_cast<double*>(dres(i) + off_kdist);
+    a.out_cnt = reinterpret_cast<uint32_t*>(dres(i));
+    any_knn = true;
+    return RKH_OK;
+  }
+  void cmd_query_point(uint32_t i, const double* query) {
+    for (int d = 0; d < RKH_MAX_DOF; ++d) h_aux[i].query[d] = d < D ? query[d] : 0.0;
+  }
+  // candidate edges of this step (see GbListMode); mode / tol as in EdgeIO
+  void cmd_edges(uint32_t i, uint32_t list_mode, uint32_t v, int mode, double tol) {
+    GbProblem& q = prob[i];
+    GbAux& a = h_aux[i];
+    a.list_mode = list_mode;
+    a.v = v;
+    EdgeIO& io = h_io[i];
+    io.src = q.tree.d_pos;
+    io.src_idx = q.d_src_idx;
+    io.src_stride = DP;
+    if (list_mode == GB_LIST_KNN_TO_QUERY || list_mode == GB_LIST_POINT) {
+      io.tgt = d_aux[i].query;
+      io.tgt_stride = 0;
+    } else {
+      io.tgt = q.tree.d_pos;
+      io.tgt_idx = q.d_tgt_idx;
+      io.tgt_stride = DP;
+    }
+    io.B = 0;
+    io.d_B = reinterpret_cast<const uint32_t*>(dres(i)) + 2;
+    io.x_out = reinterpret_cast<double*>(dres(i) + off_xout);
+    io.steps_free = reinterpret_cast<uint32_t*>(dres(i) + off_nchk);
+    io.accept = dres(i) + off_accept;
+    io.mode = mode;
+    io.steer_tol = tol;
+    io.err_flag = scene->d_err;
+    any_edges = true;
+  }
+
+  rkh_status run() {
+    hipStream_t s = stream;
+    RKH_HIP(hipMemcpyAsync(d_cmd, h_cmd, cmd_bytes, hipMemcpyHostToDevice, s));
+    if (any_append) hipLaunchKernelGGL(gb_prep_kernel, dim3(P), dim3(64), 0, s, d_aux, DP);
+    if (any_knn) {
+      rkh_status st = launch_nnk_table(s, D, d_knn, h_knn, P);
+      if (st != RKH_OK) return st;
+    }
+    hipLaunchKernelGGL(gb_list_kernel, dim3(P), dim3(64), 0, s, d_aux);
+    if (any_edges) {
+      rkh_status st = launch_edge_check(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, qs,
+                                        EdgeIO(), emax, nullptr, 0, d_io, nullptr, P);
+      if (st != RKH_OK) return st;
+    }
+    RKH_HIP(hipMemcpyAsync(h_res, d_res, res_stride * P, hipMemcpyDeviceToHost, s));
+    RKH_HIP(hipStreamSynchronize(s));
+    ++steps;
+    for (uint32_t i = 0; i < P; ++i)
+      if (h_knn[i].B && overflow(i)) {
+        set_error("graph batch: k-NN candidate capacity exceeded");
+        return RKH_ERR_CAPACITY;
+      }
+    return RKH_OK;
+  }
+};
+
+}  // namespace rkh

@@ -34,12 +34,22 @@ static constexpr int kR = kThreads / kQB;    // row subsets per block
 
 // MODE 0: bound sweep (writes per-thread subset minima).  MODE 1: collect sweep (appends candidates).
 template <int DP, int MODE>
-__global__ __launch_bounds__(kThreads) void knn_sweep_kernel(const double* __restrict__ pos, uint64_t n,
-                                                              const double* __restrict__ q, int D, uint32_t B,
-                                                              uint32_t Bpad, double radius, double* __restrict__ sub,
-                                                              const double* __restrict__ tau, uint32_t* __restrict__ cnt,
-                                                              double* __restrict__ cand_d, uint32_t* __restrict__ cand_i,
-                                                              uint32_t cmax, uint32_t* __restrict__ overflow) {
+__global__ __launch_bounds__(kThreads) void knn_sweep_kernel(KnnArgs single, const KnnArgs* __restrict__ tab) {
+  const KnnArgs a = tab ? tab[blockIdx.z] : single;
+  if (blockIdx.x >= a.ws.gx || blockIdx.y * kQB >= a.B) return;  // a table's grid is sized for its largest job
+  const double* __restrict__ pos = a.pos;
+  const uint64_t n = a.n;
+  const double* __restrict__ q = a.q;
+  const int D = a.D;
+  const uint32_t B = a.B, Bpad = a.B, cmax = a.ws.cmax;
+  const double radius = a.radius;
+  double* __restrict__ sub = a.ws.sub;
+  const double* __restrict__ tau = a.ws.tau;
+  uint32_t* __restrict__ cnt = a.ws.cnt;
+  double* __restrict__ cand_d = a.ws.cand_d;
+  uint32_t* __restrict__ cand_i = a.ws.cand_i;
+  uint32_t* __restrict__ overflow = a.ws.overflow;
+  const uint32_t gx = a.ws.gx;
   constexpr int ROWS_PER_THREAD = kTileRows / kR;
   __shared__ __attribute__((aligned(16))) double tile[kTileRows * DP];
   const int tid = threadIdx.x;
@@ -54,7 +64,7 @@ __global__ __launch_bounds__(kThreads) void knn_sweep_kernel(const double* __res
     for (int d = 0; d < DP; ++d) qv[d] = d < D ? q[qsrc * D + d] : 0.0;
   }
   const uint64_t tiles_total = (n + kTileRows - 1) / kTileRows;
-  const uint64_t tiles_per_block = (tiles_total + gridDim.x - 1) / gridDim.x;
+  const uint64_t tiles_per_block = (tiles_total + gx - 1) / gx;
   const uint64_t tile0 = uint64_t(blockIdx.x) * tiles_per_block;
   uint64_t tile1 = tile0 + tiles_per_block;
   if (tile1 > tiles_total) tile1 = tiles_total;
@@ -136,13 +146,18 @@ __device__ __forceinline__ void bitonic_sort_lds(double* key, uint32_t* idx, uin
 }
 
 // one block per query: tau = k-th smallest subset minimum (or +inf if there are fewer than k subsets)
-__global__ __launch_bounds__(256) void knn_tau_kernel(const double* __restrict__ sub, uint32_t m_sub, uint32_t m_pow2,
-                                                       uint32_t Bpad, uint32_t k, double* __restrict__ tau,
-                                                       uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow) {
+__global__ __launch_bounds__(256) void knn_tau_kernel(KnnArgs single, const KnnArgs* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const KnnArgs a = tab ? tab[blockIdx.z] : single;
+  const uint32_t qi = blockIdx.x;
+  if (qi >= a.B) return;
+  const double* __restrict__ sub = a.ws.sub;
+  const uint32_t m_sub = a.ws.m_sub, m_pow2 = a.m_pow2, Bpad = a.B, k = a.k;
+  double* __restrict__ tau = a.ws.tau;
+  uint32_t* __restrict__ cnt = a.ws.cnt;
+  uint32_t* __restrict__ overflow = a.ws.overflow;
   double* key = reinterpret_cast<double*>(smem);
   uint32_t* idx = reinterpret_cast<uint32_t*>(key + m_pow2);
-  const uint32_t qi = blockIdx.x;
   for (uint32_t i = threadIdx.x; i < m_pow2; i += blockDim.x) {
     key[i] = i < m_sub ? sub[uint64_t(i) * Bpad + qi] : INFINITY;
     idx[i] = i;
@@ -156,14 +171,20 @@ __global__ __launch_bounds__(256) void knn_tau_kernel(const double* __restrict__
 }
 
 // one block per query: sort the candidates, write the first k (nearest first), pad the rest
-__global__ __launch_bounds__(256) void knn_select_kernel(const double* __restrict__ cand_d, const uint32_t* __restrict__ cand_i,
-                                                          const uint32_t* __restrict__ cnt, uint32_t cmax, uint32_t c_pow2,
-                                                          uint32_t k, uint32_t* __restrict__ out_idx,
-                                                          double* __restrict__ out_dist, uint32_t* __restrict__ out_cnt) {
+__global__ __launch_bounds__(256) void knn_select_kernel(KnnArgs single, const KnnArgs* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const KnnArgs a = tab ? tab[blockIdx.z] : single;
+  const uint32_t qi = blockIdx.x;
+  if (qi >= a.B) return;
+  const double* __restrict__ cand_d = a.ws.cand_d;
+  const uint32_t* __restrict__ cand_i = a.ws.cand_i;
+  const uint32_t* __restrict__ cnt = a.ws.cnt;
+  const uint32_t cmax = a.ws.cmax, c_pow2 = a.ws.cmax, k = a.k;
+  uint32_t* __restrict__ out_idx = a.out_idx;
+  double* __restrict__ out_dist = a.out_dist;
+  uint32_t* __restrict__ out_cnt = a.out_cnt;
   double* key = reinterpret_cast<double*>(smem);
   uint32_t* idx = reinterpret_cast<uint32_t*>(key + c_pow2);
-  const uint32_t qi = blockIdx.x;
   uint32_t nc = cnt[qi];
   if (nc > cmax) nc = cmax;
   for (uint32_t i = threadIdx.x; i < c_pow2; i += blockDim.x) {
@@ -179,7 +200,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const double* __restric
   if (threadIdx.x == 0) out_cnt[qi] = found;
 }
 
-static uint32_t next_pow2(uint32_t v) {
+uint32_t next_pow2(uint32_t v) {
   uint32_t p = 1;
   while (p < v) p <<= 1;
   return p;
@@ -221,27 +242,20 @@ void knn_carve(void* base, uint32_t B, KnnWorkspace* ws) {
 }
 
 template <int DP>
-static void launch_nnk_dp(hipStream_t s, const NnStore& st, uint64_t n, const double* d_q, uint32_t B, uint32_t k,
-                          double radius, uint32_t* d_idx, double* d_dist, uint32_t* d_count, const KnnWorkspace& ws) {
-  const uint32_t gy = (B + kQB - 1) / kQB;
-  dim3 grid(ws.gx, gy), block(kThreads);
-  hipLaunchKernelGGL((knn_sweep_kernel<DP, 0>), grid, block, 0, s, st.d_pos, n, d_q, st.D, B, B, radius, ws.sub, nullptr,
-                     nullptr, nullptr, nullptr, ws.cmax, ws.overflow);
-  const uint32_t m_pow2 = next_pow2(ws.m_sub);
-  hipLaunchKernelGGL(knn_tau_kernel, dim3(B), dim3(256), size_t(m_pow2) * 12, s, ws.sub, ws.m_sub, m_pow2, B, k, ws.tau,
-                     ws.cnt, ws.overflow);
-  hipLaunchKernelGGL((knn_sweep_kernel<DP, 1>), grid, block, 0, s, st.d_pos, n, d_q, st.D, B, B, radius, nullptr, ws.tau,
-                     ws.cnt, ws.cand_d, ws.cand_i, ws.cmax, ws.overflow);
-  hipLaunchKernelGGL(knn_select_kernel, dim3(B), dim3(256), size_t(ws.cmax) * 12, s, ws.cand_d, ws.cand_i, ws.cnt, ws.cmax,
-                     ws.cmax, k, d_idx, d_dist, d_count);
+static void launch_nnk_dp(hipStream_t s, const KnnArgs& single, const KnnArgs* d_tab, uint32_t gx, uint32_t gy,
+                          uint32_t b_max, uint32_t m_pow2, uint32_t cmax, uint32_t n_jobs) {
+  dim3 grid(gx, gy, n_jobs), block(kThreads);
+  hipLaunchKernelGGL((knn_sweep_kernel<DP, 0>), grid, block, 0, s, single, d_tab);
+  hipLaunchKernelGGL(knn_tau_kernel, dim3(b_max, 1, n_jobs), dim3(256), size_t(m_pow2) * 12, s, single, d_tab);
+  hipLaunchKernelGGL((knn_sweep_kernel<DP, 1>), grid, block, 0, s, single, d_tab);
+  hipLaunchKernelGGL(knn_select_kernel, dim3(b_max, 1, n_jobs), dim3(256), size_t(cmax) * 12, s, single, d_tab);
 }
 
-rkh_status launch_nnk(hipStream_t s, const NnStore& st, uint64_t n, const double* d_q, uint32_t B, uint32_t k,
-                      double radius, uint32_t* d_idx, double* d_dist, uint32_t* d_count, const KnnWorkspace& ws) {
-  if (B == 0) return RKH_OK;
-  switch (nn_padded_dims(st.D)) {
+static rkh_status launch_nnk_any(hipStream_t s, int D, const KnnArgs& single, const KnnArgs* d_tab, uint32_t gx,
+                                 uint32_t gy, uint32_t b_max, uint32_t m_pow2, uint32_t cmax, uint32_t n_jobs) {
+  switch (nn_padded_dims(D)) {
 #define RKH_CASE(DP) \
-  case DP: launch_nnk_dp<DP>(s, st, n, d_q, B, k, radius, d_idx, d_dist, d_count, ws); break
+  case DP: launch_nnk_dp<DP>(s, single, d_tab, gx, gy, b_max, m_pow2, cmax, n_jobs); break
     RKH_CASE(2);
     RKH_CASE(4);
     RKH_CASE(6);
@@ -255,6 +269,39 @@ rkh_status launch_nnk(hipStream_t s, const NnStore& st, uint64_t n, const double
   }
   RKH_HIP(hipGetLastError());
   return RKH_OK;
+}
+
+rkh_status launch_nnk(hipStream_t s, const NnStore& st, uint64_t n, const double* d_q, uint32_t B, uint32_t k,
+                      double radius, uint32_t* d_idx, double* d_dist, uint32_t* d_count, const KnnWorkspace& ws) {
+  if (B == 0) return RKH_OK;
+  KnnArgs a;
+  a.pos = st.d_pos;
+  a.n = n;
+  a.q = d_q;
+  a.D = st.D;
+  a.B = B;
+  a.k = k;
+  a.radius = radius;
+  a.ws = ws;
+  a.m_pow2 = next_pow2(ws.m_sub);
+  a.out_idx = d_idx;
+  a.out_dist = d_dist;
+  a.out_cnt = d_count;
+  return launch_nnk_any(s, st.D, a, nullptr, ws.gx, (B + kQB - 1) / kQB, B, a.m_pow2, ws.cmax, 1);
+}
+
+rkh_status launch_nnk_table(hipStream_t s, int D, const KnnArgs* d_table, const KnnArgs* h_table, uint32_t n_jobs) {
+  uint32_t gx = 0, b_max = 0, m_pow2 = 0, cmax = 0;
+  for (uint32_t i = 0; i < n_jobs; ++i) {
+    const KnnArgs& a = h_table[i];
+    if (a.B == 0) continue;
+    gx = std::max(gx, a.ws.gx);
+    b_max = std::max(b_max, a.B);
+    m_pow2 = std::max(m_pow2, a.m_pow2);
+    cmax = std::max(cmax, a.ws.cmax);
+  }
+  if (b_max == 0) return RKH_OK;
+  return launch_nnk_any(s, D, KnnArgs(), d_table, gx, (b_max + kQB - 1) / kQB, b_max, m_pow2, cmax, n_jobs);
 }
 
 }  // namespace rkh

@@ -67,6 +67,24 @@ rkh_status knn_plan(uint64_t n, uint32_t B, uint32_t k, KnnWorkspace* ws, size_t
 void knn_carve(void* base, uint32_t B, KnnWorkspace* ws);
 rkh_status launch_nnk(hipStream_t s, const NnStore& st, uint64_t n, const double* d_q, uint32_t B, uint32_t k,
                       double radius, uint32_t* d_idx, double* d_dist, uint32_t* d_count, const KnnWorkspace& ws);
+// One k-NN job (one tree, B queries).  A launch serves either one job (by value) or a device table of jobs
+// (blockIdx.z = job; RRT* / PRM batches: one query per problem, all problems in the same four launches).
+struct KnnArgs {
+  const double* pos = nullptr;  // [n][DP] vertex rows
+  uint64_t n = 0;
+  const double* q = nullptr;    // [B][D]
+  int D = 0;
+  uint32_t B = 0, k = 0;
+  double radius = 0.0;
+  KnnWorkspace ws;
+  uint32_t m_pow2 = 0;          // next_pow2(ws.m_sub)
+  uint32_t* out_idx = nullptr;  // [B][k]
+  double* out_dist = nullptr;
+  uint32_t* out_cnt = nullptr;  // [B]
+};
+uint32_t next_pow2(uint32_t v);
+// Launch a table of jobs (d_table on the device, h_table its host copy for grid sizing).  All jobs share D.
+rkh_status launch_nnk_table(hipStream_t s, int D, const KnnArgs* d_table, const KnnArgs* h_table, uint32_t n_jobs);
 rkh_status launch_fill_uniform(hipStream_t s, const NnStore& st, uint64_t n, uint64_t seed);
 
 // ---- scene (propagate.hip) ---------------------------------------------------------------------
