@@ -38,6 +38,7 @@ typedef struct rkh_nn rkh_nn;           /* device-resident vertex set for NN que
 typedef struct rkh_scene rkh_scene;     /* KTE chain + proxy environment on the device */
 typedef struct rkh_planner rkh_planner; /* batched RRT driver over a scene */
 typedef struct rkh_rrtstar rkh_rrtstar; /* batched RRT* driver over a scene */
+typedef struct rkh_prm rkh_prm;         /* batched PRM driver over a scene */
 
 const char* rkh_last_error(void);
 const char* rkh_version(void);
@@ -187,6 +188,30 @@ rkh_status rkh_rrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_rr
  * near_seq[loop_iterations] (x_near returned by the node generator).  Any pointer may be NULL. */
 rkh_status rkh_rrtstar_get_graph(rkh_rrtstar* p, uint32_t problem, double* pos, uint32_t* pred, double* dist,
                                  uint32_t* near_seq);
+/* ---- PRM: prm_planner::solve_planning_query (LINEAR_SEARCH_KNN, ADJ_LIST_MOTION_GRAPH, undirected graph) ----
+ * (ctrl/path_planning/prm_path_planner.tpp:131-365 -> generate_prm, ctrl/graph_alg/probabilistic_roadmap.hpp:211-249,
+ * 309-404; prm_node_connector prm_connector.hpp:68-182; prm_conn_visitor probabilistic_roadmap.hpp:75-196;
+ * prm_density_calculator density_calculators.hpp:45-73; random_walk planning_visitors.hpp:403-432) over the
+ * quasi-static free space.  One loop iteration (construct: rejection sampling + k-NN + can_be_connected to every
+ * neighbour; expand: the 11 random-walk attempts from the lowest-density vertex + k-NN + connections) is one batched
+ * device step for all problems.  Vertex 0 = start, vertex 1 = goal.  As in the reference (which instantiates
+ * density_plan_visitor here), no solution is registered: the roadmap grows to max_vertices; merged_at_vertex is the
+ * vertex count at which start and goal first shared a connected component (-1: never). */
+typedef struct rkh_prm_stats {
+  uint64_t num_vertices, num_edges, samples, rejected, loop_iterations, num_components, publish_calls;
+  int64_t merged_at_vertex;
+  uint64_t edges_checked, device_steps;
+} rkh_prm_stats;
+rkh_status rkh_prm_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_prm_params* prms,
+                                   uint32_t n_problems, rkh_prm** out);
+rkh_status rkh_prm_destroy(rkh_prm* p);
+/* stats: array of n_problems entries.  max_loop_iterations < 0: run until keep_going() is false. */
+rkh_status rkh_prm_solve(rkh_prm* p, int64_t max_loop_iterations, rkh_prm_stats* stats);
+/* pos [num_vertices][n_dof]; edge_u/edge_v/edge_w [num_edges] in insertion order; density, cc_root [num_vertices];
+ * kind [loop_iterations] (0 construct, 1 expand, 2 expand failed -> Q.pop()); expanded [loop_iterations] (Q.top() of
+ * expansion iterations, else 0xFFFFFFFF).  Any pointer may be NULL. */
+rkh_status rkh_prm_get_graph(rkh_prm* p, uint32_t problem, double* pos, uint32_t* edge_u, uint32_t* edge_v,
+                             double* edge_w, double* density, uint32_t* cc_root, uint8_t* kind, uint32_t* expanded);
 /* With RKH_PROFILE_NN=1 in the environment at rkh_planner_create, every round brackets its NN sweep kernel with
  * HIP events on the planner stream: total kernel time, algorithmic bytes (n*D*8 per sweep) and launch count. */
 rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* total_bytes, uint64_t* launches);

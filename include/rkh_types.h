@@ -104,6 +104,15 @@ typedef struct rkh_rrt_params {
   double goal[RKH_MAX_STATE];
 } rkh_rrt_params;
 
+/* prm_planner (ctrl/path_planning/prm_path_planner.tpp:131-365): the options above plus the sampling radius used
+ * by random_walk (planning_visitors.hpp:403-432) and prm_density_calculator (density_calculators.hpp:45-73), and the
+ * expansion probability (fixed at 0.2 by the reference's generate_prm call, prm_path_planner.tpp:250-253). */
+typedef struct rkh_prm_params {
+  rkh_rrt_params base;
+  double sampling_radius;     /* m_sampling_radius */
+  double expand_probability;  /* 0.2 in the reference */
+} rkh_prm_params;
+
 #ifdef __cplusplus
 }
 #endif

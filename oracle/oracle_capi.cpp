@@ -356,6 +356,52 @@ void orc_rrtstar_copy(double* pos, uint32_t* pred, double* dist, uint32_t* near_
   if (near_seq) std::memcpy(near_seq, g_last_star.near_seq.data(), g_last_star.near_seq.size() * sizeof(uint32_t));
 }
 
+// ---- PRM over the quasi-static free space
+struct OrcPrmOut {
+  uint64_t num_vertices, num_edges, samples, rejected, loop_iterations, num_components, publish_calls;
+  int64_t merged_at_vertex;
+  uint64_t edges_checked, states_checked;
+  double seconds;
+};
+static PrmResult g_last_prm;
+int orc_prm_qs(void* h, int D, const double* lower, const double* upper, double min_interval,
+               const rkh_prm_params* prm, int64_t max_loop_iterations, OrcPrmOut* out) {
+  Scene* s = static_cast<Scene*>(h);
+  QuasiStaticSpace sp;
+  sp.D = D;
+  sp.lower.assign(lower, lower + D);
+  sp.upper.assign(upper, upper + D);
+  sp.min_interval = min_interval;
+  sp.chain = s->chain;
+  sp.env = s->env;
+  auto t0 = std::chrono::steady_clock::now();
+  generate_prm(sp, *prm, long(max_loop_iterations), g_last_prm);
+  out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  out->num_vertices = g_last_prm.density.size();
+  out->num_edges = g_last_prm.edge_w.size();
+  out->samples = g_last_prm.samples;
+  out->rejected = g_last_prm.rejected;
+  out->loop_iterations = g_last_prm.loop_iterations;
+  out->num_components = g_last_prm.num_components;
+  out->publish_calls = g_last_prm.publish_calls;
+  out->merged_at_vertex = g_last_prm.merged_at_vertex;
+  out->edges_checked = g_last_prm.cnt.edges_checked;
+  out->states_checked = g_last_prm.cnt.states_checked;
+  return 0;
+}
+void orc_prm_copy(double* pos, uint32_t* edge_u, uint32_t* edge_v, double* edge_w, double* density, uint32_t* cc_root,
+                  uint8_t* kind, uint32_t* expanded) {
+  const PrmResult& r = g_last_prm;
+  if (pos) std::memcpy(pos, r.pos.data(), r.pos.size() * sizeof(double));
+  if (edge_u) std::memcpy(edge_u, r.edge_u.data(), r.edge_u.size() * sizeof(uint32_t));
+  if (edge_v) std::memcpy(edge_v, r.edge_v.data(), r.edge_v.size() * sizeof(uint32_t));
+  if (edge_w) std::memcpy(edge_w, r.edge_w.data(), r.edge_w.size() * sizeof(double));
+  if (density) std::memcpy(density, r.density.data(), r.density.size() * sizeof(double));
+  if (cc_root) std::memcpy(cc_root, r.cc_root.data(), r.cc_root.size() * sizeof(uint32_t));
+  if (kind) std::memcpy(kind, r.kind.data(), r.kind.size());
+  if (expanded) std::memcpy(expanded, r.expanded.data(), r.expanded.size() * sizeof(uint32_t));
+}
+
 // copy the arrays of the last RRT run
 void orc_rrt_copy(double* pos, uint32_t* parent, uint32_t* nn_seq, uint8_t* accept, double* goal_dist) {
   if (pos) std::memcpy(pos, g_last.pos.data(), g_last.pos.size() * sizeof(double));

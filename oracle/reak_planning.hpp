@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <limits>
 #include <random>
+#include <set>
 #include <utility>
 #include <vector>
 
@@ -546,6 +547,335 @@ void generate_rrt_star(Space& space, const rkh_rrt_params& prm, long max_loop_it
       }
     }
   }
+  res.cnt = space.cnt;
+}
+
+}  // namespace oracle
+
+// --------------------------------------------------------------------------------------------
+// PRM (LINEAR_SEARCH_KNN, ADJ_LIST_MOTION_GRAPH, undirected motion graph):
+// prm_planner::solve_planning_query (ctrl/path_planning/prm_path_planner.tpp:131-365)
+//  -> generate_prm (ctrl/graph_alg/probabilistic_roadmap.hpp:309-404) -> generate_prm_impl (:211-249)
+// with prm_node_connector (prm_connector.hpp:68-182), prm_conn_visitor (probabilistic_roadmap.hpp:75-196),
+// density_plan_visitor<prm_density_calculator> (density_plan_visitors.hpp:50-224, density_calculators.hpp:45-73),
+// random_walk (planning_visitors.hpp:403-432) and star_neighborhood.
+//
+// Reference behaviour kept: solve_planning_query instantiates density_plan_visitor, not prm_planner_visitor, so
+// publish_path is planning_visitor_base's (planning_visitors.hpp:119-126): it tests the goal vertex's
+// distance_accum, which nothing on this path ever updates from infinity -- no solution is registered and the
+// roadmap grows until max_vertex_count.  (We report the start/goal component merge separately.)
+//
+// Third-party pieces restated from their published definitions ("parity unpinned", sources not in
+// /root/reference): boost::d_ary_heap_indirect<V,4,...,std::less<double>> (boost/graph/detail/d_ary_heap.hpp:
+// push, push_or_update = insert-or-sift-UP-only, pop, top); BGL-Extra adjacency_list_BC out_edges order, taken
+// here as the insertion order of a vertex's incident edges.
+namespace oracle {
+
+// boost::d_ary_heap_indirect, Arity 4, keys read through the density map at comparison time
+struct DAryHeap4 {
+  std::vector<uint32_t> data;
+  std::vector<std::size_t>* index_in_heap = nullptr;
+  const std::vector<double>* key = nullptr;
+  static std::size_t parent(std::size_t i) { return (i - 1) / 4; }
+  std::size_t& idx(uint32_t v) {
+    if (index_in_heap->size() <= v) index_in_heap->resize(v + 1, 0);  // vector_property_map grows with value 0
+    return (*index_in_heap)[v];
+  }
+  bool empty() const { return data.empty(); }
+  uint32_t top() const { return data[0]; }
+  void preserve_heap_property_up(std::size_t index) {
+    std::size_t orig_index = index, num_levels_moved = 0;
+    if (index == 0) return;
+    uint32_t moving = data[index];
+    double moving_dist = (*key)[moving];
+    for (;;) {
+      if (index == 0) break;
+      std::size_t parent_index = parent(index);
+      uint32_t parent_value = data[parent_index];
+      if (moving_dist < (*key)[parent_value]) {
+        ++num_levels_moved;
+        index = parent_index;
+        continue;
+      } else {
+        break;
+      }
+    }
+    index = orig_index;
+    for (std::size_t i = 0; i < num_levels_moved; ++i) {
+      std::size_t parent_index = parent(index);
+      uint32_t parent_value = data[parent_index];
+      idx(parent_value) = index;
+      data[index] = parent_value;
+      index = parent_index;
+    }
+    data[index] = moving;
+    idx(moving) = index;
+  }
+  void preserve_heap_property_down() {
+    if (data.empty()) return;
+    std::size_t index = 0;
+    uint32_t moving = data[0];
+    double moving_dist = (*key)[moving];
+    std::size_t heap_size = data.size();
+    for (;;) {
+      std::size_t first_child = index * 4 + 1;
+      if (first_child >= heap_size) break;
+      std::size_t smallest_child = 0;
+      double smallest_dist = (*key)[data[first_child]];
+      std::size_t n_children = (first_child + 4 <= heap_size) ? 4 : heap_size - first_child;
+      for (std::size_t i = 1; i < n_children; ++i) {
+        double i_dist = (*key)[data[first_child + i]];
+        if (i_dist < smallest_dist) {
+          smallest_child = i;
+          smallest_dist = i_dist;
+        }
+      }
+      if (smallest_dist < moving_dist) {
+        std::size_t c = first_child + smallest_child;  // swap_heap_elements(c, index)
+        uint32_t va = data[c], vb = data[index];
+        data[c] = vb;
+        data[index] = va;
+        idx(va) = index;
+        idx(vb) = c;
+        index = c;
+        continue;
+      } else {
+        break;
+      }
+    }
+  }
+  void push(uint32_t v) {
+    std::size_t index = data.size();
+    data.push_back(v);
+    idx(v) = index;
+    preserve_heap_property_up(index);
+  }
+  void push_or_update(uint32_t v) {  // insert if absent; in both cases only sift up
+    std::size_t index = idx(v);
+    if (index == std::size_t(-1)) {
+      index = data.size();
+      data.push_back(v);
+      idx(v) = index;
+    }
+    preserve_heap_property_up(index);
+  }
+  void pop() {
+    idx(data[0]) = std::size_t(-1);
+    if (data.size() != 1) {
+      data[0] = data.back();
+      idx(data[0]) = 0;
+      data.pop_back();
+      preserve_heap_property_down();
+    } else {
+      data.pop_back();
+    }
+  }
+};
+
+struct PrmResult {
+  int D = 0;
+  std::vector<double> pos;           // vertex 0 = start, 1 = goal
+  std::vector<uint32_t> edge_u, edge_v;
+  std::vector<double> edge_w;
+  std::vector<double> density;
+  std::vector<uint32_t> cc_root;     // raw union-find parents at the end
+  std::vector<uint8_t> kind;         // per loop iteration: 0 construct, 1 expand (vertex added), 2 expand failed (Q.pop)
+  std::vector<uint32_t> expanded;    // per loop iteration: Q.top() of expansion iterations, else 0xFFFFFFFF
+  long samples = 0, rejected = 0, loop_iterations = 0, num_components = 0;
+  long publish_calls = 0;            // times cc_set.size() < 2 triggered publish_path
+  long merged_at_vertex = -1;        // vertex count when start and goal first shared a component
+  SpaceCounters cnt;
+};
+
+template <typename Space>
+void generate_prm(Space& space, const rkh_prm_params& pp, long max_loop_iterations, PrmResult& res) {
+  const rkh_rrt_params& prm = pp.base;
+  const int D = space.D;
+  const uint32_t NIL = 0xFFFFFFFFu;
+  GlobalRng rng(prm.seed);
+  res = PrmResult();
+  res.D = D;
+  Point start(prm.start, prm.start + D), goal(prm.goal, prm.goal + D);
+  std::vector<std::vector<uint32_t>> incident;  // per vertex: incident edge ids, insertion order
+  std::vector<std::size_t> index_in_heap;
+  DAryHeap4 Q;
+  Q.index_in_heap = &index_in_heap;
+  Q.key = &res.density;
+  std::vector<uint32_t>& cc_root = res.cc_root;
+  std::set<uint32_t> cc_set;
+  const double space_dim = double(D);
+  const double gamma = 3.0 * space.metric(start, goal);
+  const double sampling_radius = pp.sampling_radius;
+  unsigned long m_iteration_count = 0;
+  auto P = [&](uint32_t v) { return Point(res.pos.begin() + std::size_t(v) * D, res.pos.begin() + std::size_t(v + 1) * D); };
+  auto keep_going = [&]() { return (m_iteration_count < prm.max_vertices) && (prm.max_results > 0ul); };
+  // prm_density_calculator::update_density (density_calculators.hpp:55-72)
+  auto update_density = [&](uint32_t u) {
+    std::size_t deg_u = incident[u].size();
+    if (deg_u == 0) {
+      res.density[u] = 0.0;
+      return;
+    }
+    std::size_t max_node_degree = std::size_t(D) + 1;
+    double sum = 0.0;
+    for (uint32_t e : incident[u]) sum += res.edge_w[e] / sampling_radius;
+    sum /= double(deg_u) * double(deg_u) / double(max_node_degree);
+    res.density[u] = std::exp(-sum * sum);
+  };
+  auto raw_add_vertex = [&](const Point& p) {
+    res.pos.insert(res.pos.end(), p.begin(), p.end());
+    res.density.push_back(0.0);
+    incident.emplace_back();
+    cc_root.push_back(0);
+    return uint32_t(res.density.size() - 1);
+  };
+  // prm_conn_visitor::requeue_vertex / affected_vertex (probabilistic_roadmap.hpp:160-166)
+  auto requeue = [&](uint32_t u) {
+    update_density(u);  // density_plan_visitor::affected_vertex -> init_nonrecursive_density
+    Q.push_or_update(u);
+  };
+  auto shortcut_cc_root = [&](uint32_t u) {  // :109-121
+    std::vector<uint32_t> trace(1, u);
+    while (cc_root[u] != u) {
+      u = cc_root[u];
+      trace.push_back(u);
+    }
+    while (!trace.empty()) {
+      cc_root[trace.back()] = u;
+      trace.pop_back();
+    }
+  };
+  auto edge_added = [&](uint32_t u, uint32_t v) {  // :123-143 (m_vis.edge_added returns early: the goal node exists)
+    shortcut_cc_root(u);
+    shortcut_cc_root(v);
+    if (cc_root[v] != cc_root[u]) {
+      uint32_t r1 = cc_root[u], r2 = cc_root[v];
+      cc_root[r2] = r1;
+      cc_root[v] = r1;
+      cc_set.erase(r2);
+      if (cc_set.size() < 2) ++res.publish_calls;  // publish_path: registers nothing (see header)
+    }
+    if (res.merged_at_vertex < 0) {
+      uint32_t a = 0, b = 1;
+      while (cc_root[a] != a) a = cc_root[a];
+      while (cc_root[b] != b) b = cc_root[b];
+      if (a == b) res.merged_at_vertex = long(res.density.size());
+    }
+  };
+  auto add_edge = [&](uint32_t u, uint32_t v, double w) {
+    uint32_t e = uint32_t(res.edge_w.size());
+    res.edge_u.push_back(u);
+    res.edge_v.push_back(v);
+    res.edge_w.push_back(w);
+    incident[u].push_back(e);
+    incident[v].push_back(e);
+    edge_added(u, v);
+  };
+  // ---- solve_planning_query: start and goal vertices (RK_PRM_PLANNER_INITIALIZE_START_AND_GOAL)
+  raw_add_vertex(start);
+  raw_add_vertex(goal);
+  // ---- generate_prm with a non-empty graph (:368-397)
+  for (uint32_t u = 0; u < 2; ++u) {
+    update_density(u);  // vis.affected_vertex
+    Q.push(u);
+    cc_root[u] = u;
+  }
+  for (uint32_t u = 0; u < 2; ++u) cc_set.insert(u);  // no edges yet: every vertex is its own component
+  std::vector<std::pair<double, std::size_t>> nc;
+  // planning_visitor_base::can_be_connected (planning_visitors.hpp:385-395)
+  auto can_be_connected = [&](uint32_t u, uint32_t v, double* w) {
+    Point p_result;
+    Point pu = P(u), pv = P(v);
+    double traveled = space.steer(pu, pv, 1.0, p_result);
+    double remaining = space.metric(p_result, pv);
+    *w = traveled;
+    return (!std::isinf(traveled)) && (remaining < prm.conn_tol * traveled);
+  };
+  // prm_node_connector::operator(), undirected (prm_connector.hpp:136-182)
+  auto connect_vertex = [&](const Point& p, uint32_t x_near, double eweight) {
+    std::size_t k;
+    double radius;
+    star_neighborhood(res.density.size(), space_dim, gamma, &k, &radius);
+    linear_knn(p.data(), res.pos.data(), res.density.size(), D, k, radius, nc);
+    std::vector<uint32_t> Nc;
+    for (auto& e : nc) Nc.push_back(uint32_t(e.second));
+    // prm_conn_visitor::create_vertex (:92-107)
+    uint32_t v = raw_add_vertex(p);
+    cc_root[v] = v;
+    cc_set.insert(v);
+    update_density(v);   // vertex_added -> initialize_vertex -> init_nonrecursive_density
+    ++m_iteration_count;  // report_progress; dispatched_register_solution: goal distance_accum is infinite
+    if (index_in_heap.size() <= v) index_in_heap.resize(v + 1, 0);
+    index_in_heap[v] = std::size_t(-1);
+    if (x_near != NIL) {  // connect_to_first_pred (:71-91)
+      add_edge(x_near, v, eweight);
+      requeue(x_near);
+    }
+    requeue(v);
+    for (uint32_t u : Nc) {
+      if (u == x_near) continue;
+      double w;
+      bool can_connect = can_be_connected(u, v, &w);
+      if (can_connect) add_edge(u, v, w);
+      requeue(u);  // affected by travel attempts
+    }
+    requeue(v);
+  };
+  while (keep_going() && (max_loop_iterations < 0 || res.loop_iterations < max_loop_iterations)) {
+    ++res.loop_iterations;
+    double rand_value = rng.uniform_01();
+    if (rand_value > pp.expand_probability) {
+      // construction node (:229-235)
+      Point p_rnd = space.random_point(rng);
+      ++res.samples;
+      while (!space.is_free(p_rnd)) {
+        ++res.rejected;
+        p_rnd = space.random_point(rng);
+        ++res.samples;
+      }
+      connect_vertex(p_rnd, NIL, 0.0);
+      res.kind.push_back(0);
+      res.expanded.push_back(NIL);
+    } else {
+      // expansion node (:237-246); random_walk (planning_visitors.hpp:403-432)
+      uint32_t v = Q.top();
+      res.expanded.push_back(v);
+      Point pv = P(v);
+      Point origin(D);  // hyperbox_topology::origin (hyperbox_topology.hpp:194-196)
+      for (int i = 0; i < D; ++i) origin[i] = space.lower[i] + 0.5 * (space.upper[i] - space.lower[i]);
+      unsigned int i = 0;
+      Point p_rnd = space.random_point(rng);
+      ++res.samples;
+      Point dp_rnd(D);
+      for (int d = 0; d < D; ++d) dp_rnd[d] = p_rnd[d] - origin[d];
+      Point p_result;
+      bool worked = false;
+      double w = 0.0;
+      do {
+        for (int d = 0; d < D; ++d) p_rnd[d] = pv[d] + dp_rnd[d];
+        double dist = space.metric(pv, p_rnd);
+        double target_dist = rng.uniform_01() * sampling_radius;
+        double traveled = space.steer(pv, p_rnd, target_dist / dist, p_result);
+        if ((!std::isinf(traveled)) && (traveled > prm.steer_tol * target_dist)) {
+          worked = true;
+          w = traveled;
+          break;
+        } else {
+          p_rnd = space.random_point(rng);
+          ++res.samples;
+          for (int d = 0; d < D; ++d) dp_rnd[d] = p_rnd[d] - origin[d];
+        }
+      } while (++i <= 10);
+      if (worked) {
+        connect_vertex(p_result, v, w);
+        res.kind.push_back(1);
+      } else {
+        Q.pop();
+        res.kind.push_back(2);
+      }
+    }
+  }
+  res.num_components = long(cc_set.size());
   res.cnt = space.cnt;
 }
 

@@ -30,10 +30,29 @@ enum GbListMode : uint32_t {
   GB_LIST_POINT = 4,         // one edge (v -> query point)
 };
 
-struct GbAux {  // per-problem command fields read by the prep / list kernels
+constexpr uint32_t kGbStageA = 16;  // candidate points / walks of the first stage
+
+enum GbSelect : uint32_t {
+  GB_SELECT_NONE = 0,
+  GB_SELECT_POINT = 1,  // the first accepted stage-A candidate point becomes the query point and the new vertex row
+  GB_SELECT_WALK = 2,   // the end point of the first accepted stage-A walk becomes the query point and the new vertex row
+};
+
+struct GbAux {  // per-problem command fields read by the prep / select / list kernels
   double query[RKH_MAX_DOF];
   double append_row[RKH_MAX_DOF];
   double* append_dst;      // null: nothing to append
+  // stage A (PRM): candidate points / random-walk targets, tested before the k-NN of the same step
+  double pts[kGbStageA][RKH_MAX_DOF];
+  double frac[kGbStageA];
+  double target_dist[kGbStageA];
+  uint32_t a_src[kGbStageA];
+  uint32_t a_count;
+  uint32_t select_mode;    // GbSelect
+  double* select_dst;      // row the selected point is appended to
+  const uint8_t* a_accept; // stage-A verdicts / end points (device result block)
+  const double* a_xout;
+  uint32_t* sel;           // selected candidate or 0xFFFFFFFF (device result block)
   uint32_t list_mode;
   uint32_t v;              // vertex id used by the list modes
   const uint32_t* kidx;    // k-NN result (device)
@@ -48,11 +67,33 @@ static __global__ void gb_prep_kernel(const GbAux* __restrict__ aux, int DP) {
   if (a.append_dst && int(threadIdx.x) < DP) a.append_dst[threadIdx.x] = threadIdx.x < RKH_MAX_DOF ? a.append_row[threadIdx.x] : 0.0;
 }
 
+// first accepted stage-A candidate -> query point of the k-NN and new vertex row (one block of 64 per problem)
+static __global__ void gb_select_kernel(GbAux* __restrict__ aux, int D, int DP) {
+  GbAux& a = aux[blockIdx.x];
+  if (a.select_mode == GB_SELECT_NONE) return;
+  uint32_t j = 0xFFFFFFFFu;
+  for (uint32_t c = 0; c < a.a_count; ++c)
+    if (a.a_accept[c]) {
+      j = c;
+      break;
+    }
+  if (threadIdx.x == 0) *a.sel = j;
+  if (j == 0xFFFFFFFFu) return;
+  const int d = threadIdx.x;
+  if (d < DP) {
+    double v = 0.0;
+    if (d < D) v = (a.select_mode == GB_SELECT_POINT) ? a.pts[j][d] : a.a_xout[size_t(j) * D + d];
+    if (d < RKH_MAX_DOF) a.query[d] = v;
+    a.select_dst[d] = v;
+  }
+}
+
 static __global__ void gb_list_kernel(const GbAux* __restrict__ aux) {
   const GbAux& a = aux[blockIdx.x];
-  const uint32_t K = (a.list_mode == GB_LIST_NONE || a.list_mode == GB_LIST_POINT) ? 0u : *a.kcnt;
+  const bool dropped = (a.select_mode != GB_SELECT_NONE) && (*a.sel == 0xFFFFFFFFu);  // nothing was selected
+  const uint32_t K = (a.list_mode == GB_LIST_NONE || a.list_mode == GB_LIST_POINT || dropped) ? 0u : *a.kcnt;
   uint32_t E = 0;
-  switch (a.list_mode) {
+  switch (dropped ? uint32_t(GB_LIST_NONE) : a.list_mode) {
     case GB_LIST_KNN_TO_QUERY:
       E = K;
       for (uint32_t e = threadIdx.x; e < K; e += blockDim.x) a.src_idx[e] = a.kidx[e];
@@ -98,16 +139,19 @@ struct GraphBatch {
   uint32_t P = 0, kmax = 0, emax = 0;
   std::vector<GbProblem> prob;
   static constexpr size_t kKnnWsBytes = 128 * 1024;
-  // command block: [KnnArgs x P][EdgeIO x P][GbAux x P], pinned host copy + device copy
+  // command block: [KnnArgs x P][EdgeIO x P][EdgeIO (stage A) x P][GbAux x P], pinned host copy + device copy
   unsigned char *h_cmd = nullptr, *d_cmd = nullptr;
   size_t cmd_bytes = 0;
   KnnArgs *h_knn = nullptr, *d_knn = nullptr;
   EdgeIO *h_io = nullptr, *d_io = nullptr;
+  EdgeIO *h_ioa = nullptr, *d_ioa = nullptr;
   GbAux *h_aux = nullptr, *d_aux = nullptr;
-  // result block per problem: {kcnt, overflow, n_edges, pad} kidx[kmax] kdist[kmax] nchk[emax] accept[emax] x_out[emax][D]
+  // result block per problem: {kcnt, overflow, n_edges, sel} kidx[kmax] kdist[kmax] nchk[emax] accept[emax] x_out[emax][D]
+  //                           a_nchk[16] a_accept[16] a_xout[16][D]
   unsigned char *h_res = nullptr, *d_res = nullptr;
-  size_t res_stride = 0, off_kidx = 0, off_kdist = 0, off_nchk = 0, off_accept = 0, off_xout = 0;
-  bool any_knn = false, any_edges = false, any_append = false;
+  size_t res_stride = 0, off_kidx = 0, off_kdist = 0, off_nchk = 0, off_accept = 0, off_xout = 0, off_anchk = 0,
+         off_aaccept = 0, off_axout = 0;
+  bool any_knn = false, any_edges = false, any_append = false, any_stage_a = false;
   uint64_t steps = 0;
 
   rkh_status init(rkh_scene* sc, const rkh_qs_space* space, uint32_t n_problems, const uint64_t* capacities,
@@ -128,23 +172,27 @@ struct GraphBatch {
     }
     RKH_HIP(hipSetDevice(sc->ctx->device));
     RKH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    cmd_bytes = size_t(P) * (sizeof(KnnArgs) + sizeof(EdgeIO) + sizeof(GbAux));
+    cmd_bytes = size_t(P) * (sizeof(KnnArgs) + 2 * sizeof(EdgeIO) + sizeof(GbAux));
     RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_cmd), cmd_bytes, hipHostMallocDefault));
     RKH_HIP(hipMalloc(reinterpret_cast<void**>(&d_cmd), cmd_bytes));
-    auto carve = [&](unsigned char* base, KnnArgs** k, EdgeIO** io, GbAux** ax) {
+    auto carve = [&](unsigned char* base, KnnArgs** k, EdgeIO** io, EdgeIO** ioa, GbAux** ax) {
       *k = reinterpret_cast<KnnArgs*>(base);
       *io = reinterpret_cast<EdgeIO*>(base + size_t(P) * sizeof(KnnArgs));
-      *ax = reinterpret_cast<GbAux*>(base + size_t(P) * (sizeof(KnnArgs) + sizeof(EdgeIO)));
+      *ioa = reinterpret_cast<EdgeIO*>(base + size_t(P) * (sizeof(KnnArgs) + sizeof(EdgeIO)));
+      *ax = reinterpret_cast<GbAux*>(base + size_t(P) * (sizeof(KnnArgs) + 2 * sizeof(EdgeIO)));
     };
-    carve(h_cmd, &h_knn, &h_io, &h_aux);
-    carve(d_cmd, &d_knn, &d_io, &d_aux);
+    carve(h_cmd, &h_knn, &h_io, &h_ioa, &h_aux);
+    carve(d_cmd, &d_knn, &d_io, &d_ioa, &d_aux);
     auto up8 = [](size_t v) { return (v + 7) / 8 * 8; };
     off_kidx = 16;
     off_kdist = up8(off_kidx + size_t(kmax) * 4);
     off_nchk = off_kdist + size_t(kmax) * 8;
     off_accept = off_nchk + size_t(emax) * 4;
     off_xout = up8(off_accept + emax);
-    res_stride = up8(off_xout + size_t(emax) * D * 8);
+    off_anchk = up8(off_xout + size_t(emax) * D * 8);
+    off_aaccept = off_anchk + kGbStageA * 4;
+    off_axout = up8(off_aaccept + kGbStageA);
+    res_stride = up8(off_axout + size_t(kGbStageA) * D * 8);
     RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_res), res_stride * P, hipHostMallocDefault));
     RKH_HIP(hipMalloc(reinterpret_cast<void**>(&d_res), res_stride * P));
     RKH_HIP(hipMemset(d_res, 0, res_stride * P));
@@ -191,14 +239,24 @@ struct GraphBatch {
   const uint32_t* nchk(uint32_t i) const { return reinterpret_cast<const uint32_t*>(hres(i) + off_nchk); }
   const uint8_t* accept(uint32_t i) const { return hres(i) + off_accept; }
   const double* x_out(uint32_t i) const { return reinterpret_cast<const double*>(hres(i) + off_xout); }
+  uint32_t selected(uint32_t i) const { return reinterpret_cast<const uint32_t*>(hres(i))[3]; }
+  const uint8_t* a_accept(uint32_t i) const { return hres(i) + off_aaccept; }
+  const double* a_x_out(uint32_t i) const { return reinterpret_cast<const double*>(hres(i) + off_axout); }
 
   // ---- command building
   void begin() {
     for (uint32_t i = 0; i < P; ++i) {
       h_knn[i] = KnnArgs();
       h_io[i] = EdgeIO();
+      h_ioa[i] = EdgeIO();
       GbAux& a = h_aux[i];
       a.append_dst = nullptr;
+      a.a_count = 0;
+      a.select_mode = GB_SELECT_NONE;
+      a.select_dst = nullptr;
+      a.a_accept = dres(i) + off_aaccept;
+      a.a_xout = reinterpret_cast<const double*>(dres(i) + off_axout);
+      a.sel = reinterpret_cast<uint32_t*>(dres(i)) + 3;
       a.list_mode = GB_LIST_NONE;
       a.v = 0;
       a.kidx = reinterpret_cast<const uint32_t*>(dres(i) + off_kidx);
@@ -207,8 +265,47 @@ struct GraphBatch {
       a.tgt_idx = prob[i].d_tgt_idx;
       a.n_edges = reinterpret_cast<uint32_t*>(dres(i)) + 2;
     }
-    any_knn = any_edges = any_append = false;
+    any_knn = any_edges = any_append = any_stage_a = false;
   }
+  // Stage A: `count` candidates of problem i, tested before this step's k-NN.
+  //   GB_SELECT_POINT: is_free(pts[c]);  GB_SELECT_WALK: walk from vertex v towards pts[c] by frac[c], accepted if
+  //   the distance travelled exceeds tol * target_dist[c] (random_walk).  The first accepted candidate (point, or
+  //   end point of the walk) becomes the query of cmd_knn and is appended as vertex row n_dev.  The caller fills
+  //   h_aux[i].pts / frac / target_dist and calls confirm_selected() after run() if selected(i) is valid.
+  rkh_status cmd_stage_a(uint32_t i, uint32_t select_mode, uint32_t count, uint32_t v, double tol) {
+    GbProblem& q = prob[i];
+    if (count > kGbStageA || q.n_dev >= q.tree.capacity) {
+      set_error("graph batch: stage-A candidate count or vertex capacity exceeded");
+      return RKH_ERR_CAPACITY;
+    }
+    GbAux& a = h_aux[i];
+    a.a_count = count;
+    a.select_mode = select_mode;
+    a.select_dst = q.tree.d_pos + q.n_dev * DP;
+    for (uint32_t c = 0; c < kGbStageA; ++c) a.a_src[c] = v;
+    EdgeIO& io = h_ioa[i];
+    io.src = q.tree.d_pos;
+    io.src_idx = d_aux[i].a_src;
+    io.src_stride = DP;
+    io.tgt = &d_aux[i].pts[0][0];
+    io.tgt_stride = RKH_MAX_DOF;
+    io.B = count;
+    io.x_out = reinterpret_cast<double*>(dres(i) + off_axout);
+    io.steps_free = reinterpret_cast<uint32_t*>(dres(i) + off_anchk);
+    io.accept = dres(i) + off_aaccept;
+    io.err_flag = scene->d_err;
+    if (select_mode == GB_SELECT_POINT) {
+      io.mode = EDGE_POINT;
+    } else {
+      io.mode = EDGE_WALK_ACCEPT;
+      io.frac = d_aux[i].frac;
+      io.best_case = d_aux[i].target_dist;
+      io.steer_tol = tol;
+    }
+    any_stage_a = true;
+    return RKH_OK;
+  }
+  void confirm_selected(uint32_t i) { ++prob[i].n_dev; }
   // vertex row n_dev of problem i (the caller's vertex ids are row numbers)
   rkh_status cmd_append(uint32_t i, const double* row) {
     GbProblem& q = prob[i];
@@ -291,6 +388,12 @@ struct GraphBatch {
     hipStream_t s = stream;
     RKH_HIP(hipMemcpyAsync(d_cmd, h_cmd, cmd_bytes, hipMemcpyHostToDevice, s));
     if (any_append) hipLaunchKernelGGL(gb_prep_kernel, dim3(P), dim3(64), 0, s, d_aux, DP);
+    if (any_stage_a) {
+      rkh_status st = launch_edge_check(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, qs,
+                                        EdgeIO(), kGbStageA, nullptr, 0, d_ioa, nullptr, P);
+      if (st != RKH_OK) return st;
+      hipLaunchKernelGGL(gb_select_kernel, dim3(P), dim3(64), 0, s, d_aux, D, DP);
+    }
     if (any_knn) {
       rkh_status st = launch_nnk_table(s, D, d_knn, h_knn, P);
       if (st != RKH_OK) return st;

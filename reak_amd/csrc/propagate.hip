@@ -698,8 +698,29 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
     __syncthreads();
     return sqrt(s);
   };
+  if (io.mode == EDGE_POINT) {
+    // is_free(target): hyperbox bounds, then proximity (manip_free_workspace.hpp:79-99,154-156); group 0 tests it
+    if (gl < N) ws.x[2 * gl] = b_d;
+    bool oob = false;
+    if (gl < N) {
+      if (lo < hi) oob = (b_d < lo) || (b_d > hi);
+      else oob = (b_d > lo) || (b_d < hi);
+    }
+    const unsigned long long mo = __ballot(oob);
+    const bool group_oob = ((mo >> gb) & 0xFFFFull) != 0ull;
+    __syncthreads();
+    const double dmin = proximity_min<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true,
+                                             g != 0 || group_oob);
+    const bool is_free = !group_oob && !(dmin < 0.0);
+    if (g == 0 && gl < N) io.x_out[uint64_t(e) * N + gl] = b_d;
+    if (lane == 0) {
+      io.steps_free[e] = 1;
+      io.accept[e] = is_free ? 1 : 0;
+    }
+    return;
+  }
   const double dist_tot = norm_n(a_d - b_d);
-  const double fraction = qs.fraction;
+  const double fraction = io.frac ? io.frac[e] : qs.fraction;
   double result = a_d;       // component gl of the returned point
   uint32_t n_checked = 0;
   if (dist_tot == INFINITY) {
@@ -774,6 +795,10 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
     } else if (io.mode == EDGE_CONNECT) {
       // planning_visitor_base::can_be_connected (planning_visitors.hpp:385-395)
       const bool ok = (!isinf(n_ar)) && (n_rb < io.steer_tol * n_ar);  // steer_tol carries the connection tolerance
+      if (lane == 0) io.accept[e] = ok ? 1 : 0;
+    } else if (io.mode == EDGE_WALK_ACCEPT) {
+      // planning_visitor_base::random_walk (planning_visitors.hpp:418-421)
+      const bool ok = (!isinf(n_ar)) && (n_ar > io.steer_tol * io.best_case[e]);
       if (lane == 0) io.accept[e] = ok ? 1 : 0;
     }
   }

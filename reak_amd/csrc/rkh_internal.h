@@ -171,7 +171,14 @@ struct DynDev {  // rkh_dyn_space on the device (passed by value)
   int8_t inner[kMaxSteps];  // runge_kutta4_integrate_impl loop iterations of step k (normally 1)
 };
 
-enum EdgeMode : int { EDGE_PLAIN = 0, EDGE_STEER_ACCEPT = 1, EDGE_GOAL_PROBE = 2, EDGE_CONNECT = 3 };
+enum EdgeMode : int {
+  EDGE_PLAIN = 0,
+  EDGE_STEER_ACCEPT = 1,
+  EDGE_GOAL_PROBE = 2,
+  EDGE_CONNECT = 3,
+  EDGE_WALK_ACCEPT = 4,  // random_walk: traveled > steer_tol * best_case[e] (best_case carries the target distance)
+  EDGE_POINT = 5,        // quasi-static kernel only: accept = is_free(target point), no walk
+};
 
 struct QsDev {  // manip_quasi_static_env on the device (passed by value)
   double min_interval, fraction;
@@ -187,6 +194,7 @@ struct EdgeIO {  // inputs / outputs of one propagate launch (all device pointer
   const uint32_t* d_tgt_off = nullptr; // row offset read on the device
   const uint32_t* tgt_idx = nullptr;   // optional: target row of edge e (quasi-static edge kernel)
   uint32_t tgt_stride = 0;             // 0: one target for all edges
+  const double* frac = nullptr;        // optional per-edge travel fraction (quasi-static kernel; null: QsDev::fraction)
   uint32_t B = 0;
   const uint32_t* d_B = nullptr;
   double* x_out = nullptr;

@@ -38,6 +38,13 @@ class RrtStarStats(C.Structure):
                 ("best_cost", C.c_double)]
 
 
+class PrmStats(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint64), ("num_edges", C.c_uint64), ("samples", C.c_uint64),
+                ("rejected", C.c_uint64), ("loop_iterations", C.c_uint64), ("num_components", C.c_uint64),
+                ("publish_calls", C.c_uint64), ("merged_at_vertex", C.c_int64), ("edges_checked", C.c_uint64),
+                ("device_steps", C.c_uint64)]
+
+
 class PlannerStats(C.Structure):
     _fields_ = [
         ("num_vertices", C.c_uint64),
@@ -59,7 +66,7 @@ EXPORTS = [
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
     "rkh_planner_nn_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
-    "rkh_rrtstar_get_graph",
+    "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph",
 ]
 
 
@@ -119,6 +126,10 @@ def load():
     lib.rkh_rrtstar_destroy.argtypes = [vp]
     lib.rkh_rrtstar_solve.argtypes = [vp, C.c_int64, C.POINTER(RrtStarStats)]
     lib.rkh_rrtstar_get_graph.argtypes = [vp, u32, dp, u32p, dp, u32p]
+    lib.rkh_prm_create_qs_batch.argtypes = [vp, C.POINTER(T.QsSpace), C.POINTER(T.PrmParams), u32, C.POINTER(vp)]
+    lib.rkh_prm_destroy.argtypes = [vp]
+    lib.rkh_prm_solve.argtypes = [vp, C.c_int64, C.POINTER(PrmStats)]
+    lib.rkh_prm_get_graph.argtypes = [vp, u32, dp, u32p, u32p, dp, dp, u32p, C.POINTER(C.c_uint8), u32p]
     lib.rkh_planner_num_problems.restype = u32
     lib.rkh_planner_num_problems.argtypes = [vp]
     lib.rkh_planner_destroy.argtypes = [vp]
@@ -409,6 +420,54 @@ class RrtStarPlanner:
     def close(self):
         if self.h:
             self.lib.rkh_rrtstar_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PrmPlanner:
+    """prm_planner (linear-search k-NN, adjacency-list motion graph) over the quasi-static free space, batch of problems."""
+
+    def __init__(self, scene, prm, qs):
+        self.scene, self.lib, self.qs = scene, scene.lib, qs
+        self.prms = list(prm) if isinstance(prm, (list, tuple)) else [prm]
+        self.P, self.D = len(self.prms), qs.n_dof
+        self._prm_arr = T.as_array(self.prms, T.PrmParams)
+        self.h = C.c_void_p()
+        _check(self.lib.rkh_prm_create_qs_batch(scene.h, C.byref(qs), self._prm_arr, self.P, C.byref(self.h)))
+        self.all_stats = (PrmStats * self.P)()
+
+    @property
+    def stats(self):
+        return self.all_stats[0]
+
+    def solve_planning_query(self, max_loop_iterations=-1):
+        _check(self.lib.rkh_prm_solve(self.h, int(max_loop_iterations), self.all_stats))
+        return self.all_stats[0]
+
+    def graph(self, problem=0):
+        st = self.all_stats[problem]
+        nv, ne, it = int(st.num_vertices), int(st.num_edges), int(st.loop_iterations)
+        pos = np.zeros((nv, self.D))
+        eu = np.zeros(max(ne, 1), dtype=np.uint32)
+        ev = np.zeros(max(ne, 1), dtype=np.uint32)
+        ew = np.zeros(max(ne, 1))
+        dens = np.zeros(nv)
+        cc = np.zeros(nv, dtype=np.uint32)
+        kind = np.zeros(max(it, 1), dtype=np.uint8)
+        exp = np.zeros(max(it, 1), dtype=np.uint32)
+        _check(self.lib.rkh_prm_get_graph(self.h, problem, T.dptr(pos), T.u32ptr(eu), T.u32ptr(ev), T.dptr(ew), T.dptr(dens),
+                                          T.u32ptr(cc), kind.ctypes.data_as(C.POINTER(C.c_uint8)), T.u32ptr(exp)))
+        return {"pos": pos, "edge_u": eu[:ne], "edge_v": ev[:ne], "edge_w": ew[:ne], "density": dens, "cc_root": cc,
+                "kind": kind[:it], "expanded": exp[:it]}
+
+    def close(self):
+        if self.h:
+            self.lib.rkh_prm_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

@@ -48,6 +48,14 @@ class Scenario:
         return p
 
 
+    def prm_params(self, sampling_radius=1.0, expand_probability=0.2, **kw):
+        p = T.PrmParams()
+        p.base = self.rrt_params(**kw)
+        p.sampling_radius = sampling_radius
+        p.expand_probability = expand_probability
+        return p
+
+
 def serial_chain_ops(axes, link_offsets, link_masses, link_inertias, joint_inertias):
     """Flatten a serial revolute chain into kte_map_chain order.  Frame 0 is the base;
     joint j: revolute base=2j, end=2j+1 ; link base=2j+1, end=2j+2 ; inertia_3D on frame 2j+2."""

@@ -77,6 +77,10 @@ class RrtParams(C.Structure):
     ]
 
 
+class PrmParams(C.Structure):
+    _fields_ = [("base", RrtParams), ("sampling_radius", C.c_double), ("expand_probability", C.c_double)]
+
+
 def make_pose(pos=(0.0, 0.0, 0.0), quat=(1.0, 0.0, 0.0, 0.0)):
     p = Pose()
     p.pos[:] = [float(v) for v in pos]

@@ -32,6 +32,13 @@ class RrtStarOut(C.Structure):
                 ("states_checked", C.c_uint64), ("best_cost", C.c_double), ("seconds", C.c_double)]
 
 
+class PrmOut(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint64), ("num_edges", C.c_uint64), ("samples", C.c_uint64),
+                ("rejected", C.c_uint64), ("loop_iterations", C.c_uint64), ("num_components", C.c_uint64),
+                ("publish_calls", C.c_uint64), ("merged_at_vertex", C.c_int64), ("edges_checked", C.c_uint64),
+                ("states_checked", C.c_uint64), ("seconds", C.c_double)]
+
+
 def build():
     subprocess.run(["make", "-s", "-C", _ORACLE_DIR], check=True)
 
@@ -84,6 +91,8 @@ def load(fast=False):
     lib.orc_qs_move.argtypes = [C.c_void_p, C.c_int, dp, dp, d, dp, dp, C.c_int, d, dp, u32p]
     lib.orc_rrtstar_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtStarOut)]
     lib.orc_rrtstar_copy.argtypes = [dp, u32p, dp, u32p]
+    lib.orc_prm_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.PrmParams), C.c_int64, C.POINTER(PrmOut)]
+    lib.orc_prm_copy.argtypes = [dp, u32p, u32p, dp, dp, u32p, C.POINTER(C.c_uint8), u32p]
     lib.orc_rrt_copy.argtypes = [dp, u32p, u32p, C.POINTER(C.c_uint8), dp]
     _libs[name] = lib
     return lib
@@ -172,6 +181,21 @@ class OracleScene:
         near = np.zeros(max(int(out.loop_iterations), 1), dtype=np.uint32)
         self.lib.orc_rrtstar_copy(T.dptr(pos), T.u32ptr(pred), T.dptr(dist), T.u32ptr(near))
         return rc, out, {"pos": pos, "pred": pred, "dist": dist, "near_seq": near[: int(out.loop_iterations)]}
+
+    def prm_qs(self, lower, upper, min_interval, prm, max_loop_iterations=-1):
+        lower = np.ascontiguousarray(lower, dtype=np.float64)
+        upper = np.ascontiguousarray(upper, dtype=np.float64)
+        out = PrmOut()
+        rc = self.lib.orc_prm_qs(self.h, len(lower), T.dptr(lower), T.dptr(upper), float(min_interval), C.byref(prm),
+                                 int(max_loop_iterations), C.byref(out))
+        nv, ne, it, D = int(out.num_vertices), int(out.num_edges), int(out.loop_iterations), len(lower)
+        pos = np.zeros((nv, D)); eu = np.zeros(max(ne, 1), dtype=np.uint32); ev = np.zeros(max(ne, 1), dtype=np.uint32)
+        ew = np.zeros(max(ne, 1)); dens = np.zeros(nv); cc = np.zeros(nv, dtype=np.uint32)
+        kind = np.zeros(max(it, 1), dtype=np.uint8); exp = np.zeros(max(it, 1), dtype=np.uint32)
+        self.lib.orc_prm_copy(T.dptr(pos), T.u32ptr(eu), T.u32ptr(ev), T.dptr(ew), T.dptr(dens), T.u32ptr(cc),
+                              kind.ctypes.data_as(C.POINTER(C.c_uint8)), T.u32ptr(exp))
+        return rc, out, {"pos": pos, "edge_u": eu[:ne], "edge_v": ev[:ne], "edge_w": ew[:ne], "density": dens,
+                         "cc_root": cc, "kind": kind[:it], "expanded": exp[:it]}
 
     def qs_move(self, lower, upper, min_interval, a, b, fraction=1.0):
         lower = np.ascontiguousarray(lower, dtype=np.float64)

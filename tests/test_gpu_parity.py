@@ -326,3 +326,44 @@ def test_rrtstar_batch_of_seeds(L, ctx, oracle):
         rc, rout, rg = osc.rrtstar_qs(lo, hi, mi, prm)
         assert pl.all_stats[i].num_vertices == rout.num_vertices and pl.all_stats[i].rewires == rout.rewires
         assert np.array_equal(pl.graph(i)["pred"], rg["pred"]) and np.array_equal(pl.graph(i)["dist"], rg["dist"])
+
+
+# ------------------------------------------------------------------ PRM (a25)
+def _prm_same(st, g, rout, rg):
+    assert (st.num_vertices, st.num_edges, st.samples, st.rejected, st.loop_iterations, st.num_components,
+            st.publish_calls, st.merged_at_vertex, st.edges_checked) == (
+        rout.num_vertices, rout.num_edges, rout.samples, rout.rejected, rout.loop_iterations, rout.num_components,
+        rout.publish_calls, rout.merged_at_vertex, rout.edges_checked)
+    assert np.array_equal(g["kind"], rg["kind"]) and np.array_equal(g["expanded"], rg["expanded"])
+    assert np.array_equal(g["pos"], rg["pos"])
+    assert np.array_equal(g["edge_u"], rg["edge_u"]) and np.array_equal(g["edge_v"], rg["edge_v"])
+    assert np.array_equal(g["edge_w"], rg["edge_w"])
+    assert np.array_equal(g["density"], rg["density"]) and np.array_equal(g["cc_root"], rg["cc_root"])
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_prm_roadmap_identical_to_sequential_planner(L, ctx, oracle, seed):
+    """PRM (construct / expand with the density heap, random walks, connected components): the roadmap, the order of
+    its edges, the densities and the random-stream consumption equal the sequential planner's."""
+    c1 = scenarios.make_c1(world_seed=1)
+    sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    prm = c1.prm_params(seed=seed, max_vertices=800, sampling_radius=1.0)
+    rc, rout, rg = osc.prm_qs(lo, hi, mi, prm)
+    pl = L.PrmPlanner(sc, prm, L.make_qs_space(3, lo, hi, mi))
+    st = pl.solve_planning_query()
+    assert st.rejected > 50 and (rg["kind"] == 1).sum() > 50  # both branches and the rejection loop were exercised
+    _prm_same(st, pl.graph(), rout, rg)
+
+
+def test_prm_batch_and_resume(L, ctx, oracle):
+    c1 = scenarios.make_c1(world_seed=1)
+    sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    prms = [c1.prm_params(seed=s, max_vertices=250, sampling_radius=0.5 + 0.25 * i) for i, s in enumerate((5, 6, 7))]
+    pl = L.PrmPlanner(sc, prms, L.make_qs_space(3, lo, hi, mi))
+    pl.solve_planning_query(max_loop_iterations=100)   # stop half way, then resume
+    pl.solve_planning_query()
+    for i, prm in enumerate(prms):
+        rc, rout, rg = osc.prm_qs(lo, hi, mi, prm)
+        _prm_same(pl.all_stats[i], pl.graph(i), rout, rg)
