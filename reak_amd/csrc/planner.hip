@@ -245,7 +245,8 @@ struct rkh_planner {
   uint32_t P = 0;
   std::vector<Problem> prob;
   uint32_t b_max = 1024;
-  int lanes_per_edge = 64;  // 64: one wavefront per candidate edge; 16: four candidates per wave
+  int lanes_per_edge = 64;  // 64: one wavefront per candidate edge; 16: four candidates per wave; 1: one lane per edge
+  double* d_lane_ws = nullptr;  // workspace of the one-lane-per-edge kernel
   uint32_t part_blocks = 0;
   uint64_t max_capacity = 0;
   // device tables (P entries each)
@@ -301,7 +302,7 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
                              p->scene->n_pairs, p->qs, EdgeIO(), grid_a, nullptr, grid_b, tab_a, tab_b, p->P);
   return launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
                           p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lanes_per_edge, tab_a, tab_b,
-                          p->P);
+                          p->P, p->d_lane_ws);
 }
 
 // goal probes still pending after the last enqueued round
@@ -419,7 +420,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   if (const char* e = getenv("RKH_BATCH_MAX")) p->b_max = std::max(8, atoi(e));
   p->b_max = std::min<uint32_t>(p->b_max, 4096);
   if (const char* e = getenv("RKH_LANES_PER_EDGE")) {
-    p->lanes_per_edge = (atoi(e) == 16) ? 16 : 64;
+    p->lanes_per_edge = (atoi(e) == 1) ? 1 : ((atoi(e) == 16) ? 16 : 64);
   } else {
     // one wavefront per candidate is the latency-optimal mapping; once a round can offer more waves than the chip
     // has slots (256 CUs x 4 SIMDs x 2 waves) four candidates share a wave
@@ -437,6 +438,8 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   RKH_HIP(hipMalloc(&p->d_nn_args, P * sizeof(NnArgs)));
   RKH_HIP(hipMalloc(&p->d_io_steer, P * sizeof(EdgeIO)));
   RKH_HIP(hipMalloc(&p->d_io_probe, P * sizeof(EdgeIO)));
+  if (!p->quasi_static && p->lanes_per_edge == 1)
+    RKH_HIP(hipMalloc(&p->d_lane_ws, propagate_lanes_workspace_bytes(p->n_dof, p->b_max, p->b_max, P)));
   for (uint32_t i = 0; i < P; ++i) {
     const uint64_t cap = (uint64_t(prms[i].max_vertices) + 1 + 255) / 256 * 256;
     p->max_capacity = std::max(p->max_capacity, cap);
@@ -582,6 +585,7 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   (void)hipFree(p->d_nn_args);
   (void)hipFree(p->d_io_steer);
   (void)hipFree(p->d_io_probe);
+  (void)hipFree(p->d_lane_ws);
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(p->stream);
   delete p;

@@ -895,9 +895,11 @@ static void launch_propagate_t(hipStream_t s, int n_env, const SceneDev* d_scene
 rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                             int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges, const EdgeIO* io_b,
                             uint32_t grid_b, int lanes_per_edge, const EdgeIO* tab_a, const EdgeIO* tab_b,
-                            uint32_t n_problems) {
+                            uint32_t n_problems, double* d_lane_ws) {
   const uint32_t eb = (io_b || tab_b) ? grid_b : 0u;
   if (grid_edges + eb == 0 || n_problems == 0) return RKH_OK;
+  if (lanes_per_edge == 1)  // one lane per edge (propagate_lane.hip)
+    return launch_propagate_lanes(s, n_dof, d_scene, dyn, io, grid_edges, io_b, grid_b, tab_a, tab_b, n_problems, d_lane_ws);
   const EdgeIO second = io_b ? *io_b : EdgeIO();
   const PairDev* pp = static_cast<const PairDev*>(d_pairs);
   if (lanes_per_edge == 16) {

@@ -316,7 +316,12 @@ rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const dou
   io.record = record ? drec.as<double>() : nullptr;
   io.record_stride = rec_stride;
   io.err_flag = scene->d_err;
-  st = launch_propagate(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, dyn, io, B);
+  int lanes = 64;  // RKH_LANES_PER_EDGE = 64 | 16 | 1 selects the kernel mapping (identical results)
+  if (const char* ev = getenv("RKH_LANES_PER_EDGE")) lanes = (atoi(ev) == 1) ? 1 : (atoi(ev) == 16 ? 16 : 64);
+  DevBuf dws;
+  if (lanes == 1) RKH_HIP(hipMalloc(&dws.p, propagate_lanes_workspace_bytes(n, B, 0, 1)));
+  st = launch_propagate(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, dyn, io, B, nullptr, 0,
+                        lanes, nullptr, nullptr, 1, dws.as<double>());
   if (st != RKH_OK) return st;
   RKH_HIP(hipMemcpyAsync(x_out, dxo.p, size_t(B) * D * 8, hipMemcpyDeviceToHost, s));
   RKH_HIP(hipMemcpyAsync(steps_free, dsf.p, size_t(B) * 4, hipMemcpyDeviceToHost, s));

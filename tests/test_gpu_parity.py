@@ -367,3 +367,43 @@ def test_prm_batch_and_resume(L, ctx, oracle):
     for i, prm in enumerate(prms):
         rc, rout, rg = osc.prm_qs(lo, hi, mi, prm)
         _prm_same(pl.all_stats[i], pl.graph(i), rout, rg)
+
+
+# ------------------------------------------------------------------ kernel mappings of the steer kernel
+def test_propagate_mappings_are_bit_identical(L, ctx, oracle, c2, monkeypatch):
+    """One wave per edge, 16 lanes per edge and one lane per edge follow the same operation order: identical bits."""
+    sc, osc = L.Scene(ctx, c2), oracle.OracleScene(c2)
+    rng = np.random.default_rng(21)
+    lo = np.array([c2.dyn.lower[i] for i in range(12)])
+    hi = np.array([c2.dyn.upper[i] for i in range(12)])
+    B = 300
+    a = rng.uniform(lo, hi, size=(B, 12)) * 0.6
+    a[:, 0::2] = rng.uniform(-2.5, 2.5, size=(B, 6))
+    a = a[osc.min_distance(a) > 0.01][:200]   # not a multiple of 64: the last wave is ragged
+    b = rng.uniform(lo, hi, size=(a.shape[0], 12))
+    res = {}
+    for lanes in ("64", "16", "1"):
+        monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
+        res[lanes] = sc.steer_position_toward(a, b, record=True)
+    for lanes in ("16", "1"):
+        assert np.array_equal(res[lanes][1], res["64"][1])
+        assert np.array_equal(res[lanes][0], res["64"][0])
+        assert np.array_equal(res[lanes][2], res["64"][2], equal_nan=True)
+    rc, rout, rsteps, _ = osc.steer(a, b)
+    assert np.array_equal(res["1"][1], rsteps) and np.allclose(res["1"][0], rout, rtol=STATE_RTOL, atol=1e-12)
+    assert res["1"][1].min() < 20 <= res["1"][1].max()
+
+
+def test_rrt_tree_with_one_lane_per_edge(L, ctx, oracle, c2, monkeypatch):
+    monkeypatch.setenv("RKH_LANES_PER_EDGE", "1")
+    sc, osc = L.Scene(ctx, c2), oracle.OracleScene(c2)
+    prm = c2.rrt_params(seed=2, max_vertices=1500)
+    rc, rout, rtree = osc.rrt_dyn(prm)
+    pl = L.RrtPlanner(sc, prm)
+    st = pl.solve_planning_query()
+    tree = pl.tree()
+    assert (st.num_vertices, st.iterations, st.edges_checked) == (rout.num_vertices, rout.iterations, rout.edges_checked)
+    assert np.array_equal(tree["nn_seq"], rtree["nn_seq"]) and np.array_equal(tree["accept"], rtree["accept"])
+    assert np.array_equal(tree["parent"], rtree["parent"])
+    assert np.allclose(tree["pos"], rtree["pos"], rtol=STATE_RTOL, atol=1e-12)
+    assert np.array_equal(np.isinf(tree["goal_dist"]), np.isinf(rtree["goal_dist"]))
