@@ -150,6 +150,152 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_kernel(NnArgs single, cons
   }
 }
 
+// The same sweep with a single-precision pre-filter, for the compute-bound regime (many queries per sweep, as in the
+// planner's speculative rounds).  Per (row, query) the exact test costs 3*Dp-1 fp64 VALU operations; here a packed fp32
+// estimate of the squared distance (Dp/2 v_pk_add_f32 + Dp/2 v_pk_fma_f32 on a float copy of the tile) rejects every
+// row that provably cannot tie or beat the thread's running best, and only the survivors -- a handful per thread -- are
+// evaluated with the exact fp64 sequence above, so the result is bit-identical.
+// Error bound of the estimate (u = 2^-24, M = coord_bound >= every |coordinate|): each float difference is off by at
+// most u (2M + 2|d|), hence |s32 - s| <= 4 u M sqrt(Dp s) + (4 + Dp) u s.  A row is skipped only if
+//   s32 > best_thr (1 + 2 (4 + Dp) u) + 8 u M sqrt(Dp) best_d   (rounded up to float)
+// which implies s > best_thr, i.e. the row could not have changed (best_d, best_i).
+typedef float rkh_f2 __attribute__((ext_vector_type(2)));
+
+template <int DP, int QB>
+__global__ __launch_bounds__(kThreads) void nn1_sweep_f32_kernel(NnArgs single, const NnArgs* __restrict__ table, int D,
+                                                                  uint32_t Bpad, double coord_bound) {
+  constexpr int R = kThreads / QB;
+  constexpr int ROWS_PER_THREAD = kTileRows / R;
+  constexpr int H = DP / 2;
+  __shared__ __attribute__((aligned(16))) double tile[kTileRows * DP];
+  __shared__ __attribute__((aligned(16))) rkh_f2 tile32[kTileRows * H];
+  __shared__ double red_d[kThreads];
+  __shared__ uint32_t red_i[kThreads];
+
+  const NnArgs a = table ? table[blockIdx.z] : single;
+  const double* __restrict__ pos = a.pos;
+  const double* __restrict__ q = a.q;
+  const uint32_t* __restrict__ d_qoff = a.d_qoff;
+  double* __restrict__ part_dist = a.part_dist;
+  uint32_t* __restrict__ part_idx = a.part_idx;
+  const uint64_t n = a.d_n ? uint64_t(*a.d_n) : a.n;
+  const uint32_t B = a.d_B ? *a.d_B : a.B;
+  const int tid = threadIdx.x;
+  const int ql = tid % QB;
+  const int r = tid / QB;
+  const uint32_t qi = blockIdx.y * QB + ql;
+  if (blockIdx.y * QB >= B) return;
+
+  double qv[DP];
+  rkh_f2 q2[H];
+  {
+    const uint64_t qsrc = uint64_t(qi < B ? qi : (B - 1)) + (d_qoff ? uint64_t(*d_qoff) : 0ull);
+#pragma unroll
+    for (int d = 0; d < DP; ++d) qv[d] = d < D ? q[qsrc * D + d] : 0.0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) q2[j] = rkh_f2{float(qv[2 * j]), float(qv[2 * j + 1])};
+  }
+  const double u32 = 5.9604644775390625e-08;  // 2^-24
+  const double slack_rel = 1.0 + 2.0 * double(4 + DP) * u32;
+  const double slack_abs = 8.0 * u32 * coord_bound * sqrt(double(DP));
+
+  const uint64_t tiles_total = (n + kTileRows - 1) / kTileRows;
+  const uint64_t tiles_per_block = (tiles_total + gridDim.x - 1) / gridDim.x;
+  const uint64_t tile0 = uint64_t(blockIdx.x) * tiles_per_block;
+  uint64_t tile1 = tile0 + tiles_per_block;
+  if (tile1 > tiles_total) tile1 = tiles_total;
+
+  double best_d = INFINITY;
+  double best_thr = INFINITY;
+  float filt = INFINITY;       // skip rows whose float estimate exceeds this
+  uint32_t best_i = 0xFFFFFFFFu;
+
+  constexpr int N2 = kTileRows * DP / 2;
+  constexpr int PF = N2 / kThreads;
+  static_assert(N2 % kThreads == 0, "tile must split evenly");
+  double2 pf[PF];
+  auto fetch = [&](uint64_t t) {
+    const uint64_t row_base = t * kTileRows;
+    const double2* src = reinterpret_cast<const double2*>(pos + row_base * DP);
+    const uint64_t valid2 = (n - row_base >= uint64_t(kTileRows)) ? uint64_t(N2) : (n - row_base) * DP / 2;
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int i = tid + j * kThreads;
+      pf[j] = (uint64_t(i) < valid2) ? src[i] : make_double2(INFINITY, INFINITY);
+    }
+  };
+  if (tile0 < tile1) fetch(tile0);
+  for (uint64_t t = tile0; t < tile1; ++t) {
+    const uint64_t row_base = t * kTileRows;
+    {
+      double2* dst = reinterpret_cast<double2*>(tile);
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        dst[tid + j * kThreads] = pf[j];
+        tile32[tid + j * kThreads] = rkh_f2{float(pf[j].x), float(pf[j].y)};  // the double2 index is the float2 index
+      }
+    }
+    if (t + 1 < tile1) fetch(t + 1);
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < ROWS_PER_THREAD; ++k) {
+      const int row = k * R + r;
+      const rkh_f2* p2 = tile32 + row * H;
+      rkh_f2 acc = rkh_f2{0.0f, 0.0f};
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const rkh_f2 df = q2[j] - p2[j];
+        acc = __builtin_elementwise_fma(df, df, acc);
+      }
+      const float s32 = acc.x + acc.y;
+      if (!(s32 > filt)) {  // survivors only: the exact fp64 sequence of nn1_sweep_kernel
+        const double* p = tile + row * DP;
+        double s;
+        {
+          double df = qv[0] - p[0];
+          s = df * df;
+        }
+#pragma unroll
+        for (int d = 1; d < DP; ++d) {
+          double df = qv[d] - p[d];
+          s = s + df * df;
+        }
+        if (s <= best_thr) {
+          const double dd = sqrt(s);
+          if (dd < best_d) {
+            best_d = dd;
+            best_i = uint32_t(row_base + row);
+            best_thr = s * (1.0 + 4.0 * DBL_EPSILON);
+            filt = __double2float_ru(best_thr * slack_rel + slack_abs * best_d);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  red_d[tid] = best_d;
+  red_i[tid] = best_i;
+  __syncthreads();
+  if (tid < QB) {
+    double bd = red_d[tid];
+    uint32_t bi = red_i[tid];
+#pragma unroll
+    for (int rr = 1; rr < R; ++rr) {
+      const double od = red_d[rr * QB + tid];
+      const uint32_t oi = red_i[rr * QB + tid];
+      if (lex_less(od, oi, bd, bi)) {
+        bd = od;
+        bi = oi;
+      }
+    }
+    if (qi < B) {
+      part_dist[uint64_t(blockIdx.x) * Bpad + qi] = bd;
+      part_idx[uint64_t(blockIdx.x) * Bpad + qi] = bi;
+    }
+  }
+}
+
 // one wave per query: lanes stride over the per-block partials, then a shuffle reduction
 __global__ __launch_bounds__(256) void nn1_reduce_kernel(NnArgs single, const NnArgs* __restrict__ table,
                                                           uint32_t nblocks, uint32_t Bpad) {
@@ -223,7 +369,7 @@ const char* nn_last_kernel_name() { return g_last_kernel; }
 template <int DP>
 static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
                                 uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0,
-                                hipEvent_t ev1) {
+                                hipEvent_t ev1, double coord_bound) {
   const uint32_t qb = pick_qb(B);
   const uint32_t gy = (B + qb - 1) / qb;
   uint32_t gx = pick_gx(n_upper, gy * n_problems);
@@ -231,15 +377,20 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
   const uint32_t Bpad = B;
   dim3 grid(gx, gy, n_problems), block(kThreads);
 #define RKH_NN1_LAUNCH(QB) hipLaunchKernelGGL((nn1_sweep_kernel<DP, QB>), grid, block, 0, s, single, d_table, D, Bpad)
+#define RKH_NN1_LAUNCH_F32(QB) \
+  hipLaunchKernelGGL((nn1_sweep_f32_kernel<DP, QB>), grid, block, 0, s, single, d_table, D, Bpad, coord_bound)
   if (ev0) (void)hipEventRecord(ev0, s);
+  const bool f32 = coord_bound > 0.0 && qb >= 32;  // compute-bound regime with known coordinate bounds
+  g_last_kernel = f32 ? "nn1_sweep_f32_kernel" : "nn1_sweep_kernel";
   switch (qb) {
     case 8: RKH_NN1_LAUNCH(8); break;
     case 16: RKH_NN1_LAUNCH(16); break;
-    case 32: RKH_NN1_LAUNCH(32); break;
-    case 128: RKH_NN1_LAUNCH(128); break;
-    default: RKH_NN1_LAUNCH(256); break;
+    case 32: if (f32) RKH_NN1_LAUNCH_F32(32); else RKH_NN1_LAUNCH(32); break;
+    case 128: if (f32) RKH_NN1_LAUNCH_F32(128); else RKH_NN1_LAUNCH(128); break;
+    default: if (f32) RKH_NN1_LAUNCH_F32(256); else RKH_NN1_LAUNCH(256); break;
   }
 #undef RKH_NN1_LAUNCH
+#undef RKH_NN1_LAUNCH_F32
   if (ev1) (void)hipEventRecord(ev1, s);
   hipLaunchKernelGGL(nn1_reduce_kernel, dim3((B + 3) / 4, n_problems), dim3(256), 0, s, single, d_table, gx, Bpad);
   RKH_HIP(hipGetLastError());
@@ -249,12 +400,12 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
 // 1-NN of up to B queries per problem.  single: one problem given by value; d_table: n_problems NnArgs in HBM.
 // n_upper (host bound on the vertex count) and B (host bound on the query count) only size the grid.
 rkh_status launch_nn1(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
-                      uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0, hipEvent_t ev1) {
+                      uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0, hipEvent_t ev1,
+                      double coord_bound) {
   if (B == 0 || n_problems == 0) return RKH_OK;
-  g_last_kernel = "nn1_sweep_kernel";
   switch (padded_dims(D)) {
 #define RKH_CASE(DP) \
-  case DP: return launch_nn1_dp<DP>(s, D, single, d_table, n_problems, n_upper, B, part_capacity_blocks, ev0, ev1)
+  case DP: return launch_nn1_dp<DP>(s, D, single, d_table, n_problems, n_upper, B, part_capacity_blocks, ev0, ev1, coord_bound)
     RKH_CASE(2);
     RKH_CASE(4);
     RKH_CASE(6);

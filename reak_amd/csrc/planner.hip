@@ -67,10 +67,15 @@ struct ProblemDev {  // device pointers of one problem
   uint32_t* round_n;  // profiling: vertex count at the start of each round (may be null)
 };
 
-__global__ void round_begin_kernel(const ProblemDev* __restrict__ probs, uint32_t round_slot) {
+// sel: {edge counter of even rounds, of odd rounds}.  Every problem adds its candidates + pending goal probes to the
+// counter of this round's parity and block 0 clears the other one for the next round; the two steer kernels of the
+// round compare the sum with their threshold (see launch_edges).
+__global__ void round_begin_kernel(const ProblemDev* __restrict__ probs, uint32_t round_slot, uint32_t* __restrict__ sel,
+                                   uint32_t parity) {
   if (threadIdx.x != 0) return;
   const ProblemDev pr = probs[blockIdx.x];
   PlannerState* st = pr.st;
+  if (blockIdx.x == 0) sel[parity ^ 1u] = 0u;
   if (pr.round_n) pr.round_n[round_slot] = st->done ? 0u : st->n;
   uint32_t B = 0;
   if (!st->done) {
@@ -88,6 +93,7 @@ __global__ void round_begin_kernel(const ProblemDev* __restrict__ probs, uint32_
     st->rounds += 1;
     st->edges_speculated += B;
   }
+  atomicAdd(&sel[parity], B + st->n_new);
 }
 
 // One wave per candidate b: smallest squared distance from sample b to the end states of accepted
@@ -246,7 +252,11 @@ struct rkh_planner {
   std::vector<Problem> prob;
   uint32_t b_max = 1024;
   int lanes_per_edge = 64;  // 64: one wavefront per candidate edge; 16: four candidates per wave; 1: one lane per edge
-  double* d_lane_ws = nullptr;  // workspace of the one-lane-per-edge kernel
+  double* d_lane_ws = nullptr;  // workspace of the two-lanes-per-edge kernel
+  double coord_bound = 0.0;     // max |coordinate| of vertices and samples (hyperbox bounds), 0 = unknown
+  uint32_t* d_sel = nullptr;    // [2] edges of the current round (by round parity), see round_begin_kernel
+  uint32_t round_parity = 0;
+  uint32_t lane_threshold = 4500;  // rounds with at least this many edges go to the two-lanes-per-edge kernel
   uint32_t part_blocks = 0;
   uint64_t max_capacity = 0;
   // device tables (P entries each)
@@ -300,9 +310,21 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
   if (p->quasi_static)
     return launch_edge_check(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
                              p->scene->n_pairs, p->qs, EdgeIO(), grid_a, nullptr, grid_b, tab_a, tab_b, p->P);
+  if (p->lanes_per_edge != 0)
+    return launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
+                            p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lanes_per_edge, tab_a, tab_b,
+                            p->P, p->d_lane_ws);
+  // automatic: both mappings are launched; on the device each compares the round's edge count with the threshold and
+  // the one that is not chosen exits at once.  Small rounds -> one wave per edge (latency), large -> 28 edges per wave.
+  KernelGate gate_wave{p->d_sel + p->round_parity, 0u, p->lane_threshold};
+  KernelGate gate_lane{p->d_sel + p->round_parity, p->lane_threshold, 0xFFFFFFFFu};
+  rkh_status st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
+                                   p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, 64, tab_a, tab_b, p->P,
+                                   nullptr, gate_wave);
+  if (st != RKH_OK) return st;
   return launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                          p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lanes_per_edge, tab_a, tab_b,
-                          p->P, p->d_lane_ws);
+                          p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, 1, tab_a, tab_b, p->P,
+                          p->d_lane_ws, gate_lane);
 }
 
 // goal probes still pending after the last enqueued round
@@ -330,9 +352,11 @@ rkh_status enqueue_round(rkh_planner* p) {
     ev0 = p->ev[2 * slot];
     ev1 = p->ev[2 * slot + 1];
   }
-  hipLaunchKernelGGL(round_begin_kernel, dim3(p->P), dim3(64), 0, s, p->d_probs, slot);
+  p->round_parity ^= 1u;
+  hipLaunchKernelGGL(round_begin_kernel, dim3(p->P), dim3(64), 0, s, p->d_probs, slot, p->d_sel, p->round_parity);
   // 1. NN sweep of every problem's samples over its snapshot
-  rkh_status st = launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, p->b_max, p->part_blocks, ev0, ev1);
+  rkh_status st = launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, p->b_max, p->part_blocks, ev0, ev1,
+                             p->coord_bound);
   if (st != RKH_OK) return st;
   // 2. speculative steer of all candidates + the goal probes of the vertices the previous round committed
   st = launch_edges(p, p->b_max, p->b_max, p->d_io_steer, p->d_io_probe);
@@ -415,12 +439,22 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     }
   }
   p->DP = nn_padded_dims(p->D);
+  // vertices and samples lie inside the hyperbox (is_free / random_point): bound for the NN sweep's float pre-filter
+  if (!getenv("RKH_NN_F64_ONLY"))
+    for (int d = 0; d < p->D; ++d) {
+      p->coord_bound = std::max(p->coord_bound, std::max(std::fabs(p->lower[d]), std::fabs(p->upper[d])));
+      for (uint32_t i = 0; i < n_problems; ++i)  // the root is a vertex too
+        p->coord_bound = std::max(p->coord_bound, std::fabs(prms[i].start[d]));
+    }
   RKH_HIP(hipSetDevice(scene->ctx->device));
   RKH_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   if (const char* e = getenv("RKH_BATCH_MAX")) p->b_max = std::max(8, atoi(e));
   p->b_max = std::min<uint32_t>(p->b_max, 4096);
+  if (const char* e = getenv("RKH_LANE_THRESHOLD")) p->lane_threshold = uint32_t(std::max(0, atoi(e)));
   if (const char* e = getenv("RKH_LANES_PER_EDGE")) {
-    p->lanes_per_edge = (atoi(e) == 1) ? 1 : ((atoi(e) == 16) ? 16 : 64);
+    p->lanes_per_edge = (atoi(e) == 1) ? 1 : ((atoi(e) == 16) ? 16 : (atoi(e) == 0 ? 0 : 64));
+  } else if (p->n_dof == 6 || p->n_dof == 3 || p->n_dof == 2 || p->n_dof == 1) {
+    p->lanes_per_edge = 0;  // automatic, per round
   } else {
     // one wavefront per candidate is the latency-optimal mapping; once a round can offer more waves than the chip
     // has slots (256 CUs x 4 SIMDs x 2 waves) four candidates share a wave
@@ -438,8 +472,10 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   RKH_HIP(hipMalloc(&p->d_nn_args, P * sizeof(NnArgs)));
   RKH_HIP(hipMalloc(&p->d_io_steer, P * sizeof(EdgeIO)));
   RKH_HIP(hipMalloc(&p->d_io_probe, P * sizeof(EdgeIO)));
-  if (!p->quasi_static && p->lanes_per_edge == 1)
+  if (!p->quasi_static && (p->lanes_per_edge == 1 || p->lanes_per_edge == 0))
     RKH_HIP(hipMalloc(&p->d_lane_ws, propagate_lanes_workspace_bytes(p->n_dof, p->b_max, p->b_max, P)));
+  RKH_HIP(hipMalloc(&p->d_sel, 2 * sizeof(uint32_t)));
+  RKH_HIP(hipMemset(p->d_sel, 0, 2 * sizeof(uint32_t)));
   for (uint32_t i = 0; i < P; ++i) {
     const uint64_t cap = (uint64_t(prms[i].max_vertices) + 1 + 255) / 256 * 256;
     p->max_capacity = std::max(p->max_capacity, cap);
@@ -586,6 +622,7 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   (void)hipFree(p->d_io_steer);
   (void)hipFree(p->d_io_probe);
   (void)hipFree(p->d_lane_ws);
+  (void)hipFree(p->d_sel);
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(p->stream);
   delete p;

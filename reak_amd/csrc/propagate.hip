@@ -490,8 +490,13 @@ template <int N, int GL>
 __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __restrict__ sc,
                                                            const PairDev* __restrict__ pairs, int n_pairs, DynDev dyn,
                                                            EdgeIO io_a, EdgeIO io_b, const EdgeIO* __restrict__ tab_a,
-                                                           const EdgeIO* __restrict__ tab_b, uint32_t grid_a) {
+                                                           const EdgeIO* __restrict__ tab_b, uint32_t grid_a,
+                                                           KernelGate gate) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (gate.count) {  // the planner's per-round choice between the kernel mappings
+    const uint32_t c = *gate.count;
+    if (c < gate.lo || c >= gate.hi) return;
+  }
   constexpr int G = 64 / GL;
   BlockLds<N, GL>& lds = *reinterpret_cast<BlockLds<N, GL>*>(smem_raw);
   ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayout<N, GL>::block_bytes);
@@ -883,11 +888,12 @@ __global__ __launch_bounds__(64) void min_distance_kernel(const SceneDev* __rest
 template <int N, int GL>
 static void launch_propagate_t(hipStream_t s, int n_env, const SceneDev* d_scene, const PairDev* d_pairs, int n_pairs,
                                const DynDev& dyn, const EdgeIO& io, uint32_t edges_a, const EdgeIO& io_b,
-                               uint32_t edges_b, const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems) {
+                               uint32_t edges_b, const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems,
+                               KernelGate gate) {
   constexpr uint32_t G = 64 / GL;
   const uint32_t ga = (edges_a + G - 1) / G, gbk = (edges_b + G - 1) / G;
   hipLaunchKernelGGL((propagate_kernel<N, GL>), dim3(ga + gbk, n_problems), dim3(64), (SmemLayout<N, GL>::bytes(n_env)),
-                     s, d_scene, d_pairs, n_pairs, dyn, io, io_b, tab_a, tab_b, ga);
+                     s, d_scene, d_pairs, n_pairs, dyn, io, io_b, tab_a, tab_b, ga, gate);
 }
 
 // Steer `grid_edges` (+ `grid_b` of a second group) edges per problem.  Either the two EdgeIO are given by value
@@ -895,19 +901,20 @@ static void launch_propagate_t(hipStream_t s, int n_env, const SceneDev* d_scene
 rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                             int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges, const EdgeIO* io_b,
                             uint32_t grid_b, int lanes_per_edge, const EdgeIO* tab_a, const EdgeIO* tab_b,
-                            uint32_t n_problems, double* d_lane_ws) {
+                            uint32_t n_problems, double* d_lane_ws, KernelGate gate) {
   const uint32_t eb = (io_b || tab_b) ? grid_b : 0u;
   if (grid_edges + eb == 0 || n_problems == 0) return RKH_OK;
   if (lanes_per_edge == 1)  // one lane per edge (propagate_lane.hip)
-    return launch_propagate_lanes(s, n_dof, d_scene, dyn, io, grid_edges, io_b, grid_b, tab_a, tab_b, n_problems, d_lane_ws);
+    return launch_propagate_lanes(s, n_dof, d_scene, dyn, io, grid_edges, io_b, grid_b, tab_a, tab_b, n_problems, d_lane_ws,
+                                  gate);
   const EdgeIO second = io_b ? *io_b : EdgeIO();
   const PairDev* pp = static_cast<const PairDev*>(d_pairs);
   if (lanes_per_edge == 16) {
     RKH_DISPATCH_N(n_dof, (launch_propagate_t<N, 16>(s, n_env, d_scene, pp, n_pairs, dyn, io, grid_edges, second, eb, tab_a,
-                                                     tab_b, n_problems)));
+                                                     tab_b, n_problems, gate)));
   } else {
     RKH_DISPATCH_N(n_dof, (launch_propagate_t<N, 64>(s, n_env, d_scene, pp, n_pairs, dyn, io, grid_edges, second, eb, tab_a,
-                                                     tab_b, n_problems)));
+                                                     tab_b, n_problems, gate)));
   }
   RKH_HIP(hipGetLastError());
   return RKH_OK;

@@ -1,24 +1,27 @@
-// propagate_lane.hip -- the throughput mapping of the steer kernel: ONE LANE PER CANDIDATE EDGE (gfx950, wave64).
+// propagate_lane.hip -- the throughput mapping of the steer kernel: TWO LANES PER CANDIDATE EDGE, 28 edges per wave
+// (gfx950, wave64).
 //
 // Same function as propagate_kernel (propagate.hip; reference citations there): RK4 forward dynamics of the KTE
 // serial chain under the held PD input, proximity test after every step, accept test / goal probe at the end.
 // propagate_kernel gives a whole wavefront to one edge (lowest latency, but its serial base->tip / tip->base sweeps
-// run redundantly on all 64 lanes); here every lane integrates its own edge with plain serial code, so no lane
-// repeats another's work and nothing crosses lanes.  The planner uses it when a round offers enough candidate edges
-// to fill the chip at 64 edges per wave.
+// run redundantly on all 64 lanes).  Here lane (el, h) = (lane & 31, lane >> 5) works on edge el of the wave: the two
+// halves h run the serial sweeps together and split what is independent (odd / even Jacobian columns, odd / even
+// rows of the mass matrix, half / full angle sin-cos, odd / even robot shapes of the proximity test).
 //
-// What shapes the kernel is storage and code size, not arithmetic:
-//   * VALU instructions address 256 architectural VGPRs = 128 doubles per lane; an unrolled f-eval of a 6-joint chain
-//     wants ~200 live doubles and ~270 KB of code (measured: 33 k instructions, 4x the 64 KB instruction cache, and it
-//     ran no faster than the wave-per-edge kernel).  So every loop over joints / Jacobian columns / matrix entries is
-//     ROLLED (one copy of each body in the instruction stream, ~25 KB in total, one copy of sincos) and the per-lane
-//     arrays they index at run time live in memory laid out [slot][lane] (conflict-free, coalesced):
-//       LDS    (78 slots x 512 B = 39 KB per wave = the CU's 160 KB at one wave per SIMD): the current body's Jacobian
-//              columns T[6N] and the mass matrix Mf[N*N] (read-modify-written once per body), the held input u[N];
-//       global workspace (29N slots per wave, L2 resident): state / target / RK4 stage vectors, sin/cos table, joint end
-//              frames (written once, read by later bodies' Jacobian columns, loads issued one column ahead) and the
-//              d'Alembert forces of the links (written by the base->tip sweep, read by the tip->base sweep);
-//       registers: the sweep recurrences and the Cholesky factor only.
+// What shapes the kernel is storage and code size, not arithmetic.  Three one-lane-per-edge versions were measured
+// first (C2, 6 joints): fully unrolled with the working set in registers = 33 k instructions (270 KB, 4x the
+// instruction cache) -> no faster than the wave-per-edge kernel; inner loops rolled with register arrays -> 400..1400
+// spilled registers (VALU instructions address only the 256 architectural VGPRs = 128 doubles per lane); everything
+// rolled with the run-time-indexed arrays in a global workspace -> 250 dependent L2 round trips per f-eval with one
+// wave per SIMD to hide them, again no gain.  Hence:
+//   * every loop over joints / Jacobian columns / matrix entries is ROLLED (one copy of each body and one copy of
+//     sincos in the instruction stream, ~25 KB in total);
+//   * every array those loops index at run time lives in LDS, [slot][edge]: joint end frames E[7N], the current body's
+//     Jacobian columns T[6N], the mass matrix Mf[N*N] (read-modify-written once per body), link forces FT[6N], the
+//     state being differentiated XE[2N], full-angle cos/sin[2N], the held input u[N]: 180 slots x 28 edges x 8 B =
+//     40 320 B per wave = the CU's 160 KB at one wave per SIMD (that is what fixes 28 edges, two lanes each);
+//   * registers hold the sweep recurrences and the Cholesky factor only; the RK4 stage vectors, touched once per
+//     f-eval with independent loads, are in a global workspace [slot][lane];
 //   * the mass matrix is accumulated body by body while the forward sweep runs (Mf(i,j) receives its terms in the same
 //     ascending-body order as the reference's Tcm^T (Mcm Tcm) product), so the 6N x N Jacobian is never stored;
 //   * chain parameters are wave-uniform: scalar loads with a uniform run-time index, SGPR operands;
@@ -44,6 +47,12 @@ RKH_DI d3 ldg3(const double* p) { return d3{p[0], p[1], p[2]}; }
 RKH_DI d4 ldg4(const double* p) { return d4{p[0], p[1], p[2], p[3]}; }
 RKH_DI m33 ldgm(const double* p) { return m33{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]}; }
 
+RKH_DI double readlane_d(double v, int src_lane) {  // wave-uniform copy of lane src_lane's value
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
 RKH_DI m33 lane_axis_angle_rotmat(double ca, double sa, d3 ax) {  // axis_angle::getRotMat (rotations_3D.hpp:2160-2180)
   const double omc = 1.0 - ca;
   const double t11 = ca + omc * ax.x * ax.x, t22 = ca + omc * ax.y * ax.y, t33 = ca + omc * ax.z * ax.z;
@@ -52,52 +61,62 @@ RKH_DI m33 lane_axis_angle_rotmat(double ca, double sa, d3 ax) {  // axis_angle:
   return m33{t11, t12 - t03, t13 + t02, t12 + t03, t22, t23 - t01, t13 - t02, t23 + t01, t33};
 }
 
-// per-lane arrays in LDS, [slot][lane]
+constexpr int kEdgesPerWave = 28;  // 180 LDS slots x 28 edges x 8 B = 40 320 B: four waves per CU, one per SIMD
+
+// per-edge arrays in LDS, [slot][edge]
+template <int N>
+struct LdsLayout {
+  enum : int {
+    ECP = 0,            // joint end frames: position
+    ECQ = 3 * N,        //                   quaternion
+    T = 7 * N,          // Jacobian columns (v, w) of the current body; afterwards the generalized forces f[N]
+    MF = 13 * N,        // Tcm^T (Mcm Tcm) before symmetrisation
+    FT = 13 * N + N * N,  // inertia_3D d'Alembert force / torque per link
+    XE = 19 * N + N * N,  // state being differentiated / tested
+    C1S1 = 21 * N + N * N,  // cos, sin of the full joint angles
+    U = 23 * N + N * N,     // held input
+    SLOTS = 24 * N + N * N
+  };
+};
 template <int N>
 struct LaneLds {
-  double T[N * 6][64];   // Jacobian columns (v, w) of the current body; afterwards the generalized forces f[N]
-  double Mf[N * N][64];  // Tcm^T (Mcm Tcm) before symmetrisation
-  double u[N][64];       // held input
+  double v[LdsLayout<N>::SLOTS][kEdgesPerWave];
 };
+#define RKH_LD(slot) lds.v[(slot)][el]
 
 // global workspace of one wave, [slot][lane]; `ws` below already points at the lane's column
 template <int N>
 struct WsLayout {
   enum : int {
-    X = 0,            // last free state
-    B = 2 * N,        // steer target
-    W = 4 * N,        // RK4: state at the start of the inner step
-    KA = 6 * N,       // RK4: k1, then (1/6) k1 + (2/6) k2
-    K3 = 8 * N,       // RK4: k3
-    XE = 10 * N,      // state being differentiated / tested
-    TRIG = 12 * N,    // per joint: cos, sin of the half angle, cos, sin of the full angle
-    ECP = 16 * N,     // joint end frames: position
-    ECQ = 19 * N,     //                   quaternion
-    FT = 23 * N,      // inertia_3D d'Alembert force / torque per link
-    SLOTS = 29 * N
+    X = 0,        // last free state
+    B = 2 * N,    // steer target
+    W = 4 * N,    // RK4: state at the start of the inner step
+    KA = 6 * N,   // RK4: k1, then (1/6) k1 + (2/6) k2
+    K3 = 8 * N,   // RK4: k3
+    SLOTS = 10 * N
   };
 };
 #define RKH_WS(slot) ws[(slot) * 64]
 
-// x' = f(x, u) of one edge.  In: the state in WS(XE..), the input in lds.u.  Out: qdd[j] (the q components of x' are
-// the qd components of x).
-template <int N>
-__device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict__ sc, LaneLds<N>& lds, int lane,
-                                                      double* __restrict__ ws, double (&qdd)[N], bool& singular) {
-  typedef WsLayout<N> L_;
-  // ---- sin/cos of the half and full joint angles (one copy of sincos in the instruction stream)
-#pragma unroll 1
-  for (int t = 0; t < 2 * N; ++t) {
-    const double q = RKH_WS(L_::XE + 2 * (t >> 1));
-    double sn, cs;
-    sincos((t & 1) ? q : 0.5 * q, &sn, &cs);
-    RKH_WS(L_::TRIG + 2 * t) = cs;
-    RKH_WS(L_::TRIG + 2 * t + 1) = sn;
+// x' = f(x, u) of one edge.  In: the state in LD(XE..), the input in LD(U..).  Out: qdd[j] (the q components of x'
+// are the qd components of x).  el = the edge's LDS column, h = which of the edge's two lanes this is.
+template <int N, bool DIAG = false>
+__device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict__ sc, LaneLds<N>& lds, int el, int h,
+                                                      double (&qdd)[N], bool& singular,
+                                                      unsigned long long* stamps = nullptr) {
+  typedef LdsLayout<N> L_;
+  // diagnostic instantiation only (rkh_diag_feval_cycles): per-phase cycle counts
+  unsigned long long t_prev = DIAG ? __builtin_readcyclecounter() : 0ull;
+#define RKH_STAMP(i)                                                \
+  if (DIAG) {                                                       \
+    const unsigned long long t_now = __builtin_readcyclecounter(); \
+    stamps[i] += t_now - t_prev;                                    \
+    t_prev = t_now;                                                 \
   }
 #pragma unroll 1
-  for (int e = 0; e < N * N; ++e) {
+  for (int e = h; e < N * N; e += 2) {
     const int i = e / N, jx = e - i * N;
-    lds.Mf[e][lane] = (i == jx) ? (0.0 + sc->joints[i].joint_inertia) : 0.0;  // inertia_gen rows: Tcm = 1
+    RKH_LD(L_::MF + e) = (i == jx) ? (0.0 + sc->joints[i].joint_inertia) : 0.0;  // inertia_gen rows: Tcm = 1
   }
 
   // ---- base -> tip sweep (kte_map_chain::doMotion) with the Jacobian columns and M terms of each body
@@ -109,8 +128,15 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
   for (int j = 0; j < N; ++j) {
     const JointDev& J = sc->joints[j];
     const d3 axis = ldg3(J.axis), axis_n = ldg3(J.axis_n);
-    const double c2 = RKH_WS(L_::TRIG + 4 * j), s2 = RKH_WS(L_::TRIG + 4 * j + 1);
-    const double qd = RKH_WS(L_::XE + 2 * j + 1);
+    const double q = RKH_LD(L_::XE + 2 * j), qd = RKH_LD(L_::XE + 2 * j + 1);
+    // one sincos per lane: half angle on lane h = 0, full angle on lane h = 1 (kept for the tip->base sweep)
+    double sn, cs;
+    sincos(h ? q : 0.5 * q, &sn, &cs);
+    const double c2 = __shfl(cs, el, 64), s2 = __shfl(sn, el, 64);
+    if (h) {
+      RKH_LD(L_::C1S1 + 2 * j) = cs;
+      RKH_LD(L_::C1S1 + 2 * j + 1) = sn;
+    }
     // revolute_joint_3D::doMotion (revolute_joint.cpp:121-148)
     const d4 tq = d4{c2, axis_n.x * s2, axis_n.y * s2, axis_n.z * s2};
     const m33 R2 = rotmat(tq);
@@ -119,10 +145,11 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
     const d3 qa = qd * axis;
     const d3 Ew = wb + qa;
     const d3 Ealpha = mulT(alpha, R2) + cross(wb, qa);
-    const d3 Epos = pos;
-    RKH_WS(L_::ECP + 3 * j) = pos.x; RKH_WS(L_::ECP + 3 * j + 1) = pos.y; RKH_WS(L_::ECP + 3 * j + 2) = pos.z;
-    RKH_WS(L_::ECQ + 4 * j) = EQ.w; RKH_WS(L_::ECQ + 4 * j + 1) = EQ.x;
-    RKH_WS(L_::ECQ + 4 * j + 2) = EQ.y; RKH_WS(L_::ECQ + 4 * j + 3) = EQ.z;
+    if (!h) {
+      RKH_LD(L_::ECP + 3 * j) = pos.x; RKH_LD(L_::ECP + 3 * j + 1) = pos.y; RKH_LD(L_::ECP + 3 * j + 2) = pos.z;
+      RKH_LD(L_::ECQ + 4 * j) = EQ.w; RKH_LD(L_::ECQ + 4 * j + 1) = EQ.x;
+      RKH_LD(L_::ECQ + 4 * j + 2) = EQ.y; RKH_LD(L_::ECQ + 4 * j + 3) = EQ.z;
+    }
     // rigid_link_3D::doMotion = frame * pose (frame_3D.hpp:240-255)
     const d3 op = ldg3(J.off_pos);
     const m33 R = rotmat(EQ);
@@ -135,55 +162,73 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
     // inertia_3D::doForce terms (inertia.cpp:111-122), applied in the backward sweep
     const d3 Fi = J.mass * qrot(qinv(Q), acc);
     const d3 Ti = sym_mul(J.inertia, alpha) + cross(w, sym_mul(J.inertia, w));
-    RKH_WS(L_::FT + 6 * j) = Fi.x; RKH_WS(L_::FT + 6 * j + 1) = Fi.y; RKH_WS(L_::FT + 6 * j + 2) = Fi.z;
-    RKH_WS(L_::FT + 6 * j + 3) = Ti.x; RKH_WS(L_::FT + 6 * j + 4) = Ti.y; RKH_WS(L_::FT + 6 * j + 5) = Ti.z;
-    // Jacobian columns of body j w.r.t. coords c = j, j-1, .., 0: get_jac_relative_to (motion_jacobians.hpp:238-251)
-    // with f2 = (~F_c) * F_b (frame_3D.hpp:184-189,222-238,368-382).  The parent frame of the next column is loaded
-    // while the current one is computed.
-    d3 cp = Epos;
-    d4 cq = EQ;
-#pragma unroll 1
-    for (int c = j; c >= 0; --c) {
-      d3 ncp = cp;
-      d4 ncq = cq;
-      if (c > 0) {
-        ncp = mk3(RKH_WS(L_::ECP + 3 * (c - 1)), RKH_WS(L_::ECP + 3 * (c - 1) + 1), RKH_WS(L_::ECP + 3 * (c - 1) + 2));
-        ncq = d4{RKH_WS(L_::ECQ + 4 * (c - 1)), RKH_WS(L_::ECQ + 4 * (c - 1) + 1), RKH_WS(L_::ECQ + 4 * (c - 1) + 2),
-                 RKH_WS(L_::ECQ + 4 * (c - 1) + 3)};
-      }
-      const m33 Rc = rotmat(cq);
-      const d4 iq = qinv(cq);
-      const d3 ipos = mulT(-cp, Rc);
-      const m33 Ri = rotmat(iq);
-      const d3 f2pos = ipos + mul(Ri, pos);
-      const d4 f2q = qmul(iq, Q);
-      const m33 Rf = rotmat(f2q);
-      const d3 ax_c = ldg3(sc->joints[c].axis);
-      const d3 wt = mulT(ax_c, Rf);
-      const d3 vt = mulT(cross(ax_c, f2pos), Rf);
-      lds.T[c * 6 + 0][lane] = vt.x; lds.T[c * 6 + 1][lane] = vt.y; lds.T[c * 6 + 2][lane] = vt.z;
-      lds.T[c * 6 + 3][lane] = wt.x; lds.T[c * 6 + 4][lane] = wt.y; lds.T[c * 6 + 5][lane] = wt.z;
-      cp = ncp;
-      cq = ncq;
+    RKH_STAMP(0)
+    if (h) {
+      RKH_LD(L_::FT + 6 * j) = Fi.x; RKH_LD(L_::FT + 6 * j + 1) = Fi.y; RKH_LD(L_::FT + 6 * j + 2) = Fi.z;
+      RKH_LD(L_::FT + 6 * j + 3) = Ti.x; RKH_LD(L_::FT + 6 * j + 4) = Ti.y; RKH_LD(L_::FT + 6 * j + 5) = Ti.z;
     }
-    // Mf += Tcm_b^T (Mcm_b Tcm_b): summation order of mat_alg_symmetric.hpp:551-566 and mat_operators.hpp:104-114
+    // Jacobian columns of body j w.r.t. coords c = j-h, j-h-2, ..: get_jac_relative_to (motion_jacobians.hpp:238-251)
+    // with f2 = (~F_c) * F_b (frame_3D.hpp:184-189,222-238,368-382); the edge's two lanes take alternate columns
+    // two columns per iteration (independent chains); a column index below 0 is computed on column 0's frame and
+    // not stored
+#pragma unroll 1
+    for (int ct = j - h; ct >= 0; ct -= 4) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int cr = ct - 2 * r;
+        const int c = cr >= 0 ? cr : 0;
+        const d3 cp = mk3(RKH_LD(L_::ECP + 3 * c), RKH_LD(L_::ECP + 3 * c + 1), RKH_LD(L_::ECP + 3 * c + 2));
+        const d4 cq = d4{RKH_LD(L_::ECQ + 4 * c), RKH_LD(L_::ECQ + 4 * c + 1), RKH_LD(L_::ECQ + 4 * c + 2),
+                         RKH_LD(L_::ECQ + 4 * c + 3)};
+        const m33 Rc = rotmat(cq);
+        const d4 iq = qinv(cq);
+        const d3 ipos = mulT(-cp, Rc);
+        // rotmat(conj(q)) is rotmat(q) transposed bit for bit (negating x, y, z flips the sign of the w-products and
+        // leaves the others unchanged), so Ri * pos is evaluated as pos * Rc: same products, same order
+        const d3 f2pos = ipos + mulT(pos, Rc);
+        const d4 f2q = qmul(iq, Q);
+        const m33 Rf = rotmat(f2q);
+        // joints[c].axis: per-lane index (the edge's two lanes work on different columns)
+        const d3 ax_c = mk3(sc->joints[c].axis[0], sc->joints[c].axis[1], sc->joints[c].axis[2]);
+        const d3 wt = mulT(ax_c, Rf);
+        const d3 vt = mulT(cross(ax_c, f2pos), Rf);
+        if (cr >= 0) {
+          RKH_LD(L_::T + c * 6 + 0) = vt.x; RKH_LD(L_::T + c * 6 + 1) = vt.y; RKH_LD(L_::T + c * 6 + 2) = vt.z;
+          RKH_LD(L_::T + c * 6 + 3) = wt.x; RKH_LD(L_::T + c * 6 + 4) = wt.y; RKH_LD(L_::T + c * 6 + 5) = wt.z;
+        }
+      }
+    }
+    RKH_STAMP(1)
+    // Mf += Tcm_b^T (Mcm_b Tcm_b): summation order of mat_alg_symmetric.hpp:551-566 and mat_operators.hpp:104-114;
+    // the edge's two lanes take alternate rows i
 #pragma unroll 1
     for (int jx = 0; jx <= j; ++jx) {
-      const double m0 = J.mass * lds.T[jx * 6 + 0][lane], m1 = J.mass * lds.T[jx * 6 + 1][lane],
-                   m2 = J.mass * lds.T[jx * 6 + 2][lane];
-      const d3 P = sym_mul(J.inertia, mk3(lds.T[jx * 6 + 3][lane], lds.T[jx * 6 + 4][lane], lds.T[jx * 6 + 5][lane]));
+      const double m0 = J.mass * RKH_LD(L_::T + jx * 6 + 0), m1 = J.mass * RKH_LD(L_::T + jx * 6 + 1),
+                   m2 = J.mass * RKH_LD(L_::T + jx * 6 + 2);
+      const d3 P = sym_mul(J.inertia, mk3(RKH_LD(L_::T + jx * 6 + 3), RKH_LD(L_::T + jx * 6 + 4), RKH_LD(L_::T + jx * 6 + 5)));
+      // three rows per iteration (i, i+2, i+4): independent accumulation chains; rows beyond j are computed on
+      // row j's operands and not stored
 #pragma unroll 1
-      for (int i = 0; i <= j; ++i) {
-        double s = lds.Mf[i * N + jx][lane];
-        s = s + lds.T[i * 6 + 0][lane] * m0;
-        s = s + lds.T[i * 6 + 1][lane] * m1;
-        s = s + lds.T[i * 6 + 2][lane] * m2;
-        s = s + lds.T[i * 6 + 3][lane] * P.x;
-        s = s + lds.T[i * 6 + 4][lane] * P.y;
-        s = s + lds.T[i * 6 + 5][lane] * P.z;
-        lds.Mf[i * N + jx][lane] = s;
+      for (int i0 = h; i0 <= j; i0 += 6) {
+        double sv[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int i = (i0 + 2 * r <= j) ? i0 + 2 * r : j;
+          double s = RKH_LD(L_::MF + i * N + jx);
+          s = s + RKH_LD(L_::T + i * 6 + 0) * m0;
+          s = s + RKH_LD(L_::T + i * 6 + 1) * m1;
+          s = s + RKH_LD(L_::T + i * 6 + 2) * m2;
+          s = s + RKH_LD(L_::T + i * 6 + 3) * P.x;
+          s = s + RKH_LD(L_::T + i * 6 + 4) * P.y;
+          s = s + RKH_LD(L_::T + i * 6 + 5) * P.z;
+          sv[r] = s;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          if (i0 + 2 * r <= j) RKH_LD(L_::MF + (i0 + 2 * r) * N + jx) = sv[r];
       }
     }
+    RKH_STAMP(2)
   }
 
   // ---- tip -> base sweep (kte_map_chain::doForce in reverse op order); f[j] lands in the (now free) T slots
@@ -193,31 +238,32 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
     for (int j = N - 1; j >= 0; --j) {
       const JointDev& J = sc->joints[j];
       const d3 axis = ldg3(J.axis);
-      LF = LF - mk3(RKH_WS(L_::FT + 6 * j), RKH_WS(L_::FT + 6 * j + 1), RKH_WS(L_::FT + 6 * j + 2));  // inertia_3D::doForce
-      LT = LT - mk3(RKH_WS(L_::FT + 6 * j + 3), RKH_WS(L_::FT + 6 * j + 4), RKH_WS(L_::FT + 6 * j + 5));
+      LF = LF - mk3(RKH_LD(L_::FT + 6 * j), RKH_LD(L_::FT + 6 * j + 1), RKH_LD(L_::FT + 6 * j + 2));  // inertia_3D::doForce
+      LT = LT - mk3(RKH_LD(L_::FT + 6 * j + 3), RKH_LD(L_::FT + 6 * j + 4), RKH_LD(L_::FT + 6 * j + 5));
       const m33 Ro = ldgm(J.off_R);                 // rigid_link_3D::doForce (rigid_link.cpp:170-178)
       const d3 op = ldg3(J.off_pos);
       const d3 tmp_force = mul(Ro, LF);
       const d3 ET = mul(Ro, LT) + cross(op, tmp_force);
-      const m33 Ra = lane_axis_angle_rotmat(RKH_WS(L_::TRIG + 4 * j + 2), RKH_WS(L_::TRIG + 4 * j + 3),
+      const m33 Ra = lane_axis_angle_rotmat(RKH_LD(L_::C1S1 + 2 * j), RKH_LD(L_::C1S1 + 2 * j + 1),
                                             ldg3(J.axis_n));  // revolute_joint_3D::doForce (revolute_joint.cpp:170-181)
       const double ta = dot(ET, axis);
       LF = mul(Ra, tmp_force);
       LT = mul(Ra, ET - ta * axis);
-      const double uj = lds.u[j][lane];  // inertia_gen::doForce (q_ddot = 0), driving_actuator_gen::doForce
-      lds.T[j][lane] = ta + uj;
+      const double uj = RKH_LD(L_::U + j);  // inertia_gen::doForce (q_ddot = 0), driving_actuator_gen::doForce
+      if (!h) RKH_LD(L_::T + j) = ta + uj;
       LT = LT - uj * axis;
     }
   }
 
+  RKH_STAMP(3)
   // ---- mat<symmetric>(general): 0.5 * (M(j,i) + M(i,j)), j < i (mat_alg_symmetric.hpp:183-187), lower triangle
   double L[N][N], f[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    f[i] = lds.T[i][lane];
+    f[i] = RKH_LD(L_::T + i);
 #pragma unroll
     for (int j = 0; j <= i; ++j)
-      L[i][j] = (i == j) ? lds.Mf[i * N + i][lane] : 0.5 * (lds.Mf[j * N + i][lane] + lds.Mf[i * N + j][lane]);
+      L[i][j] = (i == j) ? RKH_LD(L_::MF + i * N + i) : 0.5 * (RKH_LD(L_::MF + j * N + i) + RKH_LD(L_::MF + i * N + j));
   }
   // ---- linsolve_Cholesky (mat_cholesky.hpp:63-84,546-554)
 #pragma unroll
@@ -253,13 +299,23 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
   }
 #pragma unroll
   for (int j = 0; j < N; ++j) qdd[j] = f[j];
+  RKH_STAMP(4)
+#undef RKH_STAMP
 }
 
-// is the configuration in WS(XE..) (joint angles) collision-free?  (manip_dk_proxy_env_impl::is_free, proximity only)
-template <int N>
-__device__ __forceinline__ bool lane_proximity_free(const SceneDev* __restrict__ sc, int lane, double* __restrict__ ws,
-                                                    bool active) {
-  typedef WsLayout<N> L_;
+// is the configuration in LD(XE..) (joint angles) collision-free?  (manip_dk_proxy_env_impl::is_free, proximity only)
+// The edge's two lanes take alternate robot shapes; the verdict is combined across them.
+template <int N, bool DIAG = false>
+__device__ __forceinline__ bool lane_proximity_free(const SceneDev* __restrict__ sc, LaneLds<N>& lds, int el, int h,
+                                                    bool active, unsigned long long* stamps = nullptr) {
+  typedef LdsLayout<N> L_;
+  unsigned long long t_prev = DIAG ? __builtin_readcyclecounter() : 0ull;
+#define RKH_STAMP(i)                                                \
+  if (DIAG) {                                                       \
+    const unsigned long long t_now = __builtin_readcyclecounter(); \
+    stamps[i] += t_now - t_prev;                                    \
+    t_prev = t_now;                                                 \
+  }
   bool hit = !active;  // inactive lanes take no part in the scan
   {  // joint end frames: revolute_joint_3D / rigid_link_3D kinematics, position + orientation only
     d3 pos = ldg3(sc->base_pos);
@@ -269,27 +325,32 @@ __device__ __forceinline__ bool lane_proximity_free(const SceneDev* __restrict__
       const JointDev& J = sc->joints[j];
       const d3 axis_n = ldg3(J.axis_n);
       double s2, c2;
-      sincos(0.5 * RKH_WS(L_::XE + 2 * j), &s2, &c2);
+      sincos(0.5 * RKH_LD(L_::XE + 2 * j), &s2, &c2);
       const d4 tq = d4{c2, axis_n.x * s2, axis_n.y * s2, axis_n.z * s2};
       const d4 EQ = qmul(Q, tq);
-      RKH_WS(L_::ECP + 3 * j) = pos.x; RKH_WS(L_::ECP + 3 * j + 1) = pos.y; RKH_WS(L_::ECP + 3 * j + 2) = pos.z;
-      RKH_WS(L_::ECQ + 4 * j) = EQ.w; RKH_WS(L_::ECQ + 4 * j + 1) = EQ.x;
-      RKH_WS(L_::ECQ + 4 * j + 2) = EQ.y; RKH_WS(L_::ECQ + 4 * j + 3) = EQ.z;
+      if (!h) {
+        RKH_LD(L_::ECP + 3 * j) = pos.x; RKH_LD(L_::ECP + 3 * j + 1) = pos.y; RKH_LD(L_::ECP + 3 * j + 2) = pos.z;
+        RKH_LD(L_::ECQ + 4 * j) = EQ.w; RKH_LD(L_::ECQ + 4 * j + 1) = EQ.x;
+        RKH_LD(L_::ECQ + 4 * j + 2) = EQ.y; RKH_LD(L_::ECQ + 4 * j + 3) = EQ.z;
+      }
       const m33 R = rotmat(EQ);
       pos = pos + mul(R, ldg3(J.off_pos));
       Q = qmul(EQ, ldg4(J.off_quat));
     }
   }
   const int n_env = sc->n_env, n_robot = sc->n_robot;
+  RKH_STAMP(5)
 #pragma unroll 1
-  for (int r = 0; r < n_robot; ++r) {
+  for (int r0 = 0; r0 < n_robot; r0 += 2) {
     if (__all(hit)) break;
+    const int r = r0 + h;
+    const bool have = r < n_robot;
     // robot shape -> global pose (pose_3D::getGlobalPose, pose_3D.hpp:102-110)
-    const ShapeDev& sh = sc->robot[r];
+    const ShapeDev& sh = sc->robot[have ? r : r0];
     const int j = sh.link;
-    const d3 Epos = mk3(RKH_WS(L_::ECP + 3 * j), RKH_WS(L_::ECP + 3 * j + 1), RKH_WS(L_::ECP + 3 * j + 2));
-    const d4 EQ = d4{RKH_WS(L_::ECQ + 4 * j), RKH_WS(L_::ECQ + 4 * j + 1), RKH_WS(L_::ECQ + 4 * j + 2),
-                     RKH_WS(L_::ECQ + 4 * j + 3)};
+    const d3 Epos = mk3(RKH_LD(L_::ECP + 3 * j), RKH_LD(L_::ECP + 3 * j + 1), RKH_LD(L_::ECP + 3 * j + 2));
+    const d4 EQ = d4{RKH_LD(L_::ECQ + 4 * j), RKH_LD(L_::ECQ + 4 * j + 1), RKH_LD(L_::ECQ + 4 * j + 2),
+                     RKH_LD(L_::ECQ + 4 * j + 3)};
     ShapeG A;
     A.kind = sh.kind;
     A.pos = Epos + qrot(EQ, ldg3(sh.pos));
@@ -298,28 +359,49 @@ __device__ __forceinline__ bool lane_proximity_free(const SceneDev* __restrict__
     const d3 ca = pose_to_parent(A.pos, A.q, mk3(0, 0, 0));
     const double ra = sh.brad;
     const bool a_sphere = (sh.kind == RKH_SHAPE_SPHERE), a_ccyl = (sh.kind == RKH_SHAPE_CCYLINDER);
+    // capped cylinder: its axis segment (for the cull below)
+    const d3 a_ax = qrot(A.q, mk3(0.0, 0.0, 1.0));
+    const bool a_box = !a_sphere && !a_ccyl;
+    const double seg_hl = a_ccyl ? 0.5 * A.d0 : 0.0, seg_rad_m = (a_ccyl ? A.d1 : ra) + 1e-9;
 #pragma unroll 1
     for (int o0 = 0; o0 < n_env; o0 += 64) {
       const int on = (n_env - o0 < 64) ? n_env - o0 : 64;
-      // bounding-sphere cull (proxy_query_model.cpp:384-389), one bit per surviving obstacle; kind masks are uniform
-      unsigned long long mask = 0ull, k_sphere = 0ull, k_box = 0ull, k_ccyl = 0ull;
+      const unsigned long long k_sphere = sc->env_kind_mask[0][o0 >> 6], k_box = sc->env_kind_mask[1][o0 >> 6],
+                               k_ccyl = sc->env_kind_mask[2][o0 >> 6];
+      // Cull, one bit per surviving obstacle.  Lane l fetches the cull record of obstacle o0 + l once; the uniform loop
+      // over the obstacles reads it back with v_readlane (no memory latency in the loop).  A pair is dropped only if a
+      // lower bound on its distance is positive -- the bounding-sphere test of proxy_query_model.cpp:384-389 or, for
+      // a capped-cylinder robot shape, the distance from the obstacle's bounding sphere to the cylinder's axis segment --
+      // so the verdict "some pair is closer than 0" is unchanged.
+      const int ol = (o0 + (threadIdx.x & 63) < n_env) ? o0 + (threadIdx.x & 63) : o0;
+      const double ecx = sc->env_cull[ol][0], ecy = sc->env_cull[ol][1], ecz = sc->env_cull[ol][2], ecr = sc->env_cull[ol][3];
+      unsigned long long mask = 0ull;
+      // four obstacles per iteration: four independent dependency chains (one wave per SIMD: nothing else hides the
+      // fp64 latency); spare slots of the last iteration repeat obstacle o0's record and are masked off
+      auto cull_one = [&](int i) -> bool {
+        const d3 cb = mk3(readlane_d(ecx, i & 63), readlane_d(ecy, i & 63), readlane_d(ecz, i & 63));
+        const double rb = readlane_d(ecr, i & 63);
+        // branch-free: a sphere / box robot shape is a segment of length 0 with its bounding radius
+        const d3 v = cb - ca;
+        double t = dot(v, a_ax);
+        t = t > seg_hl ? seg_hl : (t < -seg_hl ? -seg_hl : t);
+        // |w| - seg_rad - rb > 1e-9, tested on the squares (no sqrt; the margin dwarfs the rounding of either form)
+        const d3 wv = v - t * a_ax;
+        const double reach = seg_rad_m + rb;
+        const bool apart = dot(wv, wv) > reach * reach;
+        const bool keep = !apart && !(a_box && ((k_box >> (i & 63)) & 1ull));  // box-box: no finder in the reference
+        return keep && (i < on);
+      };
 #pragma unroll 1
-      for (int i = 0; i < on; ++i) {
-        const ShapeDev& es = sc->env[o0 + i];
-        const int ke = es.kind;
-        const unsigned long long bit = 1ull << i;
-        if (ke == RKH_SHAPE_SPHERE) k_sphere |= bit;
-        else if (ke == RKH_SHAPE_BOX) k_box |= bit;
-        else k_ccyl |= bit;
-        // shape1 is the sphere if there is one, else the capped cylinder (createProxFinderList order)
-        const bool s1_is_robot = a_sphere || (a_ccyl && ke != RKH_SHAPE_SPHERE);
-        if (!a_sphere && !a_ccyl && ke == RKH_SHAPE_BOX) continue;  // box-box: no finder in the reference
-        const d3 cb = pose_to_parent(ldg3(es.pos), ldg4(es.quat), mk3(0, 0, 0));
-        const d3 c1 = s1_is_robot ? ca : cb, c2c = s1_is_robot ? cb : ca;
-        const double r1 = s1_is_robot ? ra : es.brad, r2 = s1_is_robot ? es.brad : ra;
-        if (!(norm_2(c2c - c1) - r1 - r2 > 0.0)) mask |= bit;
+      for (int i = 0; i < on; i += 4) {
+        const bool k0 = cull_one(i), k1 = cull_one(i + 1), k2 = cull_one(i + 2), k3 = cull_one(i + 3);
+        mask |= (k0 ? 1ull : 0ull) << i;
+        mask |= (k1 ? 2ull : 0ull) << i;
+        mask |= (k2 ? 4ull : 0ull) << i;
+        mask |= (k3 ? 8ull : 0ull) << i;
       }
-      if (hit) mask = 0ull;
+      if (hit || !have) mask = 0ull;
+      RKH_STAMP(6)
       // survivors, kind by kind
 #pragma unroll 1
       for (int kind = 0; kind < 3; ++kind) {
@@ -351,8 +433,12 @@ __device__ __forceinline__ bool lane_proximity_free(const SceneDev* __restrict__
         }
       }
     }
+    // what the edge's other lane found counts for both
+    hit = hit || (__shfl_xor(hit ? 1 : 0, 32, 64) != 0);
+    RKH_STAMP(7)
   }
   return !(hit && active);
+#undef RKH_STAMP
 }
 
 }  // namespace
@@ -361,31 +447,41 @@ template <int N>
 __global__ __launch_bounds__(64, 1) void propagate_lane_kernel(const SceneDev* __restrict__ sc, DynDev dyn, EdgeIO io_a,
                                                                 EdgeIO io_b, const EdgeIO* __restrict__ tab_a,
                                                                 const EdgeIO* __restrict__ tab_b, uint32_t grid_a,
-                                                                double* __restrict__ ws_all) {
+                                                                double* __restrict__ ws_all, KernelGate gate) {
   __shared__ LaneLds<N> lds;
-  typedef WsLayout<N> L_;
+  typedef LdsLayout<N> L_;
+  typedef WsLayout<N> W_;
+  if (gate.count) {  // the planner's per-round choice between the kernel mappings
+    const uint32_t c = *gate.count;
+    if (c < gate.lo || c >= gate.hi) return;
+  }
   constexpr int D = 2 * N;
   const bool group_b = blockIdx.x >= grid_a;
   const EdgeIO io = tab_a ? (group_b ? tab_b[blockIdx.y] : tab_a[blockIdx.y]) : (group_b ? io_b : io_a);
   const uint32_t B = io.d_B ? *io.d_B : io.B;
   const int lane = threadIdx.x;
-  const uint32_t e0 = (group_b ? blockIdx.x - grid_a : blockIdx.x) * 64u;
+  const uint32_t e0 = (group_b ? blockIdx.x - grid_a : blockIdx.x) * uint32_t(kEdgesPerWave);
   if (e0 >= B) return;
-  const uint32_t e = e0 + lane;
+  const int h = lane >> 5;
+  const int el_raw = lane & 31;
+  const bool lane_used = el_raw < kEdgesPerWave;
+  const int el = lane_used ? el_raw : 0;  // the four spare lanes mirror edge slot 0 (identical values)
+  const uint32_t e = e0 + uint32_t(el);
   const bool edge_valid = e < B;
-  const uint32_t ec = edge_valid ? e : e0;  // idle lanes shadow the wave's first edge, results discarded
-  double* __restrict__ ws = ws_all + (uint64_t(blockIdx.y) * gridDim.x + blockIdx.x) * uint64_t(L_::SLOTS * 64) + lane;
+  const bool writer = edge_valid && lane_used && h == 0;  // the lane that exports the edge's results
+  const uint32_t ec = edge_valid ? e : e0;  // idle slots shadow the wave's first edge, results discarded
+  double* __restrict__ ws = ws_all + (uint64_t(blockIdx.y) * gridDim.x + blockIdx.x) * uint64_t(W_::SLOTS * 64) + lane;
   const uint32_t si = io.src_idx ? io.src_idx[ec] : ((io.d_src_first ? *io.d_src_first : 0u) + ec);
   const uint64_t trow = (io.d_tgt_off ? uint64_t(*io.d_tgt_off) : 0ull) + ec;
   const double* __restrict__ a_row = io.src + uint64_t(si) * io.src_stride;
   const double* __restrict__ b_row = io.tgt + trow * io.tgt_stride;
-  double* __restrict__ record = edge_valid ? io.record : nullptr;
+  double* __restrict__ record = writer ? io.record : nullptr;
   const int record_stride = io.record_stride;
 #pragma unroll 1
   for (int d = 0; d < D; ++d) {
     const double av = a_row[d];
-    RKH_WS(L_::X + d) = av;
-    RKH_WS(L_::B + d) = b_row[d];
+    RKH_WS(W_::X + d) = av;
+    RKH_WS(W_::B + d) = b_row[d];
     if (record) record[(uint64_t(e) * record_stride + 0) * D + d] = av;
   }
 
@@ -399,9 +495,9 @@ __global__ __launch_bounds__(64, 1) void propagate_lane_kernel(const SceneDev* _
       double s = 0.0;
 #pragma unroll 1
       for (int d = 0; d < D; ++d) {
-        const double xv = RKH_WS(L_::X + d);
-        RKH_WS(L_::XE + d) = xv;
-        const double df = xv - RKH_WS(L_::B + d);
+        const double xv = RKH_WS(W_::X + d);
+        RKH_LD(L_::XE + d) = xv;
+        const double df = xv - RKH_WS(W_::B + d);
         s = s + df * df;
       }
       if (!(sqrt(s) > dyn.goal_tol)) alive = false;
@@ -410,26 +506,26 @@ __global__ __launch_bounds__(64, 1) void propagate_lane_kernel(const SceneDev* _
     // PD law, zero-order hold over the step
 #pragma unroll 1
     for (int j = 0; j < N; ++j) {
-      double v = dyn.kp * (RKH_WS(L_::B + 2 * j) - RKH_WS(L_::X + 2 * j)) +
-                 dyn.kd * (RKH_WS(L_::B + 2 * j + 1) - RKH_WS(L_::X + 2 * j + 1));
+      double v = dyn.kp * (RKH_WS(W_::B + 2 * j) - RKH_WS(W_::X + 2 * j)) +
+                 dyn.kd * (RKH_WS(W_::B + 2 * j + 1) - RKH_WS(W_::X + 2 * j + 1));
       if (v > dyn.u_max) v = dyn.u_max;
       else if (v < -dyn.u_max) v = -dyn.u_max;
-      lds.u[j][lane] = v;
+      RKH_LD(L_::U + j) = v;
     }
     // runge_kutta4_integrate_impl (runge_kutta4_integrator_sys.hpp:53-97): the four useful f-evals per inner step as
     // the stages of a rolled loop (one copy of the dynamics in the instruction stream)
-    const double h = dyn.dt;
+    const double h_dt = dyn.dt;
     bool sing_now = false;
     const int n_evals = 4 * dyn.inner[k];
 #pragma unroll 1
     for (int ev = 0; ev < n_evals; ++ev) {
       double qdd[N];
-      lane_state_derivative<N>(sc, lds, lane, ws, qdd, sing_now);
+      lane_state_derivative<N>(sc, lds, el, h, qdd, sing_now);
       const int stage = ev & 3;
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         // components 2j (q: derivative = qd of the differentiated state) and 2j+1 (qd: derivative = qdd)
-        const double xq = RKH_WS(L_::XE + 2 * j), xqd = RKH_WS(L_::XE + 2 * j + 1);
+        const double xq = RKH_LD(L_::XE + 2 * j), xqd = RKH_LD(L_::XE + 2 * j + 1);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           const int d = 2 * j + half;
@@ -437,23 +533,23 @@ __global__ __launch_bounds__(64, 1) void propagate_lane_kernel(const SceneDev* _
           const double dp = half ? qdd[j] : xqd;
           double xn;
           if (stage == 0) {
-            const double k1 = h * dp;
-            RKH_WS(L_::W + d) = xv;
-            RKH_WS(L_::KA + d) = k1;
+            const double k1 = h_dt * dp;
+            RKH_WS(W_::W + d) = xv;
+            RKH_WS(W_::KA + d) = k1;
             xn = xv + 0.5 * k1;
           } else if (stage == 1) {
-            const double k2 = h * dp;
-            const double k1 = RKH_WS(L_::KA + d);
-            RKH_WS(L_::KA + d) = (1.0 / 6.0) * k1 + (2.0 / 6.0) * k2;
-            xn = RKH_WS(L_::W + d) + 0.5 * k2;
+            const double k2 = h_dt * dp;
+            const double k1 = RKH_WS(W_::KA + d);
+            RKH_WS(W_::KA + d) = (1.0 / 6.0) * k1 + (2.0 / 6.0) * k2;
+            xn = RKH_WS(W_::W + d) + 0.5 * k2;
           } else if (stage == 2) {
-            const double k3v = h * dp;
-            RKH_WS(L_::K3 + d) = k3v;
-            xn = RKH_WS(L_::W + d) + k3v;
+            const double k3v = h_dt * dp;
+            RKH_WS(W_::K3 + d) = k3v;
+            xn = RKH_WS(W_::W + d) + k3v;
           } else {
-            xn = xv + ((RKH_WS(L_::KA + d) + (h / 6.0) * dp) - (2.0 / 3.0) * RKH_WS(L_::K3 + d));
+            xn = xv + ((RKH_WS(W_::KA + d) + (h_dt / 6.0) * dp) - (2.0 / 3.0) * RKH_WS(W_::K3 + d));
           }
-          RKH_WS(L_::XE + d) = xn;
+          RKH_LD(L_::XE + d) = xn;  // both lanes of the edge write the same value
         }
       }
     }
@@ -465,36 +561,36 @@ __global__ __launch_bounds__(64, 1) void propagate_lane_kernel(const SceneDev* _
     bool oob = false;
 #pragma unroll 1
     for (int d = 0; d < D; ++d) {
-      const double lo = dyn.lower[d], hi = dyn.upper[d], xv = RKH_WS(L_::XE + d);
+      const double lo = dyn.lower[d], hi = dyn.upper[d], xv = RKH_LD(L_::XE + d);
       if (lo < hi) oob = oob || (xv < lo) || (xv > hi);
       else oob = oob || (xv > lo) || (xv < hi);
     }
     if (oob) alive = false;
     if (!__any(alive)) break;
-    if (!lane_proximity_free<N>(sc, lane, ws, alive)) alive = false;
+    if (!lane_proximity_free<N>(sc, lds, el, h, alive)) alive = false;
     if (alive) {
       ++n_free;
 #pragma unroll 1
       for (int d = 0; d < D; ++d) {
-        const double xv = RKH_WS(L_::XE + d);
-        RKH_WS(L_::X + d) = xv;
+        const double xv = RKH_LD(L_::XE + d);
+        RKH_WS(W_::X + d) = xv;
         if (record) record[(uint64_t(e) * record_stride + n_free) * D + d] = xv;
       }
     }
   }
-  if (singular && edge_valid) atomicExch(io.err_flag, int(RKH_ERR_SINGULAR));
+  if (singular && writer) atomicExch(io.err_flag, int(RKH_ERR_SINGULAR));
   double s_ar = 0.0, s_ab = 0.0, s_rb = 0.0;
 #pragma unroll 1
   for (int d = 0; d < D; ++d) {
-    const double xv = RKH_WS(L_::X + d), av = a_row[d], bv = RKH_WS(L_::B + d);
-    if (edge_valid) io.x_out[uint64_t(e) * D + d] = xv;
+    const double xv = RKH_WS(W_::X + d), av = a_row[d], bv = RKH_WS(W_::B + d);
+    if (writer) io.x_out[uint64_t(e) * D + d] = xv;
     const double d_ar = av - xv, d_ab = av - bv, d_rb = xv - bv;
     s_ar = s_ar + d_ar * d_ar;
     s_ab = s_ab + d_ab * d_ab;
     s_rb = s_rb + d_rb * d_rb;
   }
-  if (edge_valid) io.steps_free[e] = n_free;
-  if (io.mode != EDGE_PLAIN && edge_valid) {
+  if (writer) io.steps_free[e] = n_free;
+  if (io.mode != EDGE_PLAIN && writer) {
     const double n_ar = sqrt(s_ar), n_ab = sqrt(s_ab), n_rb = sqrt(s_rb);
     if (io.mode == EDGE_STEER_ACCEPT) {
       // planning_visitor_base::steer_towards_position (planning_visitors.hpp:349-360)
@@ -509,24 +605,73 @@ __global__ __launch_bounds__(64, 1) void propagate_lane_kernel(const SceneDev* _
 }
 #undef RKH_WS
 
+// Diagnostic kernel (not on the product path): `iters` back-to-back f-evals + proximity tests of 28 states per wave
+// with cycle counts per phase: [frames + sincos, jacobian columns, mass matrix, force sweep, cholesky,
+// proximity: joint frames, cull, exact routines]
+template <int N>
+__global__ __launch_bounds__(64, 1) void lane_cycles_kernel(const SceneDev* __restrict__ sc, const double* __restrict__ x,
+                                                             const double* __restrict__ u, uint32_t B, int iters,
+                                                             unsigned long long* __restrict__ out,
+                                                             double* __restrict__ sink_out) {
+  __shared__ LaneLds<N> lds;
+  typedef LdsLayout<N> L_;
+  const int lane = threadIdx.x, h = lane >> 5, el_raw = lane & 31;
+  const int el = el_raw < kEdgesPerWave ? el_raw : 0;
+  uint32_t e = blockIdx.x * kEdgesPerWave + el;
+  if (e >= B) e = blockIdx.x * kEdgesPerWave;
+  for (int d = 0; d < 2 * N; ++d) RKH_LD(L_::XE + d) = x[uint64_t(e) * 2 * N + d];
+  for (int j = 0; j < N; ++j) RKH_LD(L_::U + j) = u[uint64_t(e) * N + j];
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool singular = false;
+  double accv = 0.0;
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    double qdd[N];
+    lane_state_derivative<N, true>(sc, lds, el, h, qdd, singular, st);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      accv += qdd[j];
+      RKH_LD(L_::XE + 2 * j + 1) = RKH_LD(L_::XE + 2 * j + 1) + 1e-4 * qdd[j];
+    }
+    accv += lane_proximity_free<N, true>(sc, lds, el, h, true, st) ? 1.0 : 0.0;
+  }
+  (void)t_begin;
+  if (lane == 0) {
+    for (int i = 0; i < 8; ++i) out[blockIdx.x * 8 + i] = st[i];
+    sink_out[blockIdx.x] = accv + (singular ? 1.0 : 0.0);
+  }
+}
+
+rkh_status launch_lane_cycles(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, const double* d_u,
+                              uint32_t B, int iters, unsigned long long* d_out, double* d_sink) {
+  const uint32_t waves = (B + kEdgesPerWave - 1) / kEdgesPerWave;
+  switch (n_dof) {
+    case 6: hipLaunchKernelGGL((lane_cycles_kernel<6>), dim3(waves), dim3(64), 0, s, d_scene, d_x, d_u, B, iters, d_out, d_sink); break;
+    case 3: hipLaunchKernelGGL((lane_cycles_kernel<3>), dim3(waves), dim3(64), 0, s, d_scene, d_x, d_u, B, iters, d_out, d_sink); break;
+    default: set_error("lane diagnostics: instantiated for 3 and 6 joints"); return RKH_ERR_UNSUPPORTED;
+  }
+  RKH_HIP(hipGetLastError());
+  return RKH_OK;
+}
+
 // bytes of workspace a launch of (edges_a + edges_b) edges per problem needs
 size_t propagate_lanes_workspace_bytes(int n_dof, uint32_t edges_a, uint32_t edges_b, uint32_t n_problems) {
-  const size_t waves = size_t((edges_a + 63) / 64 + (edges_b + 63) / 64) * n_problems;
-  return waves * size_t(29 * n_dof) * 64 * sizeof(double);
+  const size_t waves = size_t((edges_a + kEdgesPerWave - 1) / kEdgesPerWave + (edges_b + kEdgesPerWave - 1) / kEdgesPerWave) * n_problems;
+  return waves * size_t(10 * n_dof) * 64 * sizeof(double);
 }
 
 template <int N>
 static void launch_lane_t(hipStream_t s, const SceneDev* d_scene, const DynDev& dyn, const EdgeIO& io, uint32_t edges_a,
                           const EdgeIO& io_b, uint32_t edges_b, const EdgeIO* tab_a, const EdgeIO* tab_b,
-                          uint32_t n_problems, double* d_ws) {
-  const uint32_t ga = (edges_a + 63) / 64, gbk = (edges_b + 63) / 64;
+                          uint32_t n_problems, double* d_ws, KernelGate gate) {
+  const uint32_t ga = (edges_a + kEdgesPerWave - 1) / kEdgesPerWave, gbk = (edges_b + kEdgesPerWave - 1) / kEdgesPerWave;
   hipLaunchKernelGGL((propagate_lane_kernel<N>), dim3(ga + gbk, n_problems), dim3(64), 0, s, d_scene, dyn, io, io_b, tab_a,
-                     tab_b, ga, d_ws);
+                     tab_b, ga, d_ws, gate);
 }
 
 rkh_status launch_propagate_lanes(hipStream_t s, int n_dof, const SceneDev* d_scene, const DynDev& dyn, const EdgeIO& io,
                                   uint32_t grid_edges, const EdgeIO* io_b, uint32_t grid_b, const EdgeIO* tab_a,
-                                  const EdgeIO* tab_b, uint32_t n_problems, double* d_ws) {
+                                  const EdgeIO* tab_b, uint32_t n_problems, double* d_ws, KernelGate gate) {
   const uint32_t eb = (io_b || tab_b) ? grid_b : 0u;
   if (grid_edges + eb == 0 || n_problems == 0) return RKH_OK;
   if (!d_ws) {
@@ -535,10 +680,10 @@ rkh_status launch_propagate_lanes(hipStream_t s, int n_dof, const SceneDev* d_sc
   }
   const EdgeIO second = io_b ? *io_b : EdgeIO();
   switch (n_dof) {
-    case 1: launch_lane_t<1>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws); break;
-    case 2: launch_lane_t<2>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws); break;
-    case 3: launch_lane_t<3>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws); break;
-    case 6: launch_lane_t<6>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws); break;
+    case 1: launch_lane_t<1>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws, gate); break;
+    case 2: launch_lane_t<2>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws, gate); break;
+    case 3: launch_lane_t<3>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws, gate); break;
+    case 6: launch_lane_t<6>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws, gate); break;
     default:
       set_error("propagate: chains with this number of joints are not instantiated (1,2,3,6)");
       return RKH_ERR_UNSUPPORTED;
@@ -547,4 +692,5 @@ rkh_status launch_propagate_lanes(hipStream_t s, int n_dof, const SceneDev* d_sc
   return RKH_OK;
 }
 
+#undef RKH_LD
 }  // namespace rkh

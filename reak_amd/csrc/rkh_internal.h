@@ -50,7 +50,9 @@ struct NnArgs {  // one 1-NN problem: tree rows, queries, outputs (device pointe
 };
 rkh_status launch_nn1(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
                       uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0 = nullptr,
-                      hipEvent_t ev1 = nullptr);
+                      hipEvent_t ev1 = nullptr, double coord_bound = 0.0);
+// coord_bound > 0: every |coordinate| of rows and queries is <= coord_bound; sweeps with >= 32 queries then run the
+// single-precision pre-filter variant (identical results).
 uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B, uint32_t n_problems = 1);
 // k-NN with radius (knn_sweep.hip).  ws: device workspace from knn_workspace_bytes(); *d_overflow is set (non-zero)
 // if a query met more than the candidate capacity (pathological ties).
@@ -117,6 +119,10 @@ struct SceneDev {
   JointDev joints[kMaxDof];
   ShapeDev robot[kMaxDof * 2];
   ShapeDev env[kMaxEnvShapes];
+  // cull table of the environment: global centre of the bounding sphere (pose.transformToGlobal(0) = the pose's
+  // position) and its radius; one bit per shape and kind (sphere, box, capped cylinder) in chunks of 64 shapes
+  double env_cull[kMaxEnvShapes][4];
+  unsigned long long env_kind_mask[3][kMaxEnvShapes / 64];
 };
 
 }  // namespace rkh
@@ -209,16 +215,21 @@ struct EdgeIO {  // inputs / outputs of one propagate launch (all device pointer
   int* err_flag = nullptr;
 };
 
+// A steer kernel with a gate runs only if lo <= *count < hi (read on the device); count == nullptr: always.
+struct KernelGate {
+  const uint32_t* count = nullptr;
+  uint32_t lo = 0, hi = 0xFFFFFFFFu;
+};
 rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                             int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges,
                             const EdgeIO* io_b = nullptr, uint32_t grid_b = 0, int lanes_per_edge = 64,
                             const EdgeIO* tab_a = nullptr, const EdgeIO* tab_b = nullptr, uint32_t n_problems = 1,
-                            double* d_lane_ws = nullptr);
+                            double* d_lane_ws = nullptr, KernelGate gate = KernelGate());
 // one lane per edge (propagate_lane.hip); d_ws: propagate_lanes_workspace_bytes() of device memory
 size_t propagate_lanes_workspace_bytes(int n_dof, uint32_t edges_a, uint32_t edges_b, uint32_t n_problems);
 rkh_status launch_propagate_lanes(hipStream_t s, int n_dof, const SceneDev* d_scene, const DynDev& dyn, const EdgeIO& io,
                                   uint32_t grid_edges, const EdgeIO* io_b, uint32_t grid_b, const EdgeIO* tab_a,
-                                  const EdgeIO* tab_b, uint32_t n_problems, double* d_ws);
+                                  const EdgeIO* tab_b, uint32_t n_problems, double* d_ws, KernelGate gate = KernelGate());
 rkh_status launch_state_derivative(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x,
                                    const double* d_u, uint32_t B, double* d_pd, double* d_M, double* d_f, int* d_err);
 rkh_status launch_min_distance(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
@@ -230,5 +241,7 @@ rkh_status launch_edge_check(hipStream_t s, int n_dof, int n_env, const SceneDev
 rkh_status launch_feval_cycles(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                                int n_pairs, const double* d_x, const double* d_u, uint32_t B, int iters,
                                unsigned long long* d_out, double* d_sink);
+rkh_status launch_lane_cycles(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, const double* d_u,
+                              uint32_t B, int iters, unsigned long long* d_out, double* d_sink);
 rkh_status build_dyn_dev(const rkh_dyn_space& sp, double fraction, DynDev* out);
 }  // namespace rkh

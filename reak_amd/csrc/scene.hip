@@ -166,6 +166,9 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
         return RKH_ERR_CAPACITY;
       }
       d.link = -1;
+      for (int k = 0; k < 3; ++k) S.env_cull[S.n_env][k] = d.pos[k];
+      S.env_cull[S.n_env][3] = d.brad;
+      S.env_kind_mask[d.kind == RKH_SHAPE_SPHERE ? 0 : (d.kind == RKH_SHAPE_BOX ? 1 : 2)][S.n_env / 64] |= 1ull << (S.n_env % 64);
       S.env[S.n_env++] = d;
       env_src.push_back(i);
     }
@@ -342,9 +345,16 @@ rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double
   RKH_HIP(hipMalloc(&dsink.p, size_t(B) * 8));
   RKH_HIP(hipMemcpyAsync(dx.p, x, size_t(B) * 2 * n * 8, hipMemcpyHostToDevice, s));
   RKH_HIP(hipMemcpyAsync(du.p, u, size_t(B) * n * 8, hipMemcpyHostToDevice, s));
-  rkh_status st = launch_feval_cycles(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs,
-                                      dx.as<double>(), du.as<double>(), B, iters, dout.as<unsigned long long>(),
-                                      dsink.as<double>());
+  rkh_status st;
+  const char* ev = getenv("RKH_LANES_PER_EDGE");
+  if (ev && atoi(ev) == 1) {  // two-lanes-per-edge kernel: one record of 8 counters per wave of 28 states
+    RKH_HIP(hipMemsetAsync(dout.p, 0, size_t(B) * 8 * 8, s));
+    st = launch_lane_cycles(s, n, scene->d_scene, dx.as<double>(), du.as<double>(), B, iters,
+                            dout.as<unsigned long long>(), dsink.as<double>());
+  } else {
+    st = launch_feval_cycles(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, dx.as<double>(),
+                             du.as<double>(), B, iters, dout.as<unsigned long long>(), dsink.as<double>());
+  }
   if (st != RKH_OK) return st;
   RKH_HIP(hipMemcpyAsync(cycles, dout.p, size_t(B) * 8 * 8, hipMemcpyDeviceToHost, s));
   RKH_HIP(hipStreamSynchronize(s));
