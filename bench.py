@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--problems", type=int, default=int(os.environ.get("RKH_BENCH_PROBLEMS", "32")))
+    ap.add_argument("--problems", type=int, default=int(os.environ.get("RKH_BENCH_PROBLEMS", "128")))
     ap.add_argument("--max-vertices", type=int, default=100000)
     ap.add_argument("--rounds-per-sync", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,6 +151,8 @@ def main():
     scene = lib.Scene(ctx, scn)
     P = args.problems
 
+    nn_kernel = ["nn1_sweep_kernel"]
+
     def run_step(step_index, timed):
         seeds = dist_utils.seeds_for_rank(step_index, rank, world, P)
         pl = lib.RrtPlanner(scene, [scn.rrt_params(seed=s, max_vertices=args.max_vertices) for s in seeds])
@@ -173,6 +175,7 @@ def main():
         rounds = max(int(st.rounds) for st in pl.all_stats)
         best = min(float(st.best_cost) for st in pl.all_stats)
         prof = [pl.nn_profile()]
+        nn_kernel[0] = lib.load().rkh_nn_kernel_name().decode()
         pl.close()
         return {"seconds": t1 - t0, "nodes": nodes, "edges": edges, "spec": spec, "rounds": rounds, "best": best,
                 "nn_ms": sum(p[0] for p in prof), "nn_bytes": sum(p[1] for p in prof), "nn_launches": sum(p[2] for p in prof)}
@@ -223,11 +226,12 @@ def main():
             "rounds": tot["rounds"],
             "speculation_efficiency": (tot["edges"] / tot["spec"]) if tot["spec"] else None,
             "best_solution_cost": None if best == float("inf") else best,
-            "roofline": {"kernel": "nn1_sweep_kernel", "bound": "hbm", "achieved": nn_gbps, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"kernel": nn_kernel[0], "bound": "hbm", "achieved": nn_gbps, "peak": 8000.0, "unit": "GB/s",
                          "frac": nn_gbps / 8000.0, "traffic": None, "launches": tot["nn_launches"],
                          "avg_launch_us": (tot["nn_ms"] * 1e3 / tot["nn_launches"]) if tot["nn_launches"] else None,
-                         "note": "rank-0 sweeps of the timed region; each sweep serves a whole speculative batch of "
-                                 "queries, so it is fp64-VALU-bound by design (see nn_sweep_hbm for the HBM-bound regime)"},
+                         "note": "rank-0 sweeps of the timed region; each launch sweeps the trees of all problems for a whole "
+                                 "speculative batch of queries each, so it is VALU-bound by design (packed-fp32 pre-filter + "
+                                 "exact fp64 recheck); see nn_sweep_hbm for the same sweep in its HBM-bound regime"},
         }
         if not args.no_microbench:
             out["nn_sweep_hbm"] = nn_sweep_microbench(lib, ctx, events, 4 * 1024 * 1024, 8, 20)
