@@ -67,6 +67,38 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "c2_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
+    make_c1_golden()
+
+
+def make_c1_golden():
+    """C1 (3-DOF planar arm, quasi-static space): RRT, RRT* and PRM graphs of the oracle, small sizes."""
+    c1 = scenarios.make_c1(world_seed=1)
+    osc = oracle_lib.OracleScene(c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    out = {}
+    rng = np.random.default_rng(20260102)
+    a = rng.uniform(lo, hi, size=(400, 3))
+    x = np.zeros((400, 6)); x[:, 0::2] = a
+    a = a[osc.min_distance(x) > 0.0][:128]
+    b = rng.uniform(lo, hi, size=(a.shape[0], 3))
+    mv, nchk = osc.qs_move(lo, hi, mi, a, b, fraction=1.0)
+    out.update(walk_a=a, walk_b=b, walk_out=mv, walk_nchk=nchk)
+    rc, o, tree = osc.rrt_qs(lo, hi, mi, c1.rrt_params(seed=1, max_vertices=800))
+    out.update(rrt_counts=np.array([o.num_vertices, o.iterations, o.edges_checked, o.num_solutions], dtype=np.int64),
+               rrt_parent=tree["parent"], rrt_pos=tree["pos"], rrt_accept=tree["accept"])
+    rc, o, g = osc.rrtstar_qs(lo, hi, mi, c1.rrt_params(seed=1, max_vertices=600))
+    out.update(star_counts=np.array([o.num_vertices, o.samples, o.loop_iterations, o.num_solutions, o.rewires,
+                                     o.edges_checked], dtype=np.int64),
+               star_best=np.array([o.best_cost]), star_pred=g["pred"], star_dist=g["dist"], star_pos=g["pos"],
+               star_near=g["near_seq"])
+    rc, o, g = osc.prm_qs(lo, hi, mi, c1.prm_params(seed=1, max_vertices=500, sampling_radius=1.0))
+    out.update(prm_counts=np.array([o.num_vertices, o.num_edges, o.samples, o.rejected, o.loop_iterations,
+                                    o.num_components, o.publish_calls, o.merged_at_vertex, o.edges_checked], dtype=np.int64),
+               prm_pos=g["pos"], prm_edge_u=g["edge_u"], prm_edge_v=g["edge_v"], prm_edge_w=g["edge_w"],
+               prm_density=g["density"], prm_cc_root=g["cc_root"], prm_kind=g["kind"], prm_expanded=g["expanded"])
+    path = os.path.join(ROOT, "tests", "golden", "c1_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":
