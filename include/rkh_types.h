@@ -30,7 +30,12 @@ enum rkh_kte_kind {
   RKH_KTE_INERTIA_GEN = 2,          /* ctrl/mbd_kte/inertia.cpp:47-54           : coord, mass                */
   RKH_KTE_REVOLUTE_JOINT_3D = 3,    /* ctrl/mbd_kte/revolute_joint.cpp:121-213  : coord, axis, base, end     */
   RKH_KTE_RIGID_LINK_3D = 4,        /* ctrl/mbd_kte/rigid_link.cpp:152-186      : base, end, pose offset     */
-  RKH_KTE_INERTIA_3D = 5            /* ctrl/mbd_kte/inertia.cpp:111-122         : frame(end), mass, tensor   */
+  RKH_KTE_INERTIA_3D = 5,           /* ctrl/mbd_kte/inertia.cpp:111-122         : frame(end), mass, tensor   */
+  /* flexible_beam_3D without an object frame (ctrl/mbd_kte/flexible_beam.cpp:155-193): a linear + torsional spring
+   * between two anchors.  base_frame = mAnchor1 (a chain frame); end_frame = mAnchor2 (a chain frame) or -1 for an
+   * anchor fixed in the world at pose `offset`; axis[0] = mRestLength, axis[1] = mStiffness, axis[2] = mTorsionStiffness.
+   * The HIP kernels support one beam, listed last in the chain, from the last link's end frame to a world anchor. */
+  RKH_KTE_FLEXIBLE_BEAM_3D = 6
 };
 
 typedef struct rkh_kte_op {

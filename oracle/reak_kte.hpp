@@ -102,9 +102,30 @@ struct KteChain {
         case RKH_KTE_REVOLUTE_JOINT_3D: revolute_doForce(op); break;
         case RKH_KTE_RIGID_LINK_3D: link_doForce(op); break;
         case RKH_KTE_INERTIA_3D: inertia_3D_doForce(op); break;
+        case RKH_KTE_FLEXIBLE_BEAM_3D: beam_doForce(op); break;
         default: break;
       }
     }
+  }
+
+  // flexible_beam_3D::doForce without an object frame: flexible_beam.cpp:155-193 (:176-186)
+  void beam_doForce(const rkh_kte_op& op) {
+    Frame& a1 = frames[op.base_frame];
+    Frame world;  // mAnchor2 fixed in the world: a parentless frame at the given pose, no motion
+    if (op.end_frame < 0) {
+      world.Position = V3(op.offset.pos[0], op.offset.pos[1], op.offset.pos[2]);
+      world.Q = Quat(op.offset.quat[0], op.offset.quat[1], op.offset.quat[2], op.offset.quat[3]);
+    }
+    Frame& a2 = (op.end_frame >= 0) ? frames[op.end_frame] : world;
+    const double mRestLength = op.axis[0], mStiffness = op.axis[1], mTorsionStiffness = op.axis[2];
+    V3 diff = a1.Position - a2.Position;
+    V3 diff_a1 = invert(a1.Q) * (-diff) - V3(mRestLength, 0.0, 0.0);
+    V3 diff_a2 = invert(a2.Q) * diff + V3(mRestLength, 0.0, 0.0);
+    AxisAngle angle_diff(invert(a1.Q) * a2.Q);
+    a1.Force += mStiffness * diff_a1;
+    a1.Torque += (mTorsionStiffness * angle_diff.mAngle) * angle_diff.mAxis;
+    a2.Force += mStiffness * diff_a2;
+    a2.Torque -= (mTorsionStiffness * angle_diff.mAngle) * angle_diff.mAxis;
   }
 
   // revolute_joint_3D::doMotion: revolute_joint.cpp:121-148

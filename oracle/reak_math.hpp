@@ -148,6 +148,27 @@ struct AxisAngle {
       mAxis = V3(1.0, 0.0, 0.0);
     }
   }
+  // ctor(quaternion): rotations_3D.hpp:1986-2006
+  explicit AxisAngle(const Quat& Q) : mAngle(0.0) {
+    double v[4] = {Q.q[0], Q.q[1], Q.q[2], Q.q[3]};
+    double nrm = 0.0;  // unit(v): v /= norm_2(v) (vect_alg.hpp)
+    for (int i = 0; i < 4; ++i) nrm += v[i] * v[i];
+    nrm = std::sqrt(nrm);
+    for (int i = 0; i < 4; ++i) v[i] /= nrm;
+    double tmp = std::sqrt(v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    if (tmp > 0.0000001) {
+      mAxis = V3(v[1] / tmp, v[2] / tmp, v[3] / tmp);
+      if (v[0] < 0.0) {
+        mAngle = 2.0 * std::acos(-v[0]);
+        mAxis = V3(-mAxis[0], -mAxis[1], -mAxis[2]);
+      } else {
+        mAngle = 2.0 * std::acos(v[0]);
+      }
+    } else {
+      mAxis = V3(1.0, 0.0, 0.0);
+      mAngle = 0.0;
+    }
+  }
   // getQuaternion: rotations_3D.hpp:2107-2115
   Quat getQuaternion() const {
     double t = norm_2(mAxis);

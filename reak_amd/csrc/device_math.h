@@ -78,6 +78,32 @@ RKH_DI d3 sym_mul(const double* t, d3 V) {
   return r;
 }
 
+// flexible_beam_3D::doForce without an object frame (ctrl/mbd_kte/flexible_beam.cpp:176-186), anchor 1 only: force and
+// torque the beam adds to the frame (pos1, q1) given the world anchor (pos2, q2); axis_angle(quaternion) as in
+// rotations_3D.hpp:1986-2006 (unit(v) divides by the norm; threshold 1e-7)
+RKH_DI void beam_force(d3 pos1, d4 q1, d3 pos2, d4 q2, double rest, double k, double kt, d3* F, d3* T) {
+  const d3 diff = pos1 - pos2;
+  const d3 diff_a1 = qrot(qinv(q1), -diff) - mk3(rest, 0.0, 0.0);
+  const d4 dq = qmul(qinv(q1), q2);
+  double v0 = dq.w, v1 = dq.x, v2 = dq.y, v3 = dq.z;
+  const double nrm = sqrt(((v0 * v0 + v1 * v1) + v2 * v2) + v3 * v3);
+  v0 = v0 / nrm; v1 = v1 / nrm; v2 = v2 / nrm; v3 = v3 / nrm;
+  const double tmp = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+  d3 axis = mk3(1.0, 0.0, 0.0);
+  double angle = 0.0;
+  if (tmp > 0.0000001) {
+    axis = mk3(v1 / tmp, v2 / tmp, v3 / tmp);
+    if (v0 < 0.0) {
+      angle = 2.0 * acos(-v0);
+      axis = -axis;
+    } else {
+      angle = 2.0 * acos(v0);
+    }
+  }
+  *F = k * diff_a1;
+  *T = (kt * angle) * axis;
+}
+
 // wave64 broadcast of a double from lane `src`
 RKH_DI double bcast(double v, int src) { return __shfl(v, src, 64); }
 

@@ -54,6 +54,7 @@ struct __attribute__((aligned(16))) GroupWs {  // per-edge LDS workspace
   double Epos[N][3], Equat[N][4];   // joint end frames (jacobian parents)
   double Lpos[N][3], Lquat[N][4];   // link end frames (inertia frames)
   double FT[N][6];                  // inertia_3D d'Alembert force / torque (to be subtracted)
+  double BFT[6];                    // flexible beam force / torque on the last link's end frame (zero without a beam)
   double Tcm[N][N][6];              // [body][coord] jacobian column (v, w)
   double Mf[N][N];                  // Tcm^T (Mcm Tcm) before symmetrisation
   double M[N][N];                   // symmetric M, overwritten by its Cholesky factor
@@ -146,9 +147,10 @@ __device__ __forceinline__ void stage_env(const SceneDev* __restrict__ sc, Shape
 // x' = f(x,u) for the lane group's edge.  ws.x / ws.u hold the state and the input (already staged).
 // Returns dp for lane gl (< 2N); sets *singular if a Cholesky pivot is < 1e-8.
 template <int N, int GL>
-__device__ double state_derivative(const CPack<N>& cp, const JointLds* __restrict__ jl,
-                                   const double* __restrict__ base, GroupWs<N>& ws, double* __restrict__ sink,
-                                   int gl, int gb, bool* singular, unsigned long long* stamps = nullptr) {
+__device__ double state_derivative(const SceneDev* __restrict__ sc_beam, const CPack<N>& cp,
+                                   const JointLds* __restrict__ jl, const double* __restrict__ base, GroupWs<N>& ws,
+                                   double* __restrict__ sink, int gl, int gb, bool* singular,
+                                   unsigned long long* stamps = nullptr) {
   constexpr int D = 2 * N;
   // diagnostic builds only (rkh_diag_feval_cycles): per-phase s_memtime deltas; null in the product path
 #define RKH_STAMP(i)                                        \
@@ -215,6 +217,14 @@ __device__ double state_derivative(const CPack<N>& cp, const JointLds* __restric
       st3(lead ? ws.FT[j] : sink, Fi);
       st3(lead ? ws.FT[j] + 3 : sink, Ti);
     }
+    // flexible_beam_3D::doForce (listed last in the chain, so it runs first in the reverse pass and its force is the
+    // first term of the tip frame's accumulators)
+    d3 BF = mk3(0, 0, 0), BT = mk3(0, 0, 0);
+    if (sc_beam->beam_on)
+      beam_force(pos, Q, ld3(sc_beam->beam_pos), ld4(sc_beam->beam_quat), sc_beam->beam_rest, sc_beam->beam_k,
+                 sc_beam->beam_kt, &BF, &BT);
+    st3(lead ? ws.BFT : sink, BF);
+    st3(lead ? ws.BFT + 3 : sink, BT);
   }
   __syncthreads();
   RKH_STAMP(1)
@@ -249,7 +259,7 @@ __device__ double state_derivative(const CPack<N>& cp, const JointLds* __restric
   // ---- tip -> base sweep (kte_map_chain::doForce in reverse op order), group-uniform
   double f_mine = 0.0;  // lane i < N keeps generalized force i
   {
-    d3 LF = mk3(0, 0, 0), LT = mk3(0, 0, 0);
+    d3 LF = mk3(0, 0, 0) + ld3(ws.BFT), LT = mk3(0, 0, 0) + ld3(ws.BFT + 3);
 #pragma unroll
     for (int j = N - 1; j >= 0; --j) {
       const int jb = j * 32;
@@ -562,7 +572,7 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
       for (int ev = 0; ev < n_evals; ++ev) {
         if (gl < D) ws.x[gl] = xe;
         __syncthreads();
-        const double dp = state_derivative<N, GL>(cp, lds.joints, lds.base, ws, lds.sink[lane], gl, gb, &sing_now);
+        const double dp = state_derivative<N, GL>(sc, cp, lds.joints, lds.base, ws, lds.sink[lane], gl, gb, &sing_now);
         const int stage = ev & 3;
         if (stage == 0) {
           w = xe;
@@ -643,7 +653,7 @@ __global__ __launch_bounds__(64) void state_derivative_kernel(const SceneDev* __
   __syncthreads();
   const CPack<N> cp = load_cpack<N>(lds.joints, lane);
   bool singular = false;
-  const double dp = state_derivative<N, 64>(cp, lds.joints, lds.base, ws, lds.sink[lane], lane, 0, &singular);
+  const double dp = state_derivative<N, 64>(sc, cp, lds.joints, lds.base, ws, lds.sink[lane], lane, 0, &singular);
   if (lane < D) pd[uint64_t(e) * D + lane] = dp;
   if (singular && lane == 0) atomicExch(err_flag, int(RKH_ERR_SINGULAR));
   // exports for the kernel-level parity tests: the symmetric M is rebuilt from Mf (ws.M now holds its
@@ -836,7 +846,7 @@ __global__ __launch_bounds__(64) void feval_cycles_kernel(const SceneDev* __rest
   for (int it = 0; it < iters; ++it) {
     if (lane < D) ws.x[lane] = xv;
     __syncthreads();
-    const double dp = state_derivative<N, 64>(cp, lds.joints, lds.base, ws, lds.sink[lane], lane, 0, &singular, st);
+    const double dp = state_derivative<N, 64>(sc, cp, lds.joints, lds.base, ws, lds.sink[lane], lane, 0, &singular, st);
     xv = xv + 1e-4 * dp;
     if (lane < D) ws.x[lane] = xv;
     __syncthreads();

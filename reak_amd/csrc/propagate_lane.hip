@@ -234,6 +234,12 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
   // ---- tip -> base sweep (kte_map_chain::doForce in reverse op order); f[j] lands in the (now free) T slots
   {
     d3 LF = mk3(0, 0, 0), LT = mk3(0, 0, 0);
+    if (sc->beam_on) {  // flexible_beam_3D::doForce: listed last, so first in the reverse pass (first term of the sums)
+      d3 BF, BT;
+      beam_force(pos, Q, ldg3(sc->beam_pos), ldg4(sc->beam_quat), sc->beam_rest, sc->beam_k, sc->beam_kt, &BF, &BT);
+      LF = LF + BF;
+      LT = LT + BT;
+    }
 #pragma unroll 1
     for (int j = N - 1; j >= 0; --j) {
       const JointDev& J = sc->joints[j];

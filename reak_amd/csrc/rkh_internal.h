@@ -112,7 +112,7 @@ struct SceneDev {
   int32_t n_dof;
   int32_t n_robot;   // robot shapes (anchored)
   int32_t n_env;     // environment shapes
-  int32_t pad;
+  int32_t beam_on;   // 1: a flexible_beam_3D ties the last link's end frame to a world anchor
   double base_pos[3];
   double base_quat[4];
   double base_acc[3];
@@ -123,6 +123,9 @@ struct SceneDev {
   // position) and its radius; one bit per shape and kind (sphere, box, capped cylinder) in chunks of 64 shapes
   double env_cull[kMaxEnvShapes][4];
   unsigned long long env_kind_mask[3][kMaxEnvShapes / 64];
+  // flexible_beam_3D (flexible_beam.cpp:155-193): rest length, stiffness, torsion stiffness, world anchor pose
+  double beam_rest, beam_k, beam_kt;
+  double beam_pos[3], beam_quat[4];
 };
 
 }  // namespace rkh

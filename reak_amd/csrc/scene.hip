@@ -77,8 +77,11 @@ extern "C" {
 rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, const rkh_chain_base* base,
                             const rkh_shape* shapes, int n_shapes, rkh_scene** out) {
   if (!ctx || !prog || !base || !out || n_ops < 1 || (n_shapes > 0 && !shapes)) return RKH_ERR_BAD_ARG;
-  if (n_ops % 5 != 0 || n_ops / 5 > kMaxDof) {
-    set_error("rkh_scene_create: KTE program is not a serial chain of {actuator, inertia_gen, revolute, link, inertia_3D} groups");
+  const bool has_beam = (n_ops % 5 == 1) && prog[n_ops - 1].kind == RKH_KTE_FLEXIBLE_BEAM_3D;
+  if (has_beam) --n_ops;  // the beam is validated below, after the chain
+  if (n_ops % 5 != 0 || n_ops / 5 > kMaxDof || n_ops < 5) {
+    set_error("rkh_scene_create: KTE program is not a serial chain of {actuator, inertia_gen, revolute, link, inertia_3D} "
+              "groups (optionally followed by one flexible_beam_3D)");
     return RKH_ERR_UNSUPPORTED;
   }
   const int n = n_ops / 5;
@@ -131,6 +134,20 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
     host_rotmat(J.off_quat, J.off_R);
     J.mass = ine.mass;
     for (int i = 0; i < 6; ++i) J.inertia[i] = ine.inertia[i];
+  }
+  if (has_beam) {
+    const rkh_kte_op& bm = prog[n_ops];
+    if (bm.base_frame != link_end_frame[n - 1] || bm.end_frame != -1) {
+      delete sc;
+      set_error("rkh_scene_create: the flexible beam must tie the last link's end frame to a world anchor (end_frame = -1)");
+      return RKH_ERR_UNSUPPORTED;
+    }
+    S.beam_on = 1;
+    S.beam_rest = bm.axis[0];
+    S.beam_k = bm.axis[1];
+    S.beam_kt = bm.axis[2];
+    for (int i = 0; i < 3; ++i) S.beam_pos[i] = bm.offset.pos[i];
+    for (int i = 0; i < 4; ++i) S.beam_quat[i] = bm.offset.quat[i];
   }
   // shapes: robot model (anchored) / environment model (world)
   std::vector<int> robot_src, env_src;

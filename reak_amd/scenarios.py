@@ -111,12 +111,26 @@ def crs_like_chain():
     return axes, lengths, offsets, masses, inertias, joint_inertias
 
 
-def make_c2(world_seed=1, n_obstacles=50, capsule_radius=0.05, steps_per_edge=20, dt=1e-3):
-    """BASELINE config C2: 6-DOF revolute KTE chain, RK4 dt=1e-3 x 20 steps/edge, 50 convex obstacles."""
+def flexible_beam_op(anchor_frame, world_pose, rest_length, stiffness, torsion_stiffness):
+    """flexible_beam_3D (ctrl/mbd_kte/flexible_beam.cpp:155-193, no object frame) between a chain frame and an anchor fixed
+    in the world."""
+    op = T.KteOp(kind=T.KTE_FLEXIBLE_BEAM_3D, coord=-1, base_frame=anchor_frame, end_frame=-1, joint_op=-1, upstream=0)
+    op.axis[:] = [rest_length, stiffness, torsion_stiffness]
+    op.offset = world_pose
+    return op
+
+
+def make_c2(world_seed=1, n_obstacles=50, capsule_radius=0.05, steps_per_edge=20, dt=1e-3, tether=None):
+    """BASELINE config C2: 6-DOF revolute KTE chain, RK4 dt=1e-3 x 20 steps/edge, 50 convex obstacles.
+    tether = (rest_length, stiffness, torsion_stiffness): a flexible_beam_3D from the end effector to a world anchor
+    above the base (the beam parameters of BASELINE config C4: k = 1e4 N/m, k_theta = 1e2)."""
     rng = np.random.Generator(np.random.PCG64(world_seed))
     axes, lengths, offsets, masses, inertias, joint_inertias = crs_like_chain()
     n = len(axes)
     ops = serial_chain_ops(axes, offsets, masses, inertias, joint_inertias)
+    if tether is not None:
+        anchor = T.make_pose((0.3, 0.2, sum(lengths) + 0.1), (0.9238795325112867, 0.0, 0.3826834323650898, 0.0))
+        ops.append(flexible_beam_op(2 * n, anchor, *tether))
     base = T.ChainBase()
     base.pose = T.make_pose()
     base.acceleration[:] = [0.0, 0.0, 9.81]  # gravity as base acceleration (mbd_kte/test_bm.cpp:52)

@@ -12,6 +12,7 @@ KTE_INERTIA_GEN = 2
 KTE_REVOLUTE_JOINT_3D = 3
 KTE_RIGID_LINK_3D = 4
 KTE_INERTIA_3D = 5
+KTE_FLEXIBLE_BEAM_3D = 6
 
 # rkh_shape_kind
 SHAPE_SPHERE = 1

@@ -407,3 +407,42 @@ def test_rrt_tree_with_one_lane_per_edge(L, ctx, oracle, c2, monkeypatch):
     assert np.array_equal(tree["parent"], rtree["parent"])
     assert np.allclose(tree["pos"], rtree["pos"], rtol=STATE_RTOL, atol=1e-12)
     assert np.array_equal(np.isinf(tree["goal_dist"]), np.isinf(rtree["goal_dist"]))
+
+
+# ------------------------------------------------------------------ flexible_beam_3D (a17)
+def test_flexible_beam_dynamics_and_planner(L, ctx, oracle, monkeypatch):
+    """C2 chain with a flexible_beam_3D (k = 1e4 N/m, k_theta = 1e2, the C4 parameters) from the end effector to a world
+    anchor: x' = f(x,u), the steer kernels (all mappings) and a planner run against the oracle."""
+    scn = scenarios.make_c2(world_seed=1, tether=(0.4, 1e4, 1e2))
+    sc, osc = L.Scene(ctx, scn), oracle.OracleScene(scn)
+    plain = oracle.OracleScene(scenarios.make_c2(world_seed=1))
+    rng = np.random.default_rng(31)
+    lo = np.array([scn.dyn.lower[i] for i in range(12)])
+    hi = np.array([scn.dyn.upper[i] for i in range(12)])
+    x = rng.uniform(lo, hi, size=(128, 12))
+    u = rng.uniform(-50, 50, size=(128, 6))
+    rc, rpd, rM, rf = osc.state_derivative(x, u)
+    pd, M, f = sc.state_derivative(x, u)
+    assert rc == 0
+    assert np.max(np.abs(M - rM)) <= 1e-13 * np.abs(rM).max()      # the beam adds no inertia
+    assert np.allclose(f, rf, rtol=1e-10, atol=1e-8)               # bias force with the beam (acos: OCML vs glibc)
+    assert np.allclose(pd, rpd, rtol=1e-9, atol=1e-8)
+    assert np.abs(rf - plain.state_derivative(x, u)[3]).max() > 10.0  # and the beam does pull
+    a = x[:96] * 0.5
+    a = a[osc.min_distance(a) > 0.01][:60]
+    b = rng.uniform(lo, hi, size=(a.shape[0], 12))
+    res = {}
+    for lanes in ("64", "1"):
+        monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
+        res[lanes] = sc.steer_position_toward(a, b)
+    assert np.array_equal(res["1"][0], res["64"][0]) and np.array_equal(res["1"][1], res["64"][1])
+    rc, rout, rsteps, _ = osc.steer(a, b)
+    assert np.array_equal(res["64"][1], rsteps) and np.allclose(res["64"][0], rout, rtol=1e-9, atol=1e-10)
+    monkeypatch.delenv("RKH_LANES_PER_EDGE")
+    prm = scn.rrt_params(seed=3, max_vertices=400)
+    rc, ro, rtree = osc.rrt_dyn(prm)
+    pl = L.RrtPlanner(sc, prm)
+    st = pl.solve_planning_query()
+    tree = pl.tree()
+    assert (st.num_vertices, st.iterations, st.edges_checked) == (ro.num_vertices, ro.iterations, ro.edges_checked)
+    assert np.array_equal(tree["parent"], rtree["parent"]) and np.array_equal(tree["accept"], rtree["accept"])

@@ -228,3 +228,38 @@ def test_linear_nn_tie_rules(oracle):
     assert cnt[0] == 3 and idx[0, 0] == 0 and set(idx[0, 1:]) <= {1, 2, 3, 4} and np.all(dist[0, 1:] == 1.0)
     idx, dist, cnt = oracle.knn(q[1:2], pts, k=10, radius=1.0)
     assert cnt[0] == 1  # strict d < radius
+
+
+def test_flexible_beam_force_closed_form(oracle):
+    """flexible_beam_3D (flexible_beam.cpp:176-186) between the tip of a 1-link chain and a world anchor: with both
+    frames unrotated the force on the tip is k * ((p2 - p1) - (rest, 0, 0)), the torque vanishes; a relative rotation
+    of phi about z adds the torque k_theta * phi about z.  Checked through the generalized force of the joint."""
+    import copy
+
+    from reak_amd import scenarios as S
+    from reak_amd import types as T
+
+    L, k, kt, rest = 0.5, 100.0, 10.0, 0.2
+    pend = S.make_pendulum(length=L, mass=1.0)   # revolute about -y at the origin, link along x, gravity +z as base acc
+    base = copy.copy(pend)
+    osc0 = oracle.OracleScene(base)
+    x = np.zeros((1, 2)); u = np.zeros((1, 1))
+    rc, pd0, M0, f0 = osc0.state_derivative(x, u)
+    # anchor straight ahead of the tip (tip at (L,0,0)), unrotated: pure axial force, no moment about the joint axis
+    teth = copy.copy(pend)
+    teth.ops = list(pend.ops) + [S.flexible_beam_op(2, T.make_pose((L + 0.3, 0.0, 0.0)), rest, k, kt)]
+    rc, pd1, M1, f1 = oracle.OracleScene(teth).state_derivative(x, u)
+    assert rc == 0 and np.allclose(M1, M0) and np.allclose(f1, f0, atol=1e-12)
+    # anchor above the tip by dz: force on the tip k*(0,0,dz) -(rest,0,0)k; the joint axis is -y, lever arm L along x:
+    # torque about -y = -(r x F)_y = -(z_comp... ) = L * k * dz
+    dz = 0.05
+    teth.ops = list(pend.ops) + [S.flexible_beam_op(2, T.make_pose((L, 0.0, dz)), rest, k, kt)]
+    rc, pd2, M2, f2 = oracle.OracleScene(teth).state_derivative(x, u)
+    assert np.allclose(f2 - f0, L * k * dz, rtol=1e-12)
+    # anchor at the tip, rotated by phi about -y (the joint axis): torsion k_theta * phi about the joint axis,
+    # plus the rest-length pull along the link (no moment)
+    phi = 0.3
+    q = (np.cos(phi / 2), 0.0, -np.sin(phi / 2), 0.0)
+    teth.ops = list(pend.ops) + [S.flexible_beam_op(2, T.make_pose((L, 0.0, 0.0), q), rest, k, kt)]
+    rc, pd3, M3, f3 = oracle.OracleScene(teth).state_derivative(x, u)
+    assert np.allclose(f3 - f0, kt * phi, rtol=1e-10)
