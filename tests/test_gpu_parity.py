@@ -446,3 +446,54 @@ def test_flexible_beam_dynamics_and_planner(L, ctx, oracle, monkeypatch):
     tree = pl.tree()
     assert (st.num_vertices, st.iterations, st.edges_checked) == (ro.num_vertices, ro.iterations, ro.edges_checked)
     assert np.array_equal(tree["parent"], rtree["parent"]) and np.array_equal(tree["accept"], rtree["accept"])
+
+
+# ------------------------------------------------------------------ ragged / degenerate sizes
+def test_ragged_planner_batch(L, ctx, oracle, c2):
+    """Problems of very different sizes in one batch (they finish in different rounds; the small ones idle while the
+    large ones go on), each still the sequential planner on its seed."""
+    sc, osc = L.Scene(ctx, c2), oracle.OracleScene(c2)
+    sizes = (1, 37, 400, 1100)
+    prms = [c2.rrt_params(seed=10 + i, max_vertices=mv) for i, mv in enumerate(sizes)]
+    pl = L.RrtPlanner(sc, prms)
+    pl.solve_planning_query()
+    for i, prm in enumerate(prms):
+        rc, ro, rtree = osc.rrt_dyn(prm)
+        st, tree = pl.all_stats[i], pl.tree(i)
+        assert (st.num_vertices, st.iterations, st.edges_checked) == (ro.num_vertices, ro.iterations, ro.edges_checked)
+        assert np.array_equal(tree["parent"], rtree["parent"]) and np.array_equal(tree["nn_seq"], rtree["nn_seq"])
+
+
+def test_steer_kernels_ragged_wave_sizes(L, ctx, oracle, c2, monkeypatch):
+    """Batch sizes around the wave granularities of the two steer mappings (1, 27, 28, 29, 57 edges)."""
+    sc, osc = L.Scene(ctx, c2), oracle.OracleScene(c2)
+    rng = np.random.default_rng(77)
+    lo = np.array([c2.dyn.lower[i] for i in range(12)])
+    hi = np.array([c2.dyn.upper[i] for i in range(12)])
+    a = rng.uniform(lo, hi, size=(300, 12)) * 0.5
+    a = a[osc.min_distance(a) > 0.01]
+    b = rng.uniform(lo, hi, size=(a.shape[0], 12))
+    for B in (1, 27, 28, 29, 57):
+        rc, rout, rsteps, _ = osc.steer(a[:B], b[:B])
+        for lanes in ("64", "1"):
+            monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
+            out, steps, _ = sc.steer_position_toward(a[:B], b[:B])
+            assert np.array_equal(steps, rsteps) and np.allclose(out, rout, rtol=STATE_RTOL, atol=1e-12)
+
+
+def test_knn_degenerate_requests(L, ctx, oracle):
+    """k larger than the tree, a radius that excludes everything, a single-vertex tree."""
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-1, 1, size=(5, 3))
+    q = rng.uniform(-1, 1, size=(4, 3))
+    nn = L.HipNeighborSearch(ctx, 3, 64)
+    nn.added_vertices(pts[:1])
+    idx, dist, cnt = nn.k_nearest(q, 8, radius=np.inf)
+    assert np.all(cnt == 1) and np.all(idx[:, 0] == 0)
+    nn.added_vertices(pts[1:])
+    idx, dist, cnt = nn.k_nearest(q, 8, radius=np.inf)       # k > n: everything, nearest first
+    ridx, rdist, rcnt = oracle.knn(q, pts, 8, radius=np.inf)
+    assert np.array_equal(cnt, rcnt) and np.all(cnt == 5)
+    assert np.array_equal(idx[:, :5], ridx[:, :5]) and np.array_equal(dist[:, :5], rdist[:, :5])
+    idx, dist, cnt = nn.k_nearest(q, 3, radius=1e-9)          # nothing inside the radius
+    assert np.all(cnt == 0)
