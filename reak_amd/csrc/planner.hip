@@ -256,6 +256,10 @@ struct rkh_planner {
   double coord_bound = 0.0;     // max |coordinate| of vertices and samples (hyperbox bounds), 0 = unknown
   uint32_t* d_sel = nullptr;    // [2] edges of the current round (by round parity), see round_begin_kernel
   uint32_t round_parity = 0;
+  // host-side upper bounds that size the launches of a round (the exact counts live on the device): n_ub[i] >= vertex
+  // count of problem i (exact after every sync, + the round's batch bound per enqueued round)
+  std::vector<uint64_t> n_ub;
+  uint32_t prev_batch_ub = 0;  // batch bound of the previous round = bound on this round's goal probes
   uint32_t lane_threshold = 4500;  // rounds with at least this many edges go to the two-lanes-per-edge kernel
   uint32_t part_blocks = 0;
   uint64_t max_capacity = 0;
@@ -301,8 +305,18 @@ rkh_status upload_samples(rkh_planner* p, Problem& q, uint32_t index, uint64_t u
 }
 
 template <int DP>
-void launch_fixup(rkh_planner* p) {
-  hipLaunchKernelGGL((fixup_kernel<DP>), dim3((p->b_max + 3) / 4, p->P), dim3(256), 0, p->stream, p->d_probs, p->D);
+void launch_fixup(rkh_planner* p, uint32_t batch_ub) {
+  hipLaunchKernelGGL((fixup_kernel<DP>), dim3((batch_ub + 3) / 4, p->P), dim3(256), 0, p->stream, p->d_probs, p->D);
+}
+
+// upper bound of the batch size round_begin_kernel will choose for a problem with at most n_ub vertices (same float
+// formula, monotone in n)
+uint32_t batch_upper_bound(const PlannerState& st, uint64_t n_ub) {
+  const float want = st.batch_factor * sqrtf(float(n_ub));
+  uint32_t B = uint32_t(want);
+  if (B < st.b_min) B = st.b_min;
+  if (B > st.b_max) B = st.b_max;
+  return B;
 }
 
 // steer / probe edges of all problems: RK4 propagation (dynamic space) or the min_interval walk (quasi-static space)
@@ -352,23 +366,33 @@ rkh_status enqueue_round(rkh_planner* p) {
     ev0 = p->ev[2 * slot];
     ev1 = p->ev[2 * slot + 1];
   }
+  // launch sizes of this round from the host-side bounds
+  uint32_t batch_ub = 1;
+  for (uint32_t i = 0; i < p->P; ++i) {
+    const PlannerState& hs = p->prob[i].h_state;
+    const uint32_t b = batch_upper_bound(hs, p->n_ub[i]);
+    batch_ub = std::max(batch_ub, b);
+    p->n_ub[i] = std::min<uint64_t>(p->n_ub[i] + b, uint64_t(hs.max_total));
+  }
+  const uint32_t probe_ub = p->prev_batch_ub ? p->prev_batch_ub : p->b_max;
+  p->prev_batch_ub = batch_ub;
   p->round_parity ^= 1u;
   hipLaunchKernelGGL(round_begin_kernel, dim3(p->P), dim3(64), 0, s, p->d_probs, slot, p->d_sel, p->round_parity);
   // 1. NN sweep of every problem's samples over its snapshot
-  rkh_status st = launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, p->b_max, p->part_blocks, ev0, ev1,
+  rkh_status st = launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, batch_ub, p->part_blocks, ev0, ev1,
                              p->coord_bound);
   if (st != RKH_OK) return st;
   // 2. speculative steer of all candidates + the goal probes of the vertices the previous round committed
-  st = launch_edges(p, p->b_max, p->b_max, p->d_io_steer, p->d_io_probe);
+  st = launch_edges(p, batch_ub, probe_ub, p->d_io_steer, p->d_io_probe);
   if (st != RKH_OK) return st;
   // 3. fix-up against the vertices this round itself would add
   switch (p->DP) {
-    case 2: launch_fixup<2>(p); break;
-    case 4: launch_fixup<4>(p); break;
-    case 6: launch_fixup<6>(p); break;
-    case 8: launch_fixup<8>(p); break;
-    case 12: launch_fixup<12>(p); break;
-    case 16: launch_fixup<16>(p); break;
+    case 2: launch_fixup<2>(p, batch_ub); break;
+    case 4: launch_fixup<4>(p, batch_ub); break;
+    case 6: launch_fixup<6>(p, batch_ub); break;
+    case 8: launch_fixup<8>(p, batch_ub); break;
+    case 12: launch_fixup<12>(p, batch_ub); break;
+    case 16: launch_fixup<16>(p, batch_ub); break;
     default: set_error("planner: unsupported state dimension"); return RKH_ERR_UNSUPPORTED;
   }
   // 4. commit the valid prefix
@@ -388,7 +412,13 @@ rkh_status read_states(rkh_planner* p) {
   std::vector<PlannerState> hs(p->P);
   RKH_HIP(hipMemcpyAsync(hs.data(), p->d_states, p->P * sizeof(PlannerState), hipMemcpyDeviceToHost, p->stream));
   RKH_HIP(hipStreamSynchronize(p->stream));
-  for (uint32_t i = 0; i < p->P; ++i) p->prob[i].h_state = hs[i];
+  for (uint32_t i = 0; i < p->P; ++i) {
+    p->prob[i].h_state = hs[i];
+    p->n_ub[i] = hs[i].n;  // the stream is idle: the bound is exact again
+  }
+  uint32_t pending = 1;
+  for (uint32_t i = 0; i < p->P; ++i) pending = std::max(pending, hs[i].n_new);
+  p->prev_batch_ub = pending;
   return RKH_OK;
 }
 
@@ -461,7 +491,9 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     p->lanes_per_edge = (uint64_t(n_problems) * 2 * p->b_max > 4096) ? 16 : 64;
   }
   if (const char* e = getenv("RKH_PROFILE_NN")) p->profile_nn = atoi(e) != 0;
-  float batch_factor = 2.0f;
+  // candidates per round = batch_factor * sqrt(n): a single problem is latency-bound (bigger batches, fewer rounds), a
+  // large batch of problems fills the chip anyway and prefers less discarded speculation (measured optimum 1.25)
+  float batch_factor = (n_problems >= 16) ? 1.25f : 2.0f;
   uint32_t b_min = 8;
   if (const char* e = getenv("RKH_BATCH_FACTOR")) batch_factor = float(atof(e));
   if (const char* e = getenv("RKH_BATCH_MIN")) b_min = std::max(1, atoi(e));
@@ -481,6 +513,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     p->max_capacity = std::max(p->max_capacity, cap);
   }
   p->part_blocks = std::max(nn1_partial_blocks(p->max_capacity, p->b_max, P), nn1_partial_blocks(p->max_capacity, 1, P));
+  p->n_ub.assign(P, 1);
   std::vector<PlannerState> hs(P);
   std::vector<ProblemDev> hp(P);
   std::vector<NnArgs> hn(P);
@@ -529,6 +562,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     s0.b_min = b_min;
     s0.batch_factor = batch_factor;
     q.h_state = s0;
+    p->n_ub[i] = 1;
     PlannerState* dst = p->d_states + i;
     ProblemDev& pd = hp[i];
     pd.st = dst;
