@@ -16,6 +16,8 @@ Extra objects on the JSON line:
                 (algorithmic bytes n*D*8 per launch); peak 8 TB/s HBM3E.
   nn_sweep_hbm  the same kernel in its HBM-bound regime (tree larger than the 256 MiB Infinity Cache, 8 queries
                 per sweep), measured outside the timed region
+  steer_kernels the dominant kernels of the timed region (the two mappings of the steer kernel): share of the step time,
+                edges/s inside the kernel, achieved fp64 operation rate against the no-FMA VALU peak
   cpu_baseline  the CPU oracle (restatement of the reference planner, -O3 -march=native) on a bounded sample of the
                 same workload, single thread like ReaK itself
 """
@@ -175,14 +177,17 @@ def main():
         rounds = max(int(st.rounds) for st in pl.all_stats)
         best = min(float(st.best_cost) for st in pl.all_stats)
         prof = [pl.nn_profile()]
+        steer_ms, steer_launches = pl.steer_profile()
         nn_kernel[0] = lib.load().rkh_nn_kernel_name().decode()
         pl.close()
         return {"seconds": t1 - t0, "nodes": nodes, "edges": edges, "spec": spec, "rounds": rounds, "best": best,
-                "nn_ms": sum(p[0] for p in prof), "nn_bytes": sum(p[1] for p in prof), "nn_launches": sum(p[2] for p in prof)}
+                "nn_ms": sum(p[0] for p in prof), "nn_bytes": sum(p[1] for p in prof), "nn_launches": sum(p[2] for p in prof),
+                "steer_ms": steer_ms, "steer_launches": steer_launches}
 
     for w in range(args.warmup):
         run_step(1000 + w, False)
-    tot = {"seconds": 0.0, "nodes": 0, "edges": 0, "spec": 0, "rounds": 0, "nn_ms": 0.0, "nn_bytes": 0, "nn_launches": 0}
+    tot = {"seconds": 0.0, "nodes": 0, "edges": 0, "spec": 0, "rounds": 0, "nn_ms": 0.0, "nn_bytes": 0, "nn_launches": 0,
+           "steer_ms": 0.0, "steer_launches": 0}
     best = float("inf")
     if dist is not None:
         dist.barrier()
@@ -233,6 +238,19 @@ def main():
                                  "speculative batch of queries each, so it is VALU-bound by design (packed-fp32 pre-filter + "
                                  "exact fp64 recheck); see nn_sweep_hbm for the same sweep in its HBM-bound regime"},
         }
+        # the dominant kernels of the timed region (rank 0): the two steer mappings, fp64-VALU / latency bound.
+        # Algorithmic work per propagated edge: 20 RK4 steps x 4 f-evals x ~7.5 k fp64 operations (6 joints)
+        # + 20 proximity tests; the reference's operation order forbids FMA contraction, so the usable peak is one
+        # operation per lane and cycle = half of the 78.6 TFLOP/s FMA figure.
+        if tot["steer_ms"] > 0:
+            ops_per_edge = 20 * 4 * 7.5e3
+            rate = tot["spec"] * ops_per_edge / (tot["steer_ms"] * 1e-3) / 1e12
+            out["steer_kernels"] = {"kernels": "propagate_lane_kernel (large rounds) + propagate_kernel (small rounds)",
+                                    "bound": "fp64_valu_latency", "share_of_step_time": tot["steer_ms"] * 1e-3 / tot["seconds"],
+                                    "avg_round_ms": tot["steer_ms"] / max(1, tot["steer_launches"]),
+                                    "edges_per_s_in_kernel": tot["spec"] / (tot["steer_ms"] * 1e-3),
+                                    "achieved": rate, "peak": 39.3, "unit": "Tops/s (fp64, no FMA)", "frac": rate / 39.3,
+                                    "note": "f-eval operations only (proximity excluded); rank-0 launches of the timed region"}
         if not args.no_microbench:
             out["nn_sweep_hbm"] = nn_sweep_microbench(lib, ctx, events, 4 * 1024 * 1024, 8, 20)
         if not args.no_cpu_baseline:

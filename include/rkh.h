@@ -215,6 +215,8 @@ rkh_status rkh_prm_get_graph(rkh_prm* p, uint32_t problem, double* pos, uint32_t
 /* With RKH_PROFILE_NN=1 in the environment at rkh_planner_create, every round brackets its NN sweep kernel with
  * HIP events on the planner stream: total kernel time, algorithmic bytes (n*D*8 per sweep) and launch count. */
 rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* total_bytes, uint64_t* launches);
+/* Same switch: HIP events around the steer launches (both kernel mappings) of every round: total time, rounds. */
+rkh_status rkh_planner_steer_profile(rkh_planner* p, double* total_ms, uint64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -273,6 +273,7 @@ struct rkh_planner {
   // optional HIP-event timing of the NN sweep kernel (RKH_PROFILE_NN=1)
   bool profile_nn = false;
   std::vector<hipEvent_t> ev;  // pairs
+  std::vector<hipEvent_t> ev_steer;  // pairs around the steer launches of the same rounds
   uint32_t prof_rounds = 0;
   static constexpr uint32_t kProfMax = 8192;
 };
@@ -365,6 +366,13 @@ rkh_status enqueue_round(rkh_planner* p) {
     }
     ev0 = p->ev[2 * slot];
     ev1 = p->ev[2 * slot + 1];
+    if (p->ev_steer.size() < 2 * size_t(slot + 1)) {
+      hipEvent_t a, b;
+      RKH_HIP(hipEventCreate(&a));
+      RKH_HIP(hipEventCreate(&b));
+      p->ev_steer.push_back(a);
+      p->ev_steer.push_back(b);
+    }
   }
   // launch sizes of this round from the host-side bounds
   uint32_t batch_ub = 1;
@@ -383,8 +391,10 @@ rkh_status enqueue_round(rkh_planner* p) {
                              p->coord_bound);
   if (st != RKH_OK) return st;
   // 2. speculative steer of all candidates + the goal probes of the vertices the previous round committed
+  if (ev0) (void)hipEventRecord(p->ev_steer[2 * slot], s);
   st = launch_edges(p, batch_ub, probe_ub, p->d_io_steer, p->d_io_probe);
   if (st != RKH_OK) return st;
+  if (ev0) (void)hipEventRecord(p->ev_steer[2 * slot + 1], s);
   // 3. fix-up against the vertices this round itself would add
   switch (p->DP) {
     case 2: launch_fixup<2>(p, batch_ub); break;
@@ -658,6 +668,7 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   (void)hipFree(p->d_lane_ws);
   (void)hipFree(p->d_sel);
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->ev_steer) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(p->stream);
   delete p;
   return RKH_OK;
@@ -684,6 +695,21 @@ rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* to
     RKH_HIP(hipEventElapsedTime(&ms, p->ev[2 * r], p->ev[2 * r + 1]));
     *total_ms += ms;
     *total_bytes += rows[r] * p->DP * sizeof(double);  // algorithmic bytes of one launch: sum over problems of n * D * 8
+    *launches += 1;
+  }
+  return RKH_OK;
+}
+
+rkh_status rkh_planner_steer_profile(rkh_planner* p, double* total_ms, uint64_t* launches) {
+  if (!p || !total_ms || !launches) return RKH_ERR_BAD_ARG;
+  *total_ms = 0.0;
+  *launches = 0;
+  if (!p->profile_nn || p->prof_rounds == 0) return RKH_OK;
+  RKH_HIP(hipStreamSynchronize(p->stream));
+  for (uint32_t r = 0; r < p->prof_rounds; ++r) {
+    float ms = 0.f;
+    RKH_HIP(hipEventElapsedTime(&ms, p->ev_steer[2 * r], p->ev_steer[2 * r + 1]));
+    *total_ms += ms;
     *launches += 1;
   }
   return RKH_OK;
