@@ -440,6 +440,10 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
                                         const rkh_rrt_params* prms, uint32_t n_problems, rkh_planner** out) {
   if (!scene || (!space && !qspace) || !prms || !out || n_problems < 1) return RKH_ERR_BAD_ARG;
   const int space_dof = space ? space->n_dof : qspace->n_dof;
+  if (space && scene->host.n_branches > 0) {
+    set_error("rkh_planner_create: the dynamics kernels support a single serial chain (use the quasi-static space)");
+    return RKH_ERR_UNSUPPORTED;
+  }
   if (space_dof != scene->host.n_dof) {
     set_error("rkh_planner_create: the space's n_dof does not match the scene");
     return RKH_ERR_BAD_ARG;

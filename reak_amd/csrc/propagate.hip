@@ -69,6 +69,23 @@ struct BlockLds {
   GroupWs<N> g[64 / GL];
 };
 
+// the quasi-static kernels (edge walk, distance query) only need what the proximity test touches
+template <int N>
+struct __attribute__((aligned(16))) GroupWsQs {
+  double x[2 * N];
+  double tmp[2 * N];
+  double cs[N][4];
+  double Epos[N][3], Equat[N][4];
+  double Rpos[2 * N][3], Rquat[2 * N][4];
+};
+template <int N, int GL>
+struct BlockLdsQs {
+  JointLds joints[N];
+  double base[10];
+  double sink[64][4];
+  GroupWsQs<N> g[64 / GL];
+};
+
 RKH_DI d3 ld3(const double* p) { return d3{p[0], p[1], p[2]}; }
 RKH_DI d4 ld4(const double* p) { return d4{p[0], p[1], p[2], p[3]}; }
 RKH_DI void st3(double* p, d3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
@@ -384,18 +401,18 @@ __device__ double state_derivative(const SceneDev* __restrict__ sc_beam, const C
 // With cull_positive, pairs whose bounding spheres are apart are skipped (they cannot make the verdict
 // "colliding"; proxy_query_model.cpp:386-389 culls the same way against the running minimum) and the scan
 // stops once every edge of the wave has met a negative distance.
-template <int N, int GL>
+template <int N, int GL, typename WS>
 __device__ double proximity_min(const SceneDev* __restrict__ sc, const CPack<N>& cp,
                                 const double* __restrict__ base, const ShapeDev* __restrict__ env_lds,
-                                const PairDev* __restrict__ pairs, int n_pairs, GroupWs<N>& ws,
+                                const PairDev* __restrict__ pairs, int n_pairs, WS& ws,
                                 double* __restrict__ sink, int gl, int gb, bool cull_positive, bool group_done) {
   const bool lead = (gl == 0);
-  // half-angle sin/cos by lanes 2j
-  if (gl < 2 * N && !(gl & 1)) {
+  // half-angle sin/cos, one joint per lane (strided: a 16-lane group may carry more than 16 / 2 joints)
+  for (int jj = gl; jj < N; jj += GL) {
     double sn, cs;
-    sincos(0.5 * ws.x[gl], &sn, &cs);
-    ws.cs[gl >> 1][0] = cs;
-    ws.cs[gl >> 1][1] = sn;
+    sincos(0.5 * ws.x[2 * jj], &sn, &cs);
+    ws.cs[jj][0] = cs;
+    ws.cs[jj][1] = sn;
   }
   __syncthreads();
   {  // revolute_joint_3D / rigid_link_3D kinematics, position + orientation only
@@ -404,6 +421,11 @@ __device__ double proximity_min(const SceneDev* __restrict__ sc, const CPack<N>&
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       const int jb = j * 32;
+      if (sc->branch_start[j]) {  // a new branch: base frame * mount pose (rigid_link_3D::doMotion from frame 0)
+        const d4 bq = ld4(base + 3);
+        pos = ld3(base) + mul(rotmat(bq), ld3(sc->mount_pos[j]));
+        Q = qmul(bq, ld4(sc->mount_quat[j]));
+      }
       const d3 axis_n = cget3(cp, jb + JC_AXISN);
       const double c2 = ws.cs[j][0], s2 = ws.cs[j][1];
       const d4 tq = d4{c2, axis_n.x * s2, axis_n.y * s2, axis_n.z * s2};
@@ -487,6 +509,11 @@ RKH_DI double group_norm(GroupWs<N>& ws, double diff, int gl) {
   return sqrt(s);
 }
 
+template <int N, int GL>
+struct SmemLayoutQs {
+  static constexpr size_t block_bytes = (sizeof(BlockLdsQs<N, GL>) + 15) / 16 * 16;
+  static size_t bytes(int n_env) { return block_bytes + size_t(n_env) * sizeof(ShapeDev); }
+};
 template <int N, int GL>
 struct SmemLayout {
   static constexpr size_t block_bytes = (sizeof(BlockLds<N, GL>) + 15) / 16 * 16;
@@ -681,8 +708,8 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
                                                             const EdgeIO* __restrict__ tab_b, uint32_t grid_a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int GL = 16, G = 4;
-  BlockLds<N, GL>& lds = *reinterpret_cast<BlockLds<N, GL>*>(smem_raw);
-  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayout<N, GL>::block_bytes);
+  BlockLdsQs<N, GL>& lds = *reinterpret_cast<BlockLdsQs<N, GL>*>(smem_raw);
+  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayoutQs<N, GL>::block_bytes);
   const bool group_b = blockIdx.x >= grid_a;
   const EdgeIO io = tab_a ? (group_b ? tab_b[blockIdx.y] : tab_a[blockIdx.y]) : (group_b ? io_b : io_a);
   const uint32_t B = io.d_B ? *io.d_B : io.B;
@@ -692,14 +719,14 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
   const int g = lane / GL, gl = lane % GL, gb = g * GL;
   stage_chain<N>(sc, lds.joints, lds.base, lane);
   stage_env(sc, env_lds, lane);
-  GroupWs<N>& ws = lds.g[g];
+  GroupWsQs<N>& ws = lds.g[g];
   const uint32_t si = io.src_idx ? io.src_idx[e] : ((io.d_src_first ? *io.d_src_first : 0u) + e);
   const uint64_t trow = io.tgt_idx ? uint64_t(io.tgt_idx[e]) : ((io.d_tgt_off ? uint64_t(*io.d_tgt_off) : 0ull) + e);
   const double a_d = (gl < N) ? io.src[uint64_t(si) * io.src_stride + gl] : 0.0;
   const double b_d = (gl < N) ? io.tgt[trow * io.tgt_stride + gl] : 0.0;
   const double lo = (gl < N) ? qs.lower[gl] : 0.0;
   const double hi = (gl < N) ? qs.upper[gl] : 0.0;
-  if (gl < 2 * N) ws.x[gl] = 0.0;  // velocities stay zero (apply_to_model writes positions only)
+  for (int t = gl; t < 2 * N; t += GL) ws.x[t] = 0.0;  // velocities stay zero (apply_to_model writes positions only)
   __syncthreads();
   const CPack<N> cp = load_cpack<N>(lds.joints, lane);
 
@@ -867,15 +894,15 @@ __global__ __launch_bounds__(64) void min_distance_kernel(const SceneDev* __rest
                                                            int n_pairs, const double* __restrict__ x, uint32_t B,
                                                            double* __restrict__ dist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  BlockLds<N, 64>& lds = *reinterpret_cast<BlockLds<N, 64>*>(smem_raw);
-  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayout<N, 64>::block_bytes);
+  BlockLdsQs<N, 64>& lds = *reinterpret_cast<BlockLdsQs<N, 64>*>(smem_raw);
+  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayoutQs<N, 64>::block_bytes);
   const uint32_t e = blockIdx.x;
   if (e >= B) return;
   const int lane = threadIdx.x;
   constexpr int D = 2 * N;
   stage_chain<N>(sc, lds.joints, lds.base, lane);
   stage_env(sc, env_lds, lane);
-  GroupWs<N>& ws = lds.g[0];
+  GroupWsQs<N>& ws = lds.g[0];
   if (lane < D) ws.x[lane] = x[uint64_t(e) * D + lane];
   __syncthreads();
   const CPack<N> cp = load_cpack<N>(lds.joints, lane);
@@ -892,6 +919,18 @@ __global__ __launch_bounds__(64) void min_distance_kernel(const SceneDev* __rest
     case 6: { constexpr int N = 6; CALL; } break; \
     default:                         \
       set_error("propagate: chains with this number of joints are not instantiated (1,2,3,6)"); \
+      return RKH_ERR_UNSUPPORTED;    \
+  }
+
+#define RKH_DISPATCH_N_QS(N_, CALL)  \
+  switch (N_) {                      \
+    case 1: { constexpr int N = 1; CALL; } break; \
+    case 2: { constexpr int N = 2; CALL; } break; \
+    case 3: { constexpr int N = 3; CALL; } break; \
+    case 6: { constexpr int N = 6; CALL; } break; \
+    case 12: { constexpr int N = 12; CALL; } break; \
+    default:                         \
+      set_error("quasi-static kernels: chains with this number of joints are not instantiated (1,2,3,6,12)"); \
       return RKH_ERR_UNSUPPORTED;    \
   }
 
@@ -946,8 +985,8 @@ rkh_status launch_edge_check(hipStream_t s, int n_dof, int n_env, const SceneDev
   if (grid_edges + eb == 0 || n_problems == 0) return RKH_OK;
   const EdgeIO second = io_b ? *io_b : EdgeIO();
   const PairDev* pp = static_cast<const PairDev*>(d_pairs);
-  RKH_DISPATCH_N(n_dof, hipLaunchKernelGGL((edge_check_kernel<N>), dim3(grid_edges + eb, n_problems), dim3(64),
-                                           (SmemLayout<N, 16>::bytes(n_env)), s, d_scene, pp, n_pairs, qs, io, second, tab_a,
+  RKH_DISPATCH_N_QS(n_dof, hipLaunchKernelGGL((edge_check_kernel<N>), dim3(grid_edges + eb, n_problems), dim3(64),
+                                           (SmemLayoutQs<N, 16>::bytes(n_env)), s, d_scene, pp, n_pairs, qs, io, second, tab_a,
                                            tab_b, grid_edges));
   RKH_HIP(hipGetLastError());
   return RKH_OK;
@@ -966,7 +1005,7 @@ rkh_status launch_feval_cycles(hipStream_t s, int n_dof, int n_env, const SceneD
 rkh_status launch_min_distance(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs, int n_pairs,
                                const double* d_x, uint32_t B, double* d_dist) {
   if (B == 0) return RKH_OK;
-  RKH_DISPATCH_N(n_dof, hipLaunchKernelGGL((min_distance_kernel<N>), dim3(B), dim3(64), (SmemLayout<N, 64>::bytes(n_env)), s,
+  RKH_DISPATCH_N_QS(n_dof, hipLaunchKernelGGL((min_distance_kernel<N>), dim3(B), dim3(64), (SmemLayoutQs<N, 64>::bytes(n_env)), s,
                                            d_scene, static_cast<const PairDev*>(d_pairs), n_pairs, d_x, B, d_dist));
   RKH_HIP(hipGetLastError());
   return RKH_OK;

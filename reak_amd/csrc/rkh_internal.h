@@ -22,7 +22,7 @@ void set_error(const std::string& msg);
     }                                                                                          \
   } while (0)
 
-constexpr int kMaxDof = 8;          // HIP kernels are instantiated for 1..kMaxDof revolute joints
+constexpr int kMaxDof = 12;         // joints of a scene (dynamics kernels: 1, 2, 3, 6; quasi-static kernels also 12)
 constexpr int kMaxEnvShapes = 256;  // environment shapes resident in LDS
 constexpr int kMaxSteps = 64;       // RK4 steps per edge
 
@@ -123,6 +123,13 @@ struct SceneDev {
   // position) and its radius; one bit per shape and kind (sphere, box, capped cylinder) in chunks of 64 shapes
   double env_cull[kMaxEnvShapes][4];
   unsigned long long env_kind_mask[3][kMaxEnvShapes / 64];
+  // Branching (quasi-static kernels only): joint j with branch_start[j] != 0 does not continue the previous link but
+  // starts from the chain base through a fixed mount (rigid_link_3D from frame 0; identity if the joint sits on the base)
+  int32_t branch_start[kMaxDof];
+  int32_t n_branches;  // joints with branch_start (0 for a plain serial chain)
+  int32_t pad2;
+  double mount_pos[kMaxDof][3];
+  double mount_quat[kMaxDof][4];
   // flexible_beam_3D (flexible_beam.cpp:155-193): rest length, stiffness, torsion stiffness, world anchor pose
   double beam_rest, beam_k, beam_kt;
   double beam_pos[3], beam_quat[4];

@@ -77,14 +77,34 @@ extern "C" {
 rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, const rkh_chain_base* base,
                             const rkh_shape* shapes, int n_shapes, rkh_scene** out) {
   if (!ctx || !prog || !base || !out || n_ops < 1 || (n_shapes > 0 && !shapes)) return RKH_ERR_BAD_ARG;
-  const bool has_beam = (n_ops % 5 == 1) && prog[n_ops - 1].kind == RKH_KTE_FLEXIBLE_BEAM_3D;
+  const bool has_beam = n_ops > 1 && prog[n_ops - 1].kind == RKH_KTE_FLEXIBLE_BEAM_3D;
   if (has_beam) --n_ops;  // the beam is validated below, after the chain
-  if (n_ops % 5 != 0 || n_ops / 5 > kMaxDof || n_ops < 5) {
-    set_error("rkh_scene_create: KTE program is not a serial chain of {actuator, inertia_gen, revolute, link, inertia_3D} "
-              "groups (optionally followed by one flexible_beam_3D)");
-    return RKH_ERR_UNSUPPORTED;
+  // parse: [optional mount link from frame 0] {actuator, inertia_gen, revolute, link, inertia_3D} ...
+  struct Group { int first_op; int mount_op; };
+  std::vector<Group> groups;
+  {
+    int k = 0;
+    while (k < n_ops) {
+      Group g{0, -1};
+      if (prog[k].kind == RKH_KTE_RIGID_LINK_3D && prog[k].base_frame == 0) {
+        g.mount_op = k;
+        ++k;
+      }
+      g.first_op = k;
+      if (k + 5 > n_ops) {
+        k = -1;
+        break;
+      }
+      groups.push_back(g);
+      k += 5;
+    }
+    if (k < 0 || groups.empty() || int(groups.size()) > kMaxDof) {
+      set_error("rkh_scene_create: KTE program is not a chain of [mount link] {actuator, inertia_gen, revolute, link, "
+                "inertia_3D} groups (optionally followed by one flexible_beam_3D), or has too many joints");
+      return RKH_ERR_UNSUPPORTED;
+    }
   }
-  const int n = n_ops / 5;
+  const int n = int(groups.size());
   rkh_scene* sc = new rkh_scene();
   sc->ctx = ctx;
   SceneDev& S = sc->host;
@@ -98,18 +118,40 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
   std::vector<int> joint_end_frame(n), link_end_frame(n);
   int prev_end = 0;  // frame 0 = chain base
   bool first = true;
+  int branch_first = 0;  // first joint of the current branch
   for (int j = 0; j < n; ++j) {
-    const rkh_kte_op& act = prog[5 * j], &gen = prog[5 * j + 1], &rev = prog[5 * j + 2], &lnk = prog[5 * j + 3],
-                     &ine = prog[5 * j + 4];
+    const int k0 = groups[j].first_op;
+    const rkh_kte_op& act = prog[k0], &gen = prog[k0 + 1], &rev = prog[k0 + 2], &lnk = prog[k0 + 3], &ine = prog[k0 + 4];
+    bool starts_branch = false;
+    int expect_base = prev_end;
+    if (groups[j].mount_op >= 0) {  // a rigid link from the chain base carries this joint
+      const rkh_kte_op& mt = prog[groups[j].mount_op];
+      starts_branch = true;
+      expect_base = mt.end_frame;
+      for (int i = 0; i < 3; ++i) S.mount_pos[j][i] = mt.offset.pos[i];
+      for (int i = 0; i < 4; ++i) S.mount_quat[j][i] = mt.offset.quat[i];
+    } else if (!first && rev.base_frame == 0) {  // a second chain sitting directly on the base
+      starts_branch = true;
+      expect_base = 0;
+      S.mount_quat[j][0] = 1.0;
+    } else {
+      S.mount_quat[j][0] = 1.0;
+    }
+    if (starts_branch) {
+      S.branch_start[j] = 1;
+      ++S.n_branches;
+      branch_first = j;
+    }
+    const uint32_t branch_mask = ((j + 1 >= 32 ? 0xFFFFFFFFu : ((1u << (j + 1)) - 1u))) & ~((1u << branch_first) - 1u);
     const bool ok = act.kind == RKH_KTE_DRIVING_ACTUATOR_GEN && gen.kind == RKH_KTE_INERTIA_GEN &&
                     rev.kind == RKH_KTE_REVOLUTE_JOINT_3D && lnk.kind == RKH_KTE_RIGID_LINK_3D &&
                     ine.kind == RKH_KTE_INERTIA_3D && act.coord == j && gen.coord == j && rev.coord == j &&
-                    act.joint_op == 5 * j + 2 && gen.upstream == (1u << j) &&
-                    (first ? rev.base_frame == 0 : rev.base_frame == prev_end) && lnk.base_frame == rev.end_frame &&
-                    ine.end_frame == lnk.end_frame && ine.upstream == ((1u << (j + 1)) - 1u);
+                    act.joint_op == k0 + 2 && gen.upstream == (1u << j) &&
+                    (first && groups[j].mount_op < 0 ? rev.base_frame == 0 : rev.base_frame == expect_base) &&
+                    lnk.base_frame == rev.end_frame && ine.end_frame == lnk.end_frame && ine.upstream == branch_mask;
     if (!ok) {
       delete sc;
-      set_error("rkh_scene_create: op group " + std::to_string(j) + " does not match the serial-chain pattern");
+      set_error("rkh_scene_create: op group " + std::to_string(j) + " does not match the chain pattern");
       return RKH_ERR_UNSUPPORTED;
     }
     first = false;
@@ -137,7 +179,7 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
   }
   if (has_beam) {
     const rkh_kte_op& bm = prog[n_ops];
-    if (bm.base_frame != link_end_frame[n - 1] || bm.end_frame != -1) {
+    if (bm.base_frame != link_end_frame[n - 1] || bm.end_frame != -1 || S.n_branches > 0) {
       delete sc;
       set_error("rkh_scene_create: the flexible beam must tie the last link's end frame to a world anchor (end_frame = -1)");
       return RKH_ERR_UNSUPPORTED;
@@ -245,6 +287,13 @@ struct DevBuf {  // scoped device scratch
   ~DevBuf() { if (p) hipFree(p); }
   template <typename T> T* as() { return static_cast<T*>(p); }
 };
+rkh_status reject_branches(const rkh_scene* scene) {  // the dynamics kernels assume one serial chain
+  if (scene->host.n_branches > 0) {
+    set_error("dynamics kernels support a single serial chain; this scene has branches (quasi-static entry points only)");
+    return RKH_ERR_UNSUPPORTED;
+  }
+  return RKH_OK;
+}
 rkh_status check_err_flag(rkh_scene* scene) {
   int flag = 0;
   RKH_HIP(hipMemcpy(&flag, scene->d_err, sizeof(int), hipMemcpyDeviceToHost));
@@ -261,6 +310,7 @@ extern "C" {
 
 rkh_status rkh_state_derivative(rkh_scene* scene, const double* x, const double* u, uint32_t B, double* pd, double* M,
                                 double* f) {
+  if (scene && reject_branches(scene) != RKH_OK) return RKH_ERR_UNSUPPORTED;
   if (!scene || !x || !u || !pd) return RKH_ERR_BAD_ARG;
   if (B == 0) return RKH_OK;
   const int n = scene->host.n_dof;
@@ -302,6 +352,7 @@ rkh_status rkh_min_distance(rkh_scene* scene, const double* x, uint32_t B, doubl
 
 rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const double* a, const double* b, uint32_t B,
                          double fraction, double* x_out, uint32_t* steps_free, double* record) {
+  if (scene && reject_branches(scene) != RKH_OK) return RKH_ERR_UNSUPPORTED;
   if (!scene || !space || !a || !b || !x_out || !steps_free) return RKH_ERR_BAD_ARG;
   if (space->n_dof != scene->host.n_dof) {
     set_error("rkh_propagate: rkh_dyn_space.n_dof does not match the scene");
@@ -352,6 +403,7 @@ rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const dou
 
 rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double* u, uint32_t B, int iters,
                                  uint64_t* cycles) {
+  if (scene && reject_branches(scene) != RKH_OK) return RKH_ERR_UNSUPPORTED;
   if (!scene || !x || !u || !cycles || B == 0) return RKH_ERR_BAD_ARG;
   const int n = scene->host.n_dof;
   hipStream_t s = scene->ctx->stream;

@@ -252,3 +252,75 @@ def make_c3(world_seed=1, min_interval=0.05):
                    start=np.zeros(n), goal=np.array([1.5, 0.9, -0.8, 0.5, 0.7, -0.3]),
                    meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi), "min_interval": min_interval})
     return scn
+
+
+def make_c4(world_seed=1, n_obstacles=200, capsule_radius=0.05, mount_y=0.35, min_interval=0.05):
+    """BASELINE config C4 (kinematic part): 12-DOF dual arm -- two CRS-like 6-R arms on fixed mounts (rigid links from
+    the chain base) at y = -/+ mount_y -- and 200 convex obstacles, planned in the quasi-static joint space (PRM).
+    The reference's proximity module has closed-form pairs only (no meshes / GJK), so the obstacles are its spheres,
+    boxes and capped cylinders; the flexible beam of C4 is a force element and plays no role in a quasi-static space."""
+    rng = np.random.Generator(np.random.PCG64(4000 + world_seed))
+    axes, lengths, offsets, masses, inertias, joint_inertias = crs_like_chain()
+    n1 = len(axes)
+    ops, shapes = [], []
+    frame = 1  # frame 0 = chain base
+    for arm in range(2):
+        mount = T.KteOp(kind=T.KTE_RIGID_LINK_3D, coord=-1, base_frame=0, end_frame=frame, joint_op=-1)
+        mount.offset = T.make_pose((0.0, (-1.0 if arm == 0 else 1.0) * mount_y, 0.0))
+        ops.append(mount)
+        prev = frame
+        frame += 1
+        c0 = arm * n1
+        for j in range(n1):
+            c = c0 + j
+            k0 = len(ops)
+            ops.append(T.KteOp(kind=T.KTE_DRIVING_ACTUATOR_GEN, coord=c, base_frame=-1, end_frame=-1, joint_op=k0 + 2))
+            ops.append(T.KteOp(kind=T.KTE_INERTIA_GEN, coord=c, base_frame=-1, end_frame=-1, joint_op=-1, upstream=(1 << c),
+                               mass=float(joint_inertias[j])))
+            r = T.KteOp(kind=T.KTE_REVOLUTE_JOINT_3D, coord=c, base_frame=prev, end_frame=frame, joint_op=-1)
+            r.axis[:] = [float(v) for v in axes[j]]
+            ops.append(r)
+            l = T.KteOp(kind=T.KTE_RIGID_LINK_3D, coord=-1, base_frame=frame, end_frame=frame + 1, joint_op=-1)
+            l.offset = T.make_pose(offsets[j])
+            ops.append(l)
+            i3 = T.KteOp(kind=T.KTE_INERTIA_3D, coord=-1, base_frame=-1, end_frame=frame + 1, joint_op=-1,
+                         upstream=((1 << (c + 1)) - 1) & ~((1 << c0) - 1), mass=float(masses[j]))
+            i3.inertia[:] = [float(v) for v in inertias[j]]
+            ops.append(i3)
+            s = T.Shape(kind=T.SHAPE_CCYLINDER, anchor=frame)  # link capsule on the joint's end frame
+            s.pose = T.make_pose((0.0, 0.0, 0.5 * lengths[j]))
+            s.dims[:] = [lengths[j], capsule_radius, 0.0]
+            shapes.append(s)
+            prev = frame + 1
+            frame += 2
+    base = T.ChainBase()
+    base.pose = T.make_pose()
+    base.acceleration[:] = [0.0, 0.0, 9.81]
+    # environment: spheres / boxes / capsules around both arms, clear of the upright start poses
+    tops = [np.array([0.0, -mount_y, sum(lengths)]), np.array([0.0, mount_y, sum(lengths)])]
+    roots = [np.array([0.0, -mount_y, 0.0]), np.array([0.0, mount_y, 0.0])]
+    kinds = []
+    while len(kinds) < n_obstacles:
+        kind = [T.SHAPE_SPHERE, T.SHAPE_BOX, T.SHAPE_CCYLINDER][int(rng.integers(0, 3))]
+        center = rng.uniform([-1.0, -1.4, 0.0], [1.0, 1.4, 1.4])
+        s = T.Shape(kind=kind, anchor=-1)
+        if kind == T.SHAPE_SPHERE:
+            s.dims[:] = [rng.uniform(0.05, 0.15), 0.0, 0.0]
+            brad = s.dims[0]
+        elif kind == T.SHAPE_BOX:
+            s.dims[:] = list(rng.uniform(0.06, 0.24, size=3))
+            brad = 0.5 * float(np.linalg.norm([s.dims[0], s.dims[1], s.dims[2]]))
+        else:
+            s.dims[:] = [rng.uniform(0.1, 0.3), rng.uniform(0.03, 0.08), 0.0]
+            brad = 0.5 * s.dims[0] + s.dims[1]
+        if min(_dist_point_segment(center, roots[a], tops[a]) for a in range(2)) < brad + capsule_radius + 0.12:
+            continue
+        s.pose = T.make_pose(center, _random_unit_quat(rng))
+        shapes.append(s)
+        kinds.append(kind)
+    n = 2 * n1
+    goal = np.array([1.2, 0.8, -0.7, 0.4, 0.6, -0.3, -1.0, 0.7, -0.9, -0.5, 0.5, 0.4])
+    return Scenario(name="C4", ops=ops, base=base, shapes=shapes, dyn=None, n_dof=n, n_frames=frame,
+                    start=np.zeros(n), goal=goal,
+                    meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi), "min_interval": min_interval,
+                          "world_seed": world_seed, "n_obstacles": n_obstacles, "obstacle_kinds": kinds})

@@ -497,3 +497,39 @@ def test_knn_degenerate_requests(L, ctx, oracle):
     assert np.array_equal(idx[:, :5], ridx[:, :5]) and np.array_equal(dist[:, :5], rdist[:, :5])
     idx, dist, cnt = nn.k_nearest(q, 3, radius=1e-9)          # nothing inside the radius
     assert np.all(cnt == 0)
+
+
+# ------------------------------------------------------------------ C4: 12-DOF dual arm (branching chain), 200 obstacles
+def test_c4_dual_arm_quasi_static(L, ctx, oracle):
+    """Two 6-R arms on fixed mounts of one base (rigid links from the chain base), 200 obstacles, 12-D quasi-static space:
+    distance queries, edge walks, RRT and PRM against the oracle (whose KTE interpreter handles the branching natively)."""
+    c4 = scenarios.make_c4(world_seed=1)
+    sc, osc = L.Scene(ctx, c4), oracle.OracleScene(c4)
+    lo, hi, mi = c4.meta["lower"], c4.meta["upper"], c4.meta["min_interval"]
+    rng = np.random.default_rng(44)
+    q = rng.uniform(lo, hi, size=(200, 12))
+    x = np.zeros((200, 24)); x[:, 0::2] = q
+    d, rd = sc.min_distance(x), osc.min_distance(x)
+    assert np.allclose(d, rd, atol=1e-12)
+    far = np.abs(rd) > 1e-12
+    assert np.array_equal((d < 0)[far], (rd < 0)[far]) and 0.05 < (rd < 0).mean() < 0.95
+    a = q[rd > 0.0][:96]
+    b = rng.uniform(lo, hi, size=(a.shape[0], 12))
+    out, nchk = sc.move_position_toward(lo, hi, mi, a, b, fraction=1.0)
+    rout, rnchk = osc.qs_move(lo, hi, mi, a, b, fraction=1.0)
+    assert np.array_equal(nchk, rnchk) and np.array_equal(out, rout)
+    qs = L.make_qs_space(12, lo, hi, mi)
+    prm = c4.rrt_params(seed=1, max_vertices=300)
+    rc, ro, rtree = osc.rrt_qs(lo, hi, mi, prm)
+    pl = L.RrtPlanner(sc, prm, qs=qs)
+    st = pl.solve_planning_query()
+    assert (st.num_vertices, st.iterations, st.edges_checked) == (ro.num_vertices, ro.iterations, ro.edges_checked)
+    assert np.array_equal(pl.tree()["parent"], rtree["parent"]) and np.array_equal(pl.tree()["pos"], rtree["pos"])
+    pp = c4.prm_params(seed=2, max_vertices=200, sampling_radius=1.5)
+    rc, ro, rg = osc.prm_qs(lo, hi, mi, pp)
+    pm = L.PrmPlanner(sc, pp, qs)
+    st = pm.solve_planning_query()
+    _prm_same(st, pm.graph(), ro, rg)
+    # the dynamics entry points refuse a branching scene
+    with pytest.raises(Exception):
+        sc.state_derivative(np.zeros((1, 24)), np.zeros((1, 12)))
