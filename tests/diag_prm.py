@@ -6,13 +6,13 @@ import oracle_lib as O
 from reak_amd import lib as L, scenarios as S
 
 ctx = L.Context(0)
-for name, mk, nd, mv in (("C1", S.make_c1, 3, 3000), ("C3", S.make_c3, 6, 3000)):
+for name, mk, nd, mv in (("C1", S.make_c1, 3, 3000), ("C3", S.make_c3, 6, 3000), ("C4", S.make_c4, 12, 2000)):
     scn = mk()
     sc = L.Scene(ctx, scn)
     lo, hi, mi = scn.meta["lower"], scn.meta["upper"], scn.meta["min_interval"]
     qs = L.make_qs_space(nd, lo, hi, mi)
     for P in (1, 16, 64):
-        prms = [scn.prm_params(seed=1 + i, max_vertices=mv, sampling_radius=1.0) for i in range(P)]
+        prms = [scn.prm_params(seed=1 + i, max_vertices=mv, sampling_radius=(1.5 if nd == 12 else 1.0)) for i in range(P)]
         pl = L.PrmPlanner(sc, prms, qs)
         t0 = time.time(); pl.solve_planning_query(); dt = time.time() - t0
         it = sum(int(s.loop_iterations) for s in pl.all_stats); ed = sum(int(s.edges_checked) for s in pl.all_stats)
