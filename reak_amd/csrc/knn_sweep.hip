@@ -29,14 +29,21 @@ int nn_padded_dims(int D);
 
 static constexpr int kTileRows = 256;
 static constexpr int kThreads = 256;
-static constexpr int kQB = 32;               // queries per block
-static constexpr int kR = kThreads / kQB;    // row subsets per block
+static constexpr int kSelMax = 8;  // a block contributes the ksel <= 8 smallest of its row-subset minima per query
 
-// MODE 0: bound sweep (writes per-thread subset minima).  MODE 1: collect sweep (appends candidates).
-template <int DP, int MODE>
+static inline int knn_query_block(uint32_t B) { return B <= 8 ? 8 : 32; }  // queries per block
+
+// MODE 0: bound sweep (per query, the kSel smallest of the block's R = 256/QB row-subset minima).
+// MODE 1: collect sweep (appends candidates).
+// Thread (ql, r) keeps query ql in registers and scans rows r, r+R, .. of every tile; with few queries (RRT* / PRM:
+// one per tree) QB = 8 puts 32 threads on each query so the whole block works on the rows.  The next tile is fetched
+// into registers while the current one is scanned (as in nn_sweep.hip).
+template <int DP, int QB, int MODE>
 __global__ __launch_bounds__(kThreads) void knn_sweep_kernel(KnnArgs single, const KnnArgs* __restrict__ tab) {
+  constexpr int R = kThreads / QB;
+  constexpr int ROWS_PER_THREAD = kTileRows / R;
   const KnnArgs a = tab ? tab[blockIdx.z] : single;
-  if (blockIdx.x >= a.ws.gx || blockIdx.y * kQB >= a.B) return;  // a table's grid is sized for its largest job
+  if (blockIdx.x >= a.ws.gx || blockIdx.y * QB >= a.B) return;  // a table's grid is sized for its largest job
   const double* __restrict__ pos = a.pos;
   const uint64_t n = a.n;
   const double* __restrict__ q = a.q;
@@ -50,12 +57,12 @@ __global__ __launch_bounds__(kThreads) void knn_sweep_kernel(KnnArgs single, con
   uint32_t* __restrict__ cand_i = a.ws.cand_i;
   uint32_t* __restrict__ overflow = a.ws.overflow;
   const uint32_t gx = a.ws.gx;
-  constexpr int ROWS_PER_THREAD = kTileRows / kR;
   __shared__ __attribute__((aligned(16))) double tile[kTileRows * DP];
+  __shared__ double red[kThreads];
   const int tid = threadIdx.x;
-  const int ql = tid % kQB;
-  const int r = tid / kQB;
-  const uint32_t qi = blockIdx.y * kQB + ql;
+  const int ql = tid % QB;
+  const int r = tid / QB;
+  const uint32_t qi = blockIdx.y * QB + ql;
   const bool q_valid = qi < B;
   double qv[DP];
   {
@@ -76,25 +83,33 @@ __global__ __launch_bounds__(kThreads) void knn_sweep_kernel(KnnArgs single, con
     // squares above this cannot give sqrt(s) <= tau (4 ulp of slack for the rounding of tau*tau and of sqrt)
     thr_s = (t_q == INFINITY) ? INFINITY : (t_q * t_q) * (1.0 + 8.0 * DBL_EPSILON);
   }
+  constexpr int N2 = kTileRows * DP / 2;
+  constexpr int PF = N2 / kThreads;
+  static_assert(N2 % kThreads == 0, "tile must split evenly");
+  double2 pf[PF];
+  auto fetch = [&](uint64_t t) {
+    const uint64_t row_base = t * kTileRows;
+    const double2* src = reinterpret_cast<const double2*>(pos + row_base * DP);
+    const uint64_t valid2 = (n - row_base >= uint64_t(kTileRows)) ? uint64_t(N2) : (n - row_base) * DP / 2;
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int i = tid + j * kThreads;
+      pf[j] = (uint64_t(i) < valid2) ? src[i] : make_double2(INFINITY, INFINITY);  // rows beyond n never qualify
+    }
+  };
+  if (tile0 < tile1) fetch(tile0);
   for (uint64_t t = tile0; t < tile1; ++t) {
     const uint64_t row_base = t * kTileRows;
     {
-      const double2* src = reinterpret_cast<const double2*>(pos + row_base * DP);
       double2* dst = reinterpret_cast<double2*>(tile);
-      constexpr int N2 = kTileRows * DP / 2;
-      const uint64_t valid2 = (n - row_base >= uint64_t(kTileRows)) ? uint64_t(N2) : (n - row_base) * DP / 2;
-#pragma unroll 4
-      for (int i = tid; i < N2; i += kThreads) {
-        double2 v;
-        if (uint64_t(i) < valid2) v = src[i];
-        else v = make_double2(INFINITY, INFINITY);
-        dst[i] = v;
-      }
+#pragma unroll
+      for (int j = 0; j < PF; ++j) dst[tid + j * kThreads] = pf[j];
     }
+    if (t + 1 < tile1) fetch(t + 1);
     __syncthreads();
 #pragma unroll 2
     for (int k = 0; k < ROWS_PER_THREAD; ++k) {
-      const int row = k * kR + r;
+      const int row = k * R + r;
       const double* p = tile + row * DP;
       double df = qv[0] - p[0];
       double s = df * df;
@@ -120,7 +135,21 @@ __global__ __launch_bounds__(kThreads) void knn_sweep_kernel(KnnArgs single, con
     }
     __syncthreads();
   }
-  if (MODE == 0 && q_valid) sub[(uint64_t(blockIdx.x) * kR + r) * Bpad + qi] = sqrt(best_s);
+  if (MODE == 0) {
+    // the ksel smallest of the R subset minima of every query (ranks by (value, subset) are a permutation; any k
+    // disjoint subsets with minimum <= tau prove that k vertices lie within tau, so dropping the larger ones is safe)
+    const double mine = sqrt(best_s);
+    red[tid] = mine;
+    __syncthreads();
+    int rank = 0;
+#pragma unroll 8
+    for (int rr = 0; rr < R; ++rr) {
+      const double v = red[rr * QB + ql];
+      rank += (v < mine || (v == mine && rr < r)) ? 1 : 0;
+    }
+    const int ksel = int(a.ws.ksel);
+    if (q_valid && rank < ksel) sub[(uint64_t(blockIdx.x) * ksel + rank) * Bpad + qi] = mine;
+  }
 }
 
 // bitonic sort of (key, idx) pairs in LDS, ascending lexicographic; n_pow2 elements, blockDim.x threads
@@ -187,11 +216,13 @@ __global__ __launch_bounds__(256) void knn_select_kernel(KnnArgs single, const K
   uint32_t* idx = reinterpret_cast<uint32_t*>(key + c_pow2);
   uint32_t nc = cnt[qi];
   if (nc > cmax) nc = cmax;
-  for (uint32_t i = threadIdx.x; i < c_pow2; i += blockDim.x) {
+  uint32_t n_sort = 1;  // sort only as many slots as there are candidates (power of two, <= c_pow2)
+  while (n_sort < nc) n_sort <<= 1;
+  for (uint32_t i = threadIdx.x; i < n_sort; i += blockDim.x) {
     key[i] = i < nc ? cand_d[uint64_t(qi) * cmax + i] : INFINITY;
     idx[i] = i < nc ? cand_i[uint64_t(qi) * cmax + i] : 0xFFFFFFFFu;
   }
-  bitonic_sort_lds(key, idx, c_pow2);
+  bitonic_sort_lds(key, idx, n_sort);
   const uint32_t found = nc < k ? nc : k;
   for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
     out_idx[uint64_t(qi) * k + i] = i < found ? idx[i] : 0xFFFFFFFFu;
@@ -211,15 +242,22 @@ rkh_status knn_plan(uint64_t n, uint32_t B, uint32_t k, KnnWorkspace* ws, size_t
     set_error("k-NN: k must be in [1, 1024]");
     return RKH_ERR_BAD_ARG;
   }
-  const uint32_t gy = (B + kQB - 1) / kQB;
+  const uint32_t qb = knn_query_block(B);
+  const uint32_t gy = (B + qb - 1) / qb;
   uint64_t tiles = (n + kTileRows - 1) / kTileRows;
   if (tiles < 1) tiles = 1;
   // enough subsets for a tight bound (M >= 4k) and enough blocks to fill the chip, but M <= 4096 (LDS sort)
-  uint64_t gx = std::max<uint64_t>((4ull * k + kR - 1) / kR, 2048 / gy);
+  uint64_t gx = std::max<uint64_t>((4ull * k + kSelMax - 1) / kSelMax, 2048 / gy);
   if (gx > tiles) gx = tiles;
-  if (gx > 4096 / kR) gx = 4096 / kR;
+  if (gx > 4096 / kSelMax) gx = 4096 / kSelMax;
   ws->gx = uint32_t(gx);
-  ws->m_sub = uint32_t(gx) * kR;
+  // about 4k subset minima in total are plenty for a tight bound (the k-th smallest of M minima leaves ~ -M ln(1 - k/M)
+  // candidates); fewer minima = a shorter sort in knn_tau_kernel
+  uint32_t ksel = uint32_t((4ull * k + gx - 1) / gx);
+  if (ksel < 1) ksel = 1;
+  if (ksel > uint32_t(kSelMax)) ksel = kSelMax;
+  ws->ksel = ksel;
+  ws->m_sub = uint32_t(gx) * ksel;
   ws->cmax = std::max<uint32_t>(2048, next_pow2(8 * k));
   if (ws->cmax > 4096) ws->cmax = 4096;
   *bytes = 256 + size_t(ws->m_sub) * B * 8 + size_t(B) * 8 + size_t(B) * 4 + size_t(B) * ws->cmax * 12 + 64;
@@ -245,9 +283,12 @@ template <int DP>
 static void launch_nnk_dp(hipStream_t s, const KnnArgs& single, const KnnArgs* d_tab, uint32_t gx, uint32_t gy,
                           uint32_t b_max, uint32_t m_pow2, uint32_t cmax, uint32_t n_jobs) {
   dim3 grid(gx, gy, n_jobs), block(kThreads);
-  hipLaunchKernelGGL((knn_sweep_kernel<DP, 0>), grid, block, 0, s, single, d_tab);
+  const bool few = knn_query_block(b_max) == 8;
+  if (few) hipLaunchKernelGGL((knn_sweep_kernel<DP, 8, 0>), grid, block, 0, s, single, d_tab);
+  else hipLaunchKernelGGL((knn_sweep_kernel<DP, 32, 0>), grid, block, 0, s, single, d_tab);
   hipLaunchKernelGGL(knn_tau_kernel, dim3(b_max, 1, n_jobs), dim3(256), size_t(m_pow2) * 12, s, single, d_tab);
-  hipLaunchKernelGGL((knn_sweep_kernel<DP, 1>), grid, block, 0, s, single, d_tab);
+  if (few) hipLaunchKernelGGL((knn_sweep_kernel<DP, 8, 1>), grid, block, 0, s, single, d_tab);
+  else hipLaunchKernelGGL((knn_sweep_kernel<DP, 32, 1>), grid, block, 0, s, single, d_tab);
   hipLaunchKernelGGL(knn_select_kernel, dim3(b_max, 1, n_jobs), dim3(256), size_t(cmax) * 12, s, single, d_tab);
 }
 
@@ -287,7 +328,7 @@ rkh_status launch_nnk(hipStream_t s, const NnStore& st, uint64_t n, const double
   a.out_idx = d_idx;
   a.out_dist = d_dist;
   a.out_cnt = d_count;
-  return launch_nnk_any(s, st.D, a, nullptr, ws.gx, (B + kQB - 1) / kQB, B, a.m_pow2, ws.cmax, 1);
+  return launch_nnk_any(s, st.D, a, nullptr, ws.gx, (B + knn_query_block(B) - 1) / knn_query_block(B), B, a.m_pow2, ws.cmax, 1);
 }
 
 rkh_status launch_nnk_table(hipStream_t s, int D, const KnnArgs* d_table, const KnnArgs* h_table, uint32_t n_jobs) {
@@ -301,7 +342,7 @@ rkh_status launch_nnk_table(hipStream_t s, int D, const KnnArgs* d_table, const 
     cmax = std::max(cmax, a.ws.cmax);
   }
   if (b_max == 0) return RKH_OK;
-  return launch_nnk_any(s, D, KnnArgs(), d_table, gx, (b_max + kQB - 1) / kQB, b_max, m_pow2, cmax, n_jobs);
+  return launch_nnk_any(s, D, KnnArgs(), d_table, gx, (b_max + knn_query_block(b_max) - 1) / knn_query_block(b_max), b_max, m_pow2, cmax, n_jobs);
 }
 
 }  // namespace rkh

@@ -64,6 +64,7 @@ struct KnnWorkspace {
   uint32_t* cand_i = nullptr;  // [B][cmax]
   uint32_t* overflow = nullptr;
   uint32_t cmax = 0, m_sub = 0, gx = 0;
+  uint32_t ksel = 8;           // subset minima a block contributes per query (1..8)
 };
 rkh_status knn_plan(uint64_t n, uint32_t B, uint32_t k, KnnWorkspace* ws, size_t* bytes);
 void knn_carve(void* base, uint32_t B, KnnWorkspace* ws);
