@@ -39,6 +39,7 @@ typedef struct rkh_scene rkh_scene;     /* KTE chain + proxy environment on the 
 typedef struct rkh_planner rkh_planner; /* batched RRT driver over a scene */
 typedef struct rkh_rrtstar rkh_rrtstar; /* batched RRT* driver over a scene */
 typedef struct rkh_prm rkh_prm;         /* batched PRM driver over a scene */
+typedef struct rkh_birrt rkh_birrt;     /* batched bidirectional-RRT driver over a scene */
 
 const char* rkh_last_error(void);
 const char* rkh_version(void);
@@ -212,6 +213,24 @@ rkh_status rkh_prm_solve(rkh_prm* p, int64_t max_loop_iterations, rkh_prm_stats*
  * expansion iterations, else 0xFFFFFFFF).  Any pointer may be NULL. */
 rkh_status rkh_prm_get_graph(rkh_prm* p, uint32_t problem, double* pos, uint32_t* edge_u, uint32_t* edge_v,
                              double* edge_w, double* density, uint32_t* cc_root, uint8_t* kind, uint32_t* expanded);
+/* ---- Bidirectional RRT: rrt_planner with BIDIRECTIONAL_PLANNING (the reference's default flag,
+ * ctrl/path_planning/rrt_path_planner.hpp:114) -> generate_bidirectional_rrt (ctrl/graph_alg/rr_tree.hpp:256-317),
+ * joining_vertex_found (planning_visitors.hpp:223-231), two-graph solution registration
+ * (solution_path_factories.hpp:359-408), over the quasi-static free space.  Tree 1 is rooted at the start, tree 2 at
+ * the goal; one expansion (nearest neighbour + edge walk) is one batched device step for all problems. */
+typedef struct rkh_birrt_stats {
+  uint64_t num_vertices_1, num_vertices_2, loop_iterations, samples, num_solutions, joins, edges_checked;
+  double best_cost;
+} rkh_birrt_stats;
+rkh_status rkh_birrt_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_rrt_params* prms,
+                                     uint32_t n_problems, rkh_birrt** out);
+rkh_status rkh_birrt_destroy(rkh_birrt* p);
+/* stats: array of n_problems entries.  max_loop_iterations < 0: run until keep_going() is false. */
+rkh_status rkh_birrt_solve(rkh_birrt* p, int64_t max_loop_iterations, rkh_birrt_stats* stats);
+/* pos1 [num_vertices_1][n_dof], parent1 (root: 0xFFFFFFFF), the same for tree 2; nn_seq / accept [2 * loop_iterations]:
+ * nearest vertex and reached_new of every expansion (tree 1, tree 2, tree 1, ...).  Any pointer may be NULL. */
+rkh_status rkh_birrt_get_trees(rkh_birrt* p, uint32_t problem, double* pos1, uint32_t* parent1, double* pos2,
+                               uint32_t* parent2, uint32_t* nn_seq, uint8_t* accept);
 /* With RKH_PROFILE_NN=1 in the environment at rkh_planner_create, every round brackets its NN sweep kernel with
  * HIP events on the planner stream: total kernel time, algorithmic bytes (n*D*8 per sweep) and launch count. */
 rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* total_bytes, uint64_t* launches);

@@ -402,6 +402,45 @@ void orc_prm_copy(double* pos, uint32_t* edge_u, uint32_t* edge_v, double* edge_
   if (expanded) std::memcpy(expanded, r.expanded.data(), r.expanded.size() * sizeof(uint32_t));
 }
 
+// ---- bidirectional RRT over the quasi-static free space
+struct OrcBiRrtOut {
+  uint64_t n1, n2, loop_iterations, samples, num_solutions, joins, edges_checked;
+  double best_cost, seconds;
+};
+static BiRrtResult g_last_birrt;
+int orc_birrt_qs(void* h, int D, const double* lower, const double* upper, double min_interval, const rkh_rrt_params* prm,
+                 int64_t max_loop_iterations, OrcBiRrtOut* out) {
+  Scene* s = static_cast<Scene*>(h);
+  QuasiStaticSpace sp;
+  sp.D = D;
+  sp.lower.assign(lower, lower + D);
+  sp.upper.assign(upper, upper + D);
+  sp.min_interval = min_interval;
+  sp.chain = s->chain;
+  sp.env = s->env;
+  auto t0 = std::chrono::steady_clock::now();
+  generate_bidirectional_rrt(sp, *prm, long(max_loop_iterations), g_last_birrt);
+  out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  out->n1 = g_last_birrt.parent[0].size();
+  out->n2 = g_last_birrt.parent[1].size();
+  out->loop_iterations = g_last_birrt.loop_iterations;
+  out->samples = g_last_birrt.samples;
+  out->num_solutions = g_last_birrt.num_solutions;
+  out->joins = g_last_birrt.joins;
+  out->edges_checked = g_last_birrt.cnt.edges_checked;
+  out->best_cost = g_last_birrt.best_cost;
+  return 0;
+}
+void orc_birrt_copy(double* pos1, uint32_t* parent1, double* pos2, uint32_t* parent2, uint32_t* nn_seq, uint8_t* accept) {
+  const BiRrtResult& r = g_last_birrt;
+  if (pos1) std::memcpy(pos1, r.pos[0].data(), r.pos[0].size() * sizeof(double));
+  if (parent1) std::memcpy(parent1, r.parent[0].data(), r.parent[0].size() * sizeof(uint32_t));
+  if (pos2) std::memcpy(pos2, r.pos[1].data(), r.pos[1].size() * sizeof(double));
+  if (parent2) std::memcpy(parent2, r.parent[1].data(), r.parent[1].size() * sizeof(uint32_t));
+  if (nn_seq) std::memcpy(nn_seq, r.nn_seq.data(), r.nn_seq.size() * sizeof(uint32_t));
+  if (accept) std::memcpy(accept, r.accept.data(), r.accept.size());
+}
+
 // copy the arrays of the last RRT run
 void orc_rrt_copy(double* pos, uint32_t* parent, uint32_t* nn_seq, uint8_t* accept, double* goal_dist) {
   if (pos) std::memcpy(pos, g_last.pos.data(), g_last.pos.size() * sizeof(double));

@@ -880,3 +880,127 @@ void generate_prm(Space& space, const rkh_prm_params& pp, long max_loop_iteratio
 }
 
 }  // namespace oracle
+
+// --------------------------------------------------------------------------------------------
+// Bidirectional RRT: generate_bidirectional_rrt (ctrl/graph_alg/rr_tree.hpp:256-317) with expand_rrt_vertex
+// (:86-112), planning_visitor_base::steer_towards_position / joining_vertex_found (planning_visitors.hpp:349-360,
+// 223-231) and register_basic_solution_path_impl for two graphs (solution_path_factories.hpp:359-408).
+// Tree 1 grows from the start, tree 2 from the goal; both roots exist before the loop (rrt_path_planner.tpp), so they
+// are not counted by m_iteration_count.  vertex_added / edge_added do not probe the goal in a bidirectional planner
+// (planning_visitors.hpp:174-176,189-192).
+namespace oracle {
+
+struct BiRrtResult {
+  int D = 0;
+  std::vector<double> pos[2];        // tree 1 (root = start), tree 2 (root = goal)
+  std::vector<uint32_t> parent[2];   // root: 0xFFFFFFFF
+  std::vector<uint32_t> nn_seq;      // per expansion (two per loop iteration): nearest vertex u
+  std::vector<uint8_t> accept;       // per expansion: reached_new
+  long loop_iterations = 0, samples = 0, num_solutions = 0, joins = 0;
+  double best_cost = std::numeric_limits<double>::infinity();
+  SpaceCounters cnt;
+};
+
+template <typename Space>
+void generate_bidirectional_rrt(Space& space, const rkh_rrt_params& prm, long max_loop_iterations, BiRrtResult& res) {
+  const int D = space.D;
+  const uint32_t NIL = 0xFFFFFFFFu;
+  GlobalRng rng(prm.seed);
+  res = BiRrtResult();
+  res.D = D;
+  Point start(prm.start, prm.start + D), goal(prm.goal, prm.goal + D);
+  res.pos[0].assign(start.begin(), start.end());
+  res.parent[0].push_back(NIL);
+  res.pos[1].assign(goal.begin(), goal.end());
+  res.parent[1].push_back(NIL);
+  unsigned long m_iteration_count = 0;
+  auto keep_going = [&]() {
+    return (m_iteration_count < prm.max_vertices) && (prm.max_results > (unsigned long)res.num_solutions);
+  };
+  auto P = [&](int t, uint32_t v) {
+    return Point(res.pos[t].begin() + std::size_t(v) * D, res.pos[t].begin() + std::size_t(v + 1) * D);
+  };
+  // detail::expand_rrt_vertex on tree t towards p_target: returns (vertex, reached_new)
+  auto expand = [&](int t, const Point& p_target) {
+    std::size_t n = res.parent[t].size();
+    uint32_t u = uint32_t(linear_nn(p_target.data(), res.pos[t].data(), n, D));
+    res.nn_seq.push_back(u);
+    Point pu = P(t, u), p_v;
+    double traveled = space.steer(pu, p_target, 1.0, p_v);
+    double best_case = space.metric(pu, p_target);
+    bool reached_new = (!std::isinf(traveled)) && (traveled < 2.0 * best_case) && (traveled > prm.steer_tol * best_case);
+    res.accept.push_back(reached_new ? 1 : 0);
+    if (!reached_new) return std::make_pair(u, false);
+    res.pos[t].insert(res.pos[t].end(), p_v.begin(), p_v.end());
+    res.parent[t].push_back(u);
+    ++m_iteration_count;  // vis.vertex_added -> report_progress
+    return std::make_pair(uint32_t(res.parent[t].size() - 1), true);
+  };
+  // joining_vertex_found -> register_joining_point -> register_basic_solution_path_impl (two graphs)
+  auto joining_vertex_found = [&](uint32_t u1, uint32_t u2) {
+    ++res.joins;
+    double total = space.metric(P(0, u1), P(1, u2));
+    uint32_t j1 = u1;
+    while (res.parent[0][j1] != NIL) {
+      uint32_t v = res.parent[0][j1];
+      total += space.metric(P(0, v), P(0, j1));
+      j1 = v;
+    }
+    uint32_t j2 = u2;
+    while (res.parent[1][j2] != NIL) {
+      uint32_t v = res.parent[1][j2];
+      total += space.metric(P(1, j2), P(1, v));
+      j2 = v;
+    }
+    if (res.num_solutions == 0 || total < res.best_cost) {
+      res.best_cost = total;
+      ++res.num_solutions;
+    }
+  };
+  std::pair<uint32_t, bool> v_target2(0u, true);
+  Point p_target2 = P(0, 0);
+  std::pair<uint32_t, bool> v_target1(0u, true);
+  Point p_target1 = P(1, 0);
+  while (keep_going() && (max_loop_iterations < 0 || res.loop_iterations < max_loop_iterations)) {
+    ++res.loop_iterations;
+    // first, expand the first graph towards its target (:282-299)
+    {
+      std::size_t n_before = res.parent[0].size();
+      std::pair<uint32_t, bool> v1 = expand(0, p_target1);
+      (void)n_before;
+      if (v1.second && v_target1.second) {
+        joining_vertex_found(v1.first, v_target1.first);
+        p_target2 = space.random_point(rng);
+        ++res.samples;
+        v_target2.second = false;
+      } else if (!v1.second) {  // v1.first == u1: unsuccessful expansion
+        p_target2 = space.random_point(rng);
+        ++res.samples;
+        v_target2.second = false;
+      } else {
+        p_target2 = P(0, v1.first);
+        v_target2 = std::make_pair(v1.first, true);
+      }
+    }
+    // then, expand the second graph towards its target (:301-318)
+    {
+      std::pair<uint32_t, bool> v2 = expand(1, p_target2);
+      if (v2.second && v_target2.second) {
+        joining_vertex_found(v_target2.first, v2.first);
+        p_target1 = space.random_point(rng);
+        ++res.samples;
+        v_target1.second = false;
+      } else if (!v2.second) {
+        p_target1 = space.random_point(rng);
+        ++res.samples;
+        v_target1.second = false;
+      } else {
+        p_target1 = P(1, v2.first);
+        v_target1 = std::make_pair(v2.first, true);
+      }
+    }
+  }
+  res.cnt = space.cnt;
+}
+
+}  // namespace oracle

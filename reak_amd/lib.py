@@ -45,6 +45,12 @@ class PrmStats(C.Structure):
                 ("device_steps", C.c_uint64)]
 
 
+class BiRrtStats(C.Structure):
+    _fields_ = [("num_vertices_1", C.c_uint64), ("num_vertices_2", C.c_uint64), ("loop_iterations", C.c_uint64),
+                ("samples", C.c_uint64), ("num_solutions", C.c_uint64), ("joins", C.c_uint64),
+                ("edges_checked", C.c_uint64), ("best_cost", C.c_double)]
+
+
 class PlannerStats(C.Structure):
     _fields_ = [
         ("num_vertices", C.c_uint64),
@@ -66,7 +72,7 @@ EXPORTS = [
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
     "rkh_planner_nn_profile", "rkh_planner_steer_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
-    "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph",
+    "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph", "rkh_birrt_create_qs_batch", "rkh_birrt_destroy", "rkh_birrt_solve", "rkh_birrt_get_trees",
 ]
 
 
@@ -129,6 +135,10 @@ def load():
     lib.rkh_prm_create_qs_batch.argtypes = [vp, C.POINTER(T.QsSpace), C.POINTER(T.PrmParams), u32, C.POINTER(vp)]
     lib.rkh_prm_destroy.argtypes = [vp]
     lib.rkh_prm_solve.argtypes = [vp, C.c_int64, C.POINTER(PrmStats)]
+    lib.rkh_birrt_create_qs_batch.argtypes = [vp, C.POINTER(T.QsSpace), C.POINTER(T.RrtParams), u32, C.POINTER(vp)]
+    lib.rkh_birrt_destroy.argtypes = [vp]
+    lib.rkh_birrt_solve.argtypes = [vp, C.c_int64, C.POINTER(BiRrtStats)]
+    lib.rkh_birrt_get_trees.argtypes = [vp, u32, dp, u32p, dp, u32p, u32p, C.POINTER(C.c_uint8)]
     lib.rkh_prm_get_graph.argtypes = [vp, u32, dp, u32p, u32p, dp, dp, u32p, C.POINTER(C.c_uint8), u32p]
     lib.rkh_planner_num_problems.restype = u32
     lib.rkh_planner_num_problems.argtypes = [vp]
@@ -474,6 +484,48 @@ class PrmPlanner:
     def close(self):
         if self.h:
             self.lib.rkh_prm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BiRrtPlanner:
+    """rrt_planner with BIDIRECTIONAL_PLANNING over the quasi-static free space, batch of problems."""
+
+    def __init__(self, scene, prm, qs):
+        self.scene, self.lib, self.qs = scene, scene.lib, qs
+        self.prms = list(prm) if isinstance(prm, (list, tuple)) else [prm]
+        self.P, self.D = len(self.prms), qs.n_dof
+        self._prm_arr = T.as_array(self.prms, T.RrtParams)
+        self.h = C.c_void_p()
+        _check(self.lib.rkh_birrt_create_qs_batch(scene.h, C.byref(qs), self._prm_arr, self.P, C.byref(self.h)))
+        self.all_stats = (BiRrtStats * self.P)()
+
+    @property
+    def stats(self):
+        return self.all_stats[0]
+
+    def solve_planning_query(self, max_loop_iterations=-1):
+        _check(self.lib.rkh_birrt_solve(self.h, int(max_loop_iterations), self.all_stats))
+        return self.all_stats[0]
+
+    def trees(self, problem=0):
+        st = self.all_stats[problem]
+        n1, n2, it = int(st.num_vertices_1), int(st.num_vertices_2), int(st.loop_iterations)
+        p1 = np.zeros((n1, self.D)); q1 = np.zeros(n1, dtype=np.uint32)
+        p2 = np.zeros((n2, self.D)); q2 = np.zeros(n2, dtype=np.uint32)
+        nn = np.zeros(max(2 * it, 1), dtype=np.uint32); acc = np.zeros(max(2 * it, 1), dtype=np.uint8)
+        _check(self.lib.rkh_birrt_get_trees(self.h, problem, T.dptr(p1), T.u32ptr(q1), T.dptr(p2), T.u32ptr(q2), T.u32ptr(nn),
+                                            acc.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return {"pos1": p1, "parent1": q1, "pos2": p2, "parent2": q2, "nn_seq": nn[: 2 * it], "accept": acc[: 2 * it]}
+
+    def close(self):
+        if self.h:
+            self.lib.rkh_birrt_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

@@ -39,6 +39,12 @@ class PrmOut(C.Structure):
                 ("states_checked", C.c_uint64), ("seconds", C.c_double)]
 
 
+class BiRrtOut(C.Structure):
+    _fields_ = [("n1", C.c_uint64), ("n2", C.c_uint64), ("loop_iterations", C.c_uint64), ("samples", C.c_uint64),
+                ("num_solutions", C.c_uint64), ("joins", C.c_uint64), ("edges_checked", C.c_uint64),
+                ("best_cost", C.c_double), ("seconds", C.c_double)]
+
+
 def build():
     subprocess.run(["make", "-s", "-C", _ORACLE_DIR], check=True)
 
@@ -93,6 +99,8 @@ def load(fast=False):
     lib.orc_rrtstar_copy.argtypes = [dp, u32p, dp, u32p]
     lib.orc_prm_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.PrmParams), C.c_int64, C.POINTER(PrmOut)]
     lib.orc_prm_copy.argtypes = [dp, u32p, u32p, dp, dp, u32p, C.POINTER(C.c_uint8), u32p]
+    lib.orc_birrt_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(BiRrtOut)]
+    lib.orc_birrt_copy.argtypes = [dp, u32p, dp, u32p, u32p, C.POINTER(C.c_uint8)]
     lib.orc_rrt_copy.argtypes = [dp, u32p, u32p, C.POINTER(C.c_uint8), dp]
     _libs[name] = lib
     return lib
@@ -196,6 +204,19 @@ class OracleScene:
                               kind.ctypes.data_as(C.POINTER(C.c_uint8)), T.u32ptr(exp))
         return rc, out, {"pos": pos, "edge_u": eu[:ne], "edge_v": ev[:ne], "edge_w": ew[:ne], "density": dens,
                          "cc_root": cc, "kind": kind[:it], "expanded": exp[:it]}
+
+    def birrt_qs(self, lower, upper, min_interval, prm, max_loop_iterations=-1):
+        lower = np.ascontiguousarray(lower, dtype=np.float64)
+        upper = np.ascontiguousarray(upper, dtype=np.float64)
+        out = BiRrtOut()
+        rc = self.lib.orc_birrt_qs(self.h, len(lower), T.dptr(lower), T.dptr(upper), float(min_interval), C.byref(prm),
+                                   int(max_loop_iterations), C.byref(out))
+        n1, n2, it, D = int(out.n1), int(out.n2), int(out.loop_iterations), len(lower)
+        p1 = np.zeros((n1, D)); q1 = np.zeros(n1, dtype=np.uint32); p2 = np.zeros((n2, D)); q2 = np.zeros(n2, dtype=np.uint32)
+        nn = np.zeros(max(2 * it, 1), dtype=np.uint32); acc = np.zeros(max(2 * it, 1), dtype=np.uint8)
+        self.lib.orc_birrt_copy(T.dptr(p1), T.u32ptr(q1), T.dptr(p2), T.u32ptr(q2), T.u32ptr(nn),
+                                acc.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return rc, out, {"pos1": p1, "parent1": q1, "pos2": p2, "parent2": q2, "nn_seq": nn[: 2 * it], "accept": acc[: 2 * it]}
 
     def qs_move(self, lower, upper, min_interval, a, b, fraction=1.0):
         lower = np.ascontiguousarray(lower, dtype=np.float64)

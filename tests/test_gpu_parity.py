@@ -533,3 +533,38 @@ def test_c4_dual_arm_quasi_static(L, ctx, oracle):
     # the dynamics entry points refuse a branching scene
     with pytest.raises(Exception):
         sc.state_derivative(np.zeros((1, 24)), np.zeros((1, 12)))
+
+
+# ------------------------------------------------------------------ bidirectional RRT (a7, rr_tree.hpp:256-317)
+@pytest.mark.parametrize("seed,max_results", [(1, 3), (2, 1 << 30)])
+def test_bidirectional_rrt_identical_to_sequential_planner(L, ctx, oracle, seed, max_results):
+    c1 = scenarios.make_c1(world_seed=1)
+    sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    prm = c1.rrt_params(seed=seed, max_vertices=1500, max_results=max_results)
+    rc, ro, rt = osc.birrt_qs(lo, hi, mi, prm)
+    pl = L.BiRrtPlanner(sc, prm, L.make_qs_space(3, lo, hi, mi))
+    st = pl.solve_planning_query()
+    t = pl.trees()
+    assert (st.num_vertices_1, st.num_vertices_2, st.loop_iterations, st.samples, st.num_solutions, st.joins,
+            st.edges_checked) == (ro.n1, ro.n2, ro.loop_iterations, ro.samples, ro.num_solutions, ro.joins, ro.edges_checked)
+    assert st.best_cost == ro.best_cost and st.joins > 0
+    for k in ("nn_seq", "accept", "parent1", "parent2", "pos1", "pos2"):
+        assert np.array_equal(t[k], rt[k]), k
+
+
+def test_bidirectional_rrt_batch_c4(L, ctx, oracle):
+    """Three seeds of the 12-DOF dual arm in one batch, stopped half way and resumed."""
+    c4 = scenarios.make_c4(world_seed=1)
+    sc, osc = L.Scene(ctx, c4), oracle.OracleScene(c4)
+    lo, hi, mi = c4.meta["lower"], c4.meta["upper"], c4.meta["min_interval"]
+    prms = [c4.rrt_params(seed=s, max_vertices=150, max_results=2) for s in (3, 4, 5)]
+    pl = L.BiRrtPlanner(sc, prms, L.make_qs_space(12, lo, hi, mi))
+    pl.solve_planning_query(max_loop_iterations=40)
+    pl.solve_planning_query()
+    for i, prm in enumerate(prms):
+        rc, ro, rt = osc.birrt_qs(lo, hi, mi, prm)
+        st, t = pl.all_stats[i], pl.trees(i)
+        assert (st.num_vertices_1, st.num_vertices_2, st.loop_iterations, st.num_solutions) == (
+            ro.n1, ro.n2, ro.loop_iterations, ro.num_solutions)
+        assert np.array_equal(t["parent1"], rt["parent1"]) and np.array_equal(t["pos2"], rt["pos2"])
