@@ -231,6 +231,17 @@ rkh_status rkh_birrt_solve(rkh_birrt* p, int64_t max_loop_iterations, rkh_birrt_
  * nearest vertex and reached_new of every expansion (tree 1, tree 2, tree 1, ...).  Any pointer may be NULL. */
 rkh_status rkh_birrt_get_trees(rkh_birrt* p, uint32_t problem, double* pos1, uint32_t* parent1, double* pos2,
                                uint32_t* parent2, uint32_t* nn_seq, uint8_t* accept);
+/* ---- Solution paths (what register_*_solution_path_impl of ctrl/path_planning/solution_path_factories.hpp walks) ----
+ * Vertex indices into the arrays of rkh_planner_get_tree / rkh_rrtstar_get_graph / rkh_birrt_get_trees, start first;
+ * n_path = 0 if no solution is registered; the path pointers may be NULL to query the lengths; cost = the registered
+ * solution cost (RRT: path + goal-probe distance of the last vertex; RRT*: distance_accum of the goal; bidirectional:
+ * both tree paths + joining distance). */
+rkh_status rkh_planner_get_solution(rkh_planner* p, uint32_t problem, uint32_t* path, uint32_t capacity,
+                                    uint32_t* n_path, double* cost);
+rkh_status rkh_rrtstar_get_solution(rkh_rrtstar* p, uint32_t problem, uint32_t* path, uint32_t capacity, uint32_t* n_path,
+                                    double* cost);
+rkh_status rkh_birrt_get_solution(rkh_birrt* p, uint32_t problem, uint32_t* path1, uint32_t* n_path1, uint32_t* path2,
+                                  uint32_t* n_path2, uint32_t capacity, double* cost);
 /* With RKH_PROFILE_NN=1 in the environment at rkh_planner_create, every round brackets its NN sweep kernel with
  * HIP events on the planner stream: total kernel time, algorithmic bytes (n*D*8 per sweep) and launch count. */
 rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* total_bytes, uint64_t* launches);

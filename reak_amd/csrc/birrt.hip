@@ -41,6 +41,7 @@ struct BiProblem {
   std::vector<uint8_t> accept;
   uint64_t iteration_count = 0, loop_iterations = 0, samples = 0, num_solutions = 0, joins = 0, edges_checked = 0;
   double best_cost = std::numeric_limits<double>::infinity();
+  uint32_t best_join[2] = {NIL, NIL};  // joining vertices (tree 1, tree 2) of the best registered solution
   // loop state (rr_tree.hpp:272-281)
   uint32_t v_target[2] = {0, 0};     // v_target1 (a vertex of tree 2), v_target2 (a vertex of tree 1)
   bool target_is_vertex[2] = {true, true};
@@ -92,6 +93,8 @@ void joining_vertex_found(BiProblem& q, int D, uint32_t u1, uint32_t u2) {
   }
   if (q.num_solutions == 0 || total < q.best_cost) {
     q.best_cost = total;
+    q.best_join[0] = u1;
+    q.best_join[1] = u2;
     ++q.num_solutions;
   }
 }
@@ -238,6 +241,35 @@ rkh_status rkh_birrt_solve(rkh_birrt* p, int64_t max_loop_iterations, rkh_birrt_
       o.edges_checked = q.edges_checked;
       o.best_cost = q.best_cost;
     }
+  return RKH_OK;
+}
+
+// The best registered solution: vertices of tree 1 from the start to the joining vertex, then vertices of tree 2 from
+// its joining vertex to the goal (register_basic_solution_path_impl for two graphs, solution_path_factories.hpp:359-408).
+rkh_status rkh_birrt_get_solution(rkh_birrt* p, uint32_t problem, uint32_t* path1, uint32_t* n_path1, uint32_t* path2,
+                                  uint32_t* n_path2, uint32_t capacity, double* cost) {
+  if (!p || problem >= p->P || !n_path1 || !n_path2) return RKH_ERR_BAD_ARG;
+  const BiProblem& q = p->prob[problem];
+  *n_path1 = *n_path2 = 0;
+  if (cost) *cost = q.best_cost;
+  if (q.best_join[0] == NIL) return RKH_OK;
+  std::vector<uint32_t> rev;
+  for (uint32_t v = q.best_join[0]; v != NIL; v = q.parent[0][v]) rev.push_back(v);
+  std::vector<uint32_t> fwd;
+  for (uint32_t v = q.best_join[1]; v != NIL; v = q.parent[1][v]) fwd.push_back(v);
+  *n_path1 = uint32_t(rev.size());
+  *n_path2 = uint32_t(fwd.size());
+  if (capacity < rev.size() || capacity < fwd.size()) {
+    if (path1 || path2) {
+      set_error("rkh_birrt_get_solution: path buffer too small");
+      return RKH_ERR_CAPACITY;
+    }
+    return RKH_OK;
+  }
+  if (path1)
+    for (size_t i = 0; i < rev.size(); ++i) path1[i] = rev[rev.size() - 1 - i];
+  if (path2)
+    for (size_t i = 0; i < fwd.size(); ++i) path2[i] = fwd[i];
   return RKH_OK;
 }
 

@@ -235,6 +235,7 @@ struct Problem {  // host view of one planning problem
   uint64_t goal_checked = 0;
   uint64_t num_solutions = 0;
   double best_cost = INFINITY;
+  uint32_t best_vertex = 0xFFFFFFFFu;  // vertex whose goal probe gave the best registered solution
   bool truncated = false;
   uint64_t final_n = 0, final_iterations = 0;
 };
@@ -797,6 +798,7 @@ rkh_status rkh_planner_sync(rkh_planner* p, rkh_planner_stats* stats) {
         }
         if (q.num_solutions == 0 || total < q.best_cost) {
           q.best_cost = total;
+          q.best_vertex = uint32_t(first + k + 1);
           ++q.num_solutions;
           if (q.num_solutions >= q.prm.max_results) {
             // the sequential planner stops right after this vertex: drop what speculation added beyond it
@@ -825,6 +827,31 @@ rkh_status rkh_planner_sync(rkh_planner* p, rkh_planner_stats* stats) {
       o.best_cost = q.best_cost;
       o.done = (q.truncated || hs.done == 1) ? 1u : 0u;
     }
+  }
+  return RKH_OK;
+}
+
+// The best registered solution as a vertex path root -> ... -> v (the motion then goes on to the goal, which the goal
+// probe of v reached): register_basic_solution_path_impl (solution_path_factories.hpp:58-110) walks the same parents.
+rkh_status rkh_planner_get_solution(rkh_planner* p, uint32_t problem, uint32_t* path, uint32_t capacity,
+                                    uint32_t* n_path, double* cost) {
+  if (!p || problem >= p->P || !n_path) return RKH_ERR_BAD_ARG;
+  Problem& q = p->prob[problem];
+  *n_path = 0;
+  if (cost) *cost = q.best_cost;
+  if (q.best_vertex == 0xFFFFFFFFu) return RKH_OK;  // no solution registered
+  RKH_HIP(hipStreamSynchronize(p->stream));
+  std::vector<uint32_t> par(size_t(q.best_vertex) + 1);
+  RKH_HIP(hipMemcpy(par.data(), q.d_parent, par.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  std::vector<uint32_t> rev;
+  for (uint32_t v = q.best_vertex; v != 0xFFFFFFFFu; v = par[v]) rev.push_back(v);
+  *n_path = uint32_t(rev.size());
+  if (path) {
+    if (capacity < rev.size()) {
+      set_error("rkh_planner_get_solution: path buffer too small");
+      return RKH_ERR_CAPACITY;
+    }
+    for (size_t i = 0; i < rev.size(); ++i) path[i] = rev[rev.size() - 1 - i];
   }
   return RKH_OK;
 }

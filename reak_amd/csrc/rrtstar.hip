@@ -370,6 +370,31 @@ rkh_status rkh_rrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_rr
   return RKH_OK;
 }
 
+// The current best solution: the predecessor chain of the goal vertex (vertex 1), start first
+// (register_optimal_solution_path_impl, solution_path_factories.hpp:226-270).
+rkh_status rkh_rrtstar_get_solution(rkh_rrtstar* p, uint32_t problem, uint32_t* path, uint32_t capacity, uint32_t* n_path,
+                                    double* cost) {
+  if (!p || problem >= p->P || !n_path) return RKH_ERR_BAD_ARG;
+  const StarProblem& q = p->prob[problem];
+  *n_path = 0;
+  if (cost) *cost = q.dist[1];
+  if (q.pred[1] == NIL) return RKH_OK;  // the goal is not connected
+  std::vector<uint32_t> rev;
+  for (uint32_t v = 1; rev.size() <= q.pred.size(); v = q.pred[v]) {
+    rev.push_back(v);
+    if (v == 0) break;
+  }
+  *n_path = uint32_t(rev.size());
+  if (path) {
+    if (capacity < rev.size()) {
+      set_error("rkh_rrtstar_get_solution: path buffer too small");
+      return RKH_ERR_CAPACITY;
+    }
+    for (size_t i = 0; i < rev.size(); ++i) path[i] = rev[rev.size() - 1 - i];
+  }
+  return RKH_OK;
+}
+
 rkh_status rkh_rrtstar_get_graph(rkh_rrtstar* p, uint32_t problem, double* pos, uint32_t* pred, double* dist,
                                  uint32_t* near_seq) {
   if (!p || problem >= p->P) return RKH_ERR_BAD_ARG;

@@ -72,7 +72,7 @@ EXPORTS = [
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
     "rkh_planner_nn_profile", "rkh_planner_steer_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
-    "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph", "rkh_birrt_create_qs_batch", "rkh_birrt_destroy", "rkh_birrt_solve", "rkh_birrt_get_trees",
+    "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph", "rkh_birrt_create_qs_batch", "rkh_birrt_destroy", "rkh_birrt_solve", "rkh_birrt_get_trees", "rkh_planner_get_solution", "rkh_rrtstar_get_solution", "rkh_birrt_get_solution",
 ]
 
 
@@ -135,6 +135,9 @@ def load():
     lib.rkh_prm_create_qs_batch.argtypes = [vp, C.POINTER(T.QsSpace), C.POINTER(T.PrmParams), u32, C.POINTER(vp)]
     lib.rkh_prm_destroy.argtypes = [vp]
     lib.rkh_prm_solve.argtypes = [vp, C.c_int64, C.POINTER(PrmStats)]
+    lib.rkh_planner_get_solution.argtypes = [vp, u32, u32p, u32, u32p, dp]
+    lib.rkh_rrtstar_get_solution.argtypes = [vp, u32, u32p, u32, u32p, dp]
+    lib.rkh_birrt_get_solution.argtypes = [vp, u32, u32p, u32p, u32p, u32p, u32, dp]
     lib.rkh_birrt_create_qs_batch.argtypes = [vp, C.POINTER(T.QsSpace), C.POINTER(T.RrtParams), u32, C.POINTER(vp)]
     lib.rkh_birrt_destroy.argtypes = [vp]
     lib.rkh_birrt_solve.argtypes = [vp, C.c_int64, C.POINTER(BiRrtStats)]
@@ -374,6 +377,13 @@ class RrtPlanner:
         _check(self.lib.rkh_planner_nn_profile(self.h, C.byref(ms), C.byref(by), C.byref(ln)))
         return ms.value, by.value, ln.value
 
+    def solution(self, problem=0):
+        n, cost = C.c_uint32(), C.c_double()
+        _check(self.lib.rkh_planner_get_solution(self.h, problem, None, 0, C.byref(n), C.byref(cost)))
+        path = np.zeros(max(n.value, 1), dtype=np.uint32)
+        _check(self.lib.rkh_planner_get_solution(self.h, problem, T.u32ptr(path), len(path), C.byref(n), C.byref(cost)))
+        return path[: n.value], cost.value
+
     def steer_profile(self):
         ms, ln = C.c_double(), C.c_uint64()
         _check(self.lib.rkh_planner_steer_profile(self.h, C.byref(ms), C.byref(ln)))
@@ -422,6 +432,13 @@ class RrtStarPlanner:
     def solve_planning_query(self, max_loop_iterations=-1):
         _check(self.lib.rkh_rrtstar_solve(self.h, int(max_loop_iterations), self.all_stats))
         return self.all_stats[0]
+
+    def solution(self, problem=0):
+        n, cost = C.c_uint32(), C.c_double()
+        _check(self.lib.rkh_rrtstar_get_solution(self.h, problem, None, 0, C.byref(n), C.byref(cost)))
+        path = np.zeros(max(n.value, 1), dtype=np.uint32)
+        _check(self.lib.rkh_rrtstar_get_solution(self.h, problem, T.u32ptr(path), len(path), C.byref(n), C.byref(cost)))
+        return path[: n.value], cost.value
 
     def graph(self, problem=0):
         st = self.all_stats[problem]
@@ -512,6 +529,15 @@ class BiRrtPlanner:
     def solve_planning_query(self, max_loop_iterations=-1):
         _check(self.lib.rkh_birrt_solve(self.h, int(max_loop_iterations), self.all_stats))
         return self.all_stats[0]
+
+    def solution(self, problem=0):
+        n1, n2, cost = C.c_uint32(), C.c_uint32(), C.c_double()
+        _check(self.lib.rkh_birrt_get_solution(self.h, problem, None, C.byref(n1), None, C.byref(n2), 0, C.byref(cost)))
+        cap = max(n1.value, n2.value, 1)
+        p1 = np.zeros(cap, dtype=np.uint32); p2 = np.zeros(cap, dtype=np.uint32)
+        _check(self.lib.rkh_birrt_get_solution(self.h, problem, T.u32ptr(p1), C.byref(n1), T.u32ptr(p2), C.byref(n2), cap,
+                                               C.byref(cost)))
+        return p1[: n1.value], p2[: n2.value], cost.value
 
     def trees(self, problem=0):
         st = self.all_stats[problem]

@@ -568,3 +568,40 @@ def test_bidirectional_rrt_batch_c4(L, ctx, oracle):
         assert (st.num_vertices_1, st.num_vertices_2, st.loop_iterations, st.num_solutions) == (
             ro.n1, ro.n2, ro.loop_iterations, ro.num_solutions)
         assert np.array_equal(t["parent1"], rt["parent1"]) and np.array_equal(t["pos2"], rt["pos2"])
+
+
+# ------------------------------------------------------------------ solution paths
+def _path_len(pos, path):
+    return sum(float(np.sqrt(((pos[a] - pos[b]) ** 2).sum())) for a, b in zip(path[:-1], path[1:]))
+
+
+def test_solution_paths_are_consistent_with_the_registered_costs(L, ctx, oracle):
+    """The vertex paths of the best solutions follow the parent / predecessor arrays from the start and re-add to the
+    registered costs (solution_path_factories.hpp walks)."""
+    c1 = scenarios.make_c1(world_seed=1)
+    sc = L.Scene(ctx, c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    qs = L.make_qs_space(3, lo, hi, mi)
+    # RRT: path to the vertex whose goal probe connected + that probe's distance
+    pl = L.RrtPlanner(sc, c1.rrt_params(seed=1, max_vertices=1500), qs=qs)
+    st = pl.solve_planning_query()
+    tree = pl.tree()
+    path, cost = pl.solution()
+    assert st.num_solutions > 0 and cost == st.best_cost and path[0] == 0
+    assert all(tree["parent"][b] == a for a, b in zip(path[:-1], path[1:]))
+    assert np.isclose(_path_len(tree["pos"], path) + tree["goal_dist"][path[-1] - 1], cost, rtol=1e-12)
+    # RRT*: predecessor chain of the goal vertex
+    ps = L.RrtStarPlanner(sc, c1.rrt_params(seed=1, max_vertices=1200), qs)
+    st = ps.solve_planning_query()
+    g = ps.graph()
+    path, cost = ps.solution()
+    assert path[0] == 0 and path[-1] == 1 and cost == g["dist"][1] == st.best_cost
+    assert all(g["pred"][b] == a for a, b in zip(path[:-1], path[1:]))
+    # bidirectional RRT: tree-1 path to the joining vertex, joining gap, tree-2 path to the goal
+    pb = L.BiRrtPlanner(sc, c1.rrt_params(seed=2, max_vertices=800), qs)
+    st = pb.solve_planning_query()
+    t = pb.trees()
+    p1, p2, cost = pb.solution()
+    assert st.num_solutions > 0 and cost == st.best_cost and p1[0] == 0 and p2[-1] == 0
+    total = _path_len(t["pos1"], p1) + _path_len(t["pos2"], p2) + float(np.sqrt(((t["pos1"][p1[-1]] - t["pos2"][p2[0]]) ** 2).sum()))
+    assert np.isclose(total, cost, rtol=1e-12)
