@@ -498,7 +498,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   if (const char* e = getenv("RKH_LANE_THRESHOLD")) p->lane_threshold = uint32_t(std::max(0, atoi(e)));
   if (const char* e = getenv("RKH_LANES_PER_EDGE")) {
     p->lanes_per_edge = (atoi(e) == 1) ? 1 : ((atoi(e) == 16) ? 16 : (atoi(e) == 0 ? 0 : 64));
-  } else if (p->n_dof == 6 || p->n_dof == 3 || p->n_dof == 2 || p->n_dof == 1) {
+  } else if (p->n_dof <= 6) {
     p->lanes_per_edge = 0;  // automatic, per round
   } else {
     // one wavefront per candidate is the latency-optimal mapping; once a round can offer more waves than the chip

@@ -916,9 +916,11 @@ __global__ __launch_bounds__(64) void min_distance_kernel(const SceneDev* __rest
     case 1: { constexpr int N = 1; CALL; } break; \
     case 2: { constexpr int N = 2; CALL; } break; \
     case 3: { constexpr int N = 3; CALL; } break; \
+    case 4: { constexpr int N = 4; CALL; } break; \
     case 6: { constexpr int N = 6; CALL; } break; \
+    case 7: { constexpr int N = 7; CALL; } break; \
     default:                         \
-      set_error("propagate: chains with this number of joints are not instantiated (1,2,3,6)"); \
+      set_error("propagate: chains with this number of joints are not instantiated (1,2,3,4,6,7)"); \
       return RKH_ERR_UNSUPPORTED;    \
   }
 
@@ -927,10 +929,12 @@ __global__ __launch_bounds__(64) void min_distance_kernel(const SceneDev* __rest
     case 1: { constexpr int N = 1; CALL; } break; \
     case 2: { constexpr int N = 2; CALL; } break; \
     case 3: { constexpr int N = 3; CALL; } break; \
+    case 4: { constexpr int N = 4; CALL; } break; \
     case 6: { constexpr int N = 6; CALL; } break; \
+    case 7: { constexpr int N = 7; CALL; } break; \
     case 12: { constexpr int N = 12; CALL; } break; \
     default:                         \
-      set_error("quasi-static kernels: chains with this number of joints are not instantiated (1,2,3,6,12)"); \
+      set_error("quasi-static kernels: chains with this number of joints are not instantiated (1,2,3,4,6,7,12)"); \
       return RKH_ERR_UNSUPPORTED;    \
   }
 

@@ -689,9 +689,11 @@ rkh_status launch_propagate_lanes(hipStream_t s, int n_dof, const SceneDev* d_sc
     case 1: launch_lane_t<1>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws, gate); break;
     case 2: launch_lane_t<2>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws, gate); break;
     case 3: launch_lane_t<3>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws, gate); break;
+    case 4: launch_lane_t<4>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws, gate); break;
+    case 7: launch_lane_t<7>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws, gate); break;
     case 6: launch_lane_t<6>(s, d_scene, dyn, io, grid_edges, second, eb, tab_a, tab_b, n_problems, d_ws, gate); break;
     default:
-      set_error("propagate: chains with this number of joints are not instantiated (1,2,3,6)");
+      set_error("propagate: chains with this number of joints are not instantiated (1,2,3,4,6,7)");
       return RKH_ERR_UNSUPPORTED;
   }
   RKH_HIP(hipGetLastError());

@@ -324,3 +324,48 @@ def make_c4(world_seed=1, n_obstacles=200, capsule_radius=0.05, mount_y=0.35, mi
                     start=np.zeros(n), goal=goal,
                     meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi), "min_interval": min_interval,
                           "world_seed": world_seed, "n_obstacles": n_obstacles, "obstacle_kinds": kinds})
+
+
+def make_random_chain(n, seed=1, n_obstacles=12):
+    """A random n-joint serial chain (oblique joint axes, skew link offsets, full inertia tensors) with capsule links
+    and a few obstacles: exercises the kernels' template instantiations beyond the BASELINE configurations."""
+    rng = np.random.Generator(np.random.PCG64(7000 + 31 * n + seed))
+    axes = [tuple(v / np.linalg.norm(v)) for v in rng.normal(size=(n, 3))]
+    lengths = list(rng.uniform(0.12, 0.3, size=n))
+    offsets = [tuple(np.array([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), L])) for L in lengths]
+    masses = list(rng.uniform(0.5, 4.0, size=n))
+    inertias = []
+    for _ in range(n):
+        a = rng.uniform(-0.02, 0.02, size=(3, 3))
+        m = a @ a.T + np.diag(rng.uniform(0.01, 0.05, size=3))
+        inertias.append((m[0, 0], m[0, 1], m[0, 2], m[1, 1], m[1, 2], m[2, 2]))
+    ops = serial_chain_ops(axes, offsets, masses, inertias, list(rng.uniform(0.2, 1.0, size=n)))
+    base = T.ChainBase()
+    base.pose = T.make_pose((0.1, -0.2, 0.05), _random_unit_quat(rng))
+    base.acceleration[:] = [0.0, 0.0, 9.81]
+    shapes = []
+    for j in range(n):
+        s = T.Shape(kind=T.SHAPE_CCYLINDER, anchor=2 * j + 1)
+        s.pose = T.make_pose((0.0, 0.0, 0.5 * lengths[j]))
+        s.dims[:] = [lengths[j], 0.04, 0.0]
+        shapes.append(s)
+    for _ in range(n_obstacles):
+        kind = [T.SHAPE_SPHERE, T.SHAPE_BOX, T.SHAPE_CCYLINDER][int(rng.integers(0, 3))]
+        s = T.Shape(kind=kind, anchor=-1)
+        c = rng.uniform(-1.0, 1.0, size=3)
+        c *= max(1.0, 0.9 / np.linalg.norm(c))  # keep a clear ball around the base
+        s.pose = T.make_pose(c, _random_unit_quat(rng))
+        s.dims[:] = {T.SHAPE_SPHERE: [rng.uniform(0.05, 0.15), 0, 0], T.SHAPE_BOX: list(rng.uniform(0.1, 0.3, size=3)),
+                     T.SHAPE_CCYLINDER: [rng.uniform(0.1, 0.3), rng.uniform(0.03, 0.08), 0]}[kind]
+        shapes.append(s)
+    dyn = T.DynSpace()
+    dyn.n_dof, dyn.steps_per_edge, dyn.dt = n, 20, 1e-3
+    dyn.kp, dyn.kd, dyn.u_max, dyn.goal_tol = 40.0, 8.0, 40.0, 1e-3
+    for j in range(n):
+        dyn.lower[2 * j], dyn.upper[2 * j] = -np.pi, np.pi
+        dyn.lower[2 * j + 1], dyn.upper[2 * j + 1] = -2.0, 2.0
+    goal = np.zeros(2 * n)
+    goal[0::2] = rng.uniform(-1.0, 1.0, size=n)
+    return Scenario(name=f"chain{n}", ops=ops, base=base, shapes=shapes, dyn=dyn, n_dof=n, n_frames=2 * n + 1,
+                    start=np.zeros(2 * n), goal=goal, meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi),
+                                                            "min_interval": 0.05})

@@ -605,3 +605,37 @@ def test_solution_paths_are_consistent_with_the_registered_costs(L, ctx, oracle)
     assert st.num_solutions > 0 and cost == st.best_cost and p1[0] == 0 and p2[-1] == 0
     total = _path_len(t["pos1"], p1) + _path_len(t["pos2"], p2) + float(np.sqrt(((t["pos1"][p1[-1]] - t["pos2"][p2[0]]) ** 2).sum()))
     assert np.isclose(total, cost, rtol=1e-12)
+
+
+# ------------------------------------------------------------------ other chain sizes (template instantiations)
+@pytest.mark.parametrize("n", [2, 3, 4, 7])
+def test_random_chains_of_other_sizes(L, ctx, oracle, n, monkeypatch):
+    """Oblique joint axes, skew offsets, full inertia tensors, rotated base: x' = f(x,u), both steer mappings and a short
+    planner run for every joint count the dynamics kernels are instantiated for (6 is BASELINE C2, 1 the pendulum)."""
+    scn = scenarios.make_random_chain(n, seed=n)
+    sc, osc = L.Scene(ctx, scn), oracle.OracleScene(scn)
+    rng = np.random.default_rng(100 + n)
+    lo = np.array([scn.dyn.lower[i] for i in range(2 * n)])
+    hi = np.array([scn.dyn.upper[i] for i in range(2 * n)])
+    x = rng.uniform(lo, hi, size=(96, 2 * n))
+    u = rng.uniform(-30, 30, size=(96, n))
+    rc, rpd, rM, rf = osc.state_derivative(x, u)
+    pd, M, f = sc.state_derivative(x, u)
+    assert rc == 0 and np.max(np.abs(M - rM)) <= 1e-12 * np.abs(rM).max()
+    assert np.allclose(f, rf, rtol=1e-10, atol=1e-9) and np.allclose(pd, rpd, rtol=1e-9, atol=1e-8)
+    a = x[osc.min_distance(x) > 0.01][:40]
+    b = rng.uniform(lo, hi, size=(a.shape[0], 2 * n))
+    res = {}
+    for lanes in ("64", "1"):
+        monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
+        res[lanes] = sc.steer_position_toward(a, b)
+    assert np.array_equal(res["1"][0], res["64"][0]) and np.array_equal(res["1"][1], res["64"][1])
+    rc, rout, rsteps, _ = osc.steer(a, b)
+    assert np.array_equal(res["64"][1], rsteps) and np.allclose(res["64"][0], rout, rtol=1e-9, atol=1e-10)
+    monkeypatch.delenv("RKH_LANES_PER_EDGE")
+    prm = scn.rrt_params(seed=1, max_vertices=250)
+    rc, ro, rtree = osc.rrt_dyn(prm)
+    pl = L.RrtPlanner(sc, prm)
+    st = pl.solve_planning_query()
+    assert (st.num_vertices, st.iterations) == (ro.num_vertices, ro.iterations)
+    assert np.array_equal(pl.tree()["parent"], rtree["parent"])
