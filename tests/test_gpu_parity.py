@@ -639,3 +639,21 @@ def test_random_chains_of_other_sizes(L, ctx, oracle, n, monkeypatch):
     st = pl.solve_planning_query()
     assert (st.num_vertices, st.iterations) == (ro.num_vertices, ro.iterations)
     assert np.array_equal(pl.tree()["parent"], rtree["parent"])
+
+
+def test_large_batch_in_auto_mode_matches_oracle(L, ctx, oracle, c2):
+    """A batch big enough for the planner's own choices to matter: rounds above the lane threshold run the two-lanes-per-
+    edge kernel, small ones the wave-per-edge kernel, the NN sweep runs its fp32 pre-filter, launch sizes come from the
+    host-side bounds.  Spot-checked problems must still be the sequential planner on their seeds."""
+    sc, osc = L.Scene(ctx, c2), oracle.OracleScene(c2, fast=True)
+    P, mv = 48, 3000
+    prms = [c2.rrt_params(seed=100 + i, max_vertices=mv) for i in range(P)]
+    pl = L.RrtPlanner(sc, prms)
+    pl.solve_planning_query()
+    for i in (0, 17, 47):
+        rc, ro, rtree = osc.rrt_dyn(prms[i])
+        st, tree = pl.all_stats[i], pl.tree(i)
+        assert (st.num_vertices, st.iterations, st.edges_checked) == (ro.num_vertices, ro.iterations, ro.edges_checked)
+        assert np.array_equal(tree["nn_seq"], rtree["nn_seq"]) and np.array_equal(tree["accept"], rtree["accept"])
+        assert np.array_equal(tree["parent"], rtree["parent"])
+        assert np.allclose(tree["pos"], rtree["pos"], rtol=STATE_RTOL, atol=1e-12)
