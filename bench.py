@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--problems", type=int, default=int(os.environ.get("RKH_BENCH_PROBLEMS", "128")))
+    ap.add_argument("--problems", type=int, default=int(os.environ.get("RKH_BENCH_PROBLEMS", "256")))
     ap.add_argument("--max-vertices", type=int, default=100000)
     ap.add_argument("--rounds-per-sync", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
