@@ -342,11 +342,14 @@ static int padded_dims(int D) {
 int nn_padded_dims(int D) { return padded_dims(D); }
 
 static uint32_t pick_qb(uint32_t B) {
+  // queries per block: the smallest padded query count wins (a block computes all its QB slots); ties go to the larger
+  // block (fewer re-reads of the tiles)
   if (B <= 8) return 8;
   if (B <= 16) return 16;
   if (B <= 32) return 32;
-  if (B <= 128) return 128;
-  return 256;
+  if (B <= 64) return 64;
+  const uint32_t pad128 = (B + 127) / 128 * 128, pad256 = (B + 255) / 256 * 256;
+  return pad128 < pad256 ? 128 : 256;
 }
 
 static uint32_t pick_gx(uint64_t n_upper, uint32_t gy) {
@@ -386,6 +389,7 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
     case 8: RKH_NN1_LAUNCH(8); break;
     case 16: RKH_NN1_LAUNCH(16); break;
     case 32: if (f32) RKH_NN1_LAUNCH_F32(32); else RKH_NN1_LAUNCH(32); break;
+    case 64: if (f32) RKH_NN1_LAUNCH_F32(64); else RKH_NN1_LAUNCH(64); break;
     case 128: if (f32) RKH_NN1_LAUNCH_F32(128); else RKH_NN1_LAUNCH(128); break;
     default: if (f32) RKH_NN1_LAUNCH_F32(256); else RKH_NN1_LAUNCH(256); break;
   }
