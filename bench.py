@@ -137,12 +137,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
 
+    # RKH_BENCH_BACKEND=gloo + RKH_BENCH_SHARE_GPU=1: rehearsal of the N > 1 path on a box with fewer GPUs than ranks
+    # (ranks share the card, reductions go through gloo on the CPU); the driver's runs use RCCL, one rank per GPU.
+    backend = os.environ.get("RKH_BENCH_BACKEND", "nccl")
+    if os.environ.get("RKH_BENCH_SHARE_GPU") == "1":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    reduce_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     from reak_amd import dist_utils, lib, scenarios
 
@@ -205,7 +214,7 @@ def main():
 
     # tree-size / edge counters (sum) and best solution cost (min) over all seeds: the only collectives
     elapsed, nodes_all, edges_all, spec_all, best = dist_utils.reduce_results(
-        dist, elapsed, tot["nodes"], tot["edges"], tot["spec"], best, torch.device("cuda", local_rank))
+        dist, elapsed, tot["nodes"], tot["edges"], tot["spec"], best, reduce_device)
 
     if rank == 0:
         nn_gbps = (tot["nn_bytes"] / (tot["nn_ms"] * 1e-3) / 1e9) if tot["nn_ms"] > 0 else 0.0
