@@ -201,31 +201,36 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
     RKH_STAMP(1)
     // Mf += Tcm_b^T (Mcm_b Tcm_b): summation order of mat_alg_symmetric.hpp:551-566 and mat_operators.hpp:104-114;
     // the edge's two lanes take alternate rows i
+    // this lane's rows i = h, h+2, h+4 (N <= 6: at most three; for longer chains a second pass): their Jacobian columns do
+    // not depend on jx, so they are read from LDS once per body; rows beyond j repeat row j's operands and are not stored
 #pragma unroll 1
-    for (int jx = 0; jx <= j; ++jx) {
-      const double m0 = J.mass * RKH_LD(L_::T + jx * 6 + 0), m1 = J.mass * RKH_LD(L_::T + jx * 6 + 1),
-                   m2 = J.mass * RKH_LD(L_::T + jx * 6 + 2);
-      const d3 P = sym_mul(J.inertia, mk3(RKH_LD(L_::T + jx * 6 + 3), RKH_LD(L_::T + jx * 6 + 4), RKH_LD(L_::T + jx * 6 + 5)));
-      // three rows per iteration (i, i+2, i+4): independent accumulation chains; rows beyond j are computed on
-      // row j's operands and not stored
+    for (int i0 = h; i0 <= j; i0 += 6) {
+      double Ti[3][6];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int i = (i0 + 2 * r <= j) ? i0 + 2 * r : j;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Ti[r][k] = RKH_LD(L_::T + i * 6 + k);
+      }
 #pragma unroll 1
-      for (int i0 = h; i0 <= j; i0 += 6) {
-        double sv[3];
+      for (int jx = 0; jx <= j; ++jx) {
+        const double m0 = J.mass * RKH_LD(L_::T + jx * 6 + 0), m1 = J.mass * RKH_LD(L_::T + jx * 6 + 1),
+                     m2 = J.mass * RKH_LD(L_::T + jx * 6 + 2);
+        const d3 P = sym_mul(J.inertia, mk3(RKH_LD(L_::T + jx * 6 + 3), RKH_LD(L_::T + jx * 6 + 4), RKH_LD(L_::T + jx * 6 + 5)));
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-          const int i = (i0 + 2 * r <= j) ? i0 + 2 * r : j;
-          double s = RKH_LD(L_::MF + i * N + jx);
-          s = s + RKH_LD(L_::T + i * 6 + 0) * m0;
-          s = s + RKH_LD(L_::T + i * 6 + 1) * m1;
-          s = s + RKH_LD(L_::T + i * 6 + 2) * m2;
-          s = s + RKH_LD(L_::T + i * 6 + 3) * P.x;
-          s = s + RKH_LD(L_::T + i * 6 + 4) * P.y;
-          s = s + RKH_LD(L_::T + i * 6 + 5) * P.z;
-          sv[r] = s;
+          if (i0 + 2 * r <= j) {
+            const int i = i0 + 2 * r;
+            double s = RKH_LD(L_::MF + i * N + jx);
+            s = s + Ti[r][0] * m0;
+            s = s + Ti[r][1] * m1;
+            s = s + Ti[r][2] * m2;
+            s = s + Ti[r][3] * P.x;
+            s = s + Ti[r][4] * P.y;
+            s = s + Ti[r][5] * P.z;
+            RKH_LD(L_::MF + i * N + jx) = s;
+          }
         }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-          if (i0 + 2 * r <= j) RKH_LD(L_::MF + (i0 + 2 * r) * N + jx) = sv[r];
       }
     }
     RKH_STAMP(2)
