@@ -270,7 +270,15 @@ struct rkh_planner {
   NnArgs* d_nn_args = nullptr;
   EdgeIO* d_io_steer = nullptr;
   EdgeIO* d_io_probe = nullptr;
-  std::vector<double> h_chunk;
+  // pinned staging for the sample stream: [0] what the enqueued rounds need, [1] the next call's share, generated and
+  // copied while the GPU works on the rounds just enqueued
+  struct Staging {
+    double* h = nullptr;
+    uint32_t* h_sr = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+  } staging[2];
   // optional HIP-event timing of the NN sweep kernel (RKH_PROFILE_NN=1)
   bool profile_nn = false;
   std::vector<hipEvent_t> ev;  // pairs
@@ -281,28 +289,61 @@ struct rkh_planner {
 
 namespace {
 
-rkh_status upload_samples(rkh_planner* p, Problem& q, uint32_t index, uint64_t upto) {
-  // hyperbox_topology::random_point (hyperbox_topology.hpp:97-103): D draws of uniform_01 per sample,
-  // uniform_01<mt19937&,double> = eng() * 2^-32 (Boost.Random; one 32-bit draw per coordinate)
-  if (upto > q.sample_cap) upto = q.sample_cap;
-  if (upto <= q.samples_ready) return RKH_OK;
-  const uint64_t cnt = upto - q.samples_ready;
+// Extend every problem's device-resident sample stream by `ahead` samples beyond its (last known) cursor.
+// hyperbox_topology::random_point (hyperbox_topology.hpp:97-103): D draws of uniform_01 per sample,
+// uniform_01<mt19937&,double> = eng() * 2^-32 (Boost.Random; one 32-bit draw per coordinate).
+// All copies are asynchronous on the planner stream out of one pinned staging buffer; the buffer's previous use is
+// awaited through its event, so no stream synchronisation happens here.
+rkh_status upload_samples_all(rkh_planner* p, uint64_t ahead, int which) {
+  rkh_planner::Staging& sg = p->staging[which];
   const int D = p->D;
-  p->h_chunk.resize(cnt * D);
-  for (uint64_t i = 0; i < cnt; ++i)
-    for (int d = 0; d < D; ++d) {
-      double u;
-      do {
-        u = double(q.eng()) * (1.0 / 4294967296.0);
-      } while (!(u < 1.0));
-      p->h_chunk[i * D + d] = p->lower[d] + u * (p->upper[d] - p->lower[d]);
-    }
-  RKH_HIP(hipMemcpyAsync(q.d_samples + q.samples_ready * D, p->h_chunk.data(), cnt * D * sizeof(double),
-                         hipMemcpyHostToDevice, p->stream));
-  q.samples_ready = upto;
-  const uint32_t sr = uint32_t(upto);
-  RKH_HIP(hipMemcpyAsync(&p->d_states[index].samples_ready, &sr, sizeof(uint32_t), hipMemcpyHostToDevice, p->stream));
-  RKH_HIP(hipStreamSynchronize(p->stream));  // h_chunk and sr are reused
+  std::vector<uint64_t> upto(p->P, 0);
+  size_t total = 0;
+  for (uint32_t i = 0; i < p->P; ++i) {
+    Problem& q = p->prob[i];
+    if (q.truncated || q.h_state.done == 1) continue;
+    uint64_t want = uint64_t(q.h_state.s0) + ahead;
+    if (want > q.sample_cap) want = q.sample_cap;
+    if (want <= q.samples_ready) continue;
+    upto[i] = want;
+    total += size_t(want - q.samples_ready) * D;
+  }
+  if (total == 0) return RKH_OK;
+  if (sg.pending) {
+    RKH_HIP(hipEventSynchronize(sg.done));
+    sg.pending = false;
+  }
+  if (!sg.done) RKH_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
+  if (!sg.h_sr) RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&sg.h_sr), p->P * sizeof(uint32_t), hipHostMallocDefault));
+  if (total > sg.cap) {
+    if (sg.h) (void)hipHostFree(sg.h);
+    sg.h = nullptr;
+    sg.cap = total + total / 4;
+    RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&sg.h), sg.cap * sizeof(double), hipHostMallocDefault));
+  }
+  size_t off = 0;
+  for (uint32_t i = 0; i < p->P; ++i) {
+    if (!upto[i]) continue;
+    Problem& q = p->prob[i];
+    const uint64_t cnt = upto[i] - q.samples_ready;
+    double* dst = sg.h + off;
+    for (uint64_t k = 0; k < cnt; ++k)
+      for (int d = 0; d < D; ++d) {
+        double u;
+        do {
+          u = double(q.eng()) * (1.0 / 4294967296.0);
+        } while (!(u < 1.0));
+        dst[k * D + d] = p->lower[d] + u * (p->upper[d] - p->lower[d]);
+      }
+    RKH_HIP(hipMemcpyAsync(q.d_samples + q.samples_ready * D, dst, cnt * D * sizeof(double), hipMemcpyHostToDevice,
+                           p->stream));
+    q.samples_ready = upto[i];
+    sg.h_sr[i] = uint32_t(upto[i]);
+    RKH_HIP(hipMemcpyAsync(&p->d_states[i].samples_ready, &sg.h_sr[i], sizeof(uint32_t), hipMemcpyHostToDevice, p->stream));
+    off += size_t(cnt) * D;
+  }
+  RKH_HIP(hipEventRecord(sg.done, p->stream));
+  sg.pending = true;
   return RKH_OK;
 }
 
@@ -670,6 +711,12 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   (void)hipFree(p->d_nn_args);
   (void)hipFree(p->d_io_steer);
   (void)hipFree(p->d_io_probe);
+  for (auto& sg : p->staging) {
+    if (sg.pending) (void)hipEventSynchronize(sg.done);
+    if (sg.h) (void)hipHostFree(sg.h);
+    if (sg.h_sr) (void)hipHostFree(sg.h_sr);
+    if (sg.done) (void)hipEventDestroy(sg.done);
+  }
   (void)hipFree(p->d_lane_ws);
   (void)hipFree(p->d_sel);
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
@@ -722,19 +769,18 @@ rkh_status rkh_planner_steer_profile(rkh_planner* p, double* total_ms, uint64_t*
 
 rkh_status rkh_planner_enqueue(rkh_planner* p, uint32_t rounds) {
   if (!p) return RKH_ERR_BAD_ARG;
-  // make sure the enqueued rounds cannot run out of samples
-  for (uint32_t i = 0; i < p->P; ++i) {
-    Problem& q = p->prob[i];
-    if (q.truncated || q.h_state.done == 1) continue;
-    const uint64_t need = uint64_t(q.h_state.s0) + uint64_t(rounds) * p->b_max;
-    rkh_status st = upload_samples(p, q, i, need);
-    if (st != RKH_OK) return st;
-  }
+  // make sure the enqueued rounds cannot run out of samples (usually already there: see below)
+  const uint64_t share = uint64_t(rounds ? rounds : 1) * p->b_max;
+  rkh_status st = upload_samples_all(p, share, 0);
+  if (st != RKH_OK) return st;
   for (uint32_t r = 0; r < rounds; ++r) {
-    rkh_status st = enqueue_round(p);
+    st = enqueue_round(p);
     if (st != RKH_OK) return st;
   }
-  return RKH_OK;
+  // while the GPU works on these rounds: the next call's share of the stream (generated on the host, copied behind the
+  // rounds on the same stream)
+  if (rounds) st = upload_samples_all(p, 2 * share, 1);
+  return st;
 }
 
 rkh_status rkh_planner_sync(rkh_planner* p, rkh_planner_stats* stats) {
