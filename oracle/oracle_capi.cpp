@@ -8,6 +8,7 @@
 #include "reak_kte.hpp"
 #include "reak_math.hpp"
 #include "reak_planning.hpp"
+#include "vp_tree.hpp"
 #include "reak_proximity.hpp"
 
 using namespace oracle;
@@ -439,6 +440,23 @@ void orc_birrt_copy(double* pos1, uint32_t* parent1, double* pos2, uint32_t* par
   if (parent2) std::memcpy(parent2, r.parent[1].data(), r.parent[1].size() * sizeof(uint32_t));
   if (nn_seq) std::memcpy(nn_seq, r.nn_seq.data(), r.nn_seq.size() * sizeof(uint32_t));
   if (accept) std::memcpy(accept, r.accept.data(), r.accept.size());
+}
+
+// ---- static vantage-point tree (CPU yardstick for the NN sweep; vp_tree.hpp)
+int orc_vptree_nn1(const double* q, uint32_t B, const double* pts, uint64_t n, int D, uint32_t* idx, double* dist,
+                   double* build_seconds, double* query_seconds) {
+  auto t0 = std::chrono::steady_clock::now();
+  VpTree tree(pts, std::size_t(n), D);
+  auto t1 = std::chrono::steady_clock::now();
+  for (uint32_t b = 0; b < B; ++b) {
+    auto r = tree.nearest(q + std::size_t(b) * D);
+    idx[b] = r.first;
+    dist[b] = r.second;
+  }
+  auto t2 = std::chrono::steady_clock::now();
+  if (build_seconds) *build_seconds = std::chrono::duration<double>(t1 - t0).count();
+  if (query_seconds) *query_seconds = std::chrono::duration<double>(t2 - t1).count();
+  return 0;
 }
 
 // copy the arrays of the last RRT run

@@ -66,4 +66,7 @@ print(f"1-NN linear search 6-D N=25000, 1000 queries: {ms*1e3:.1f} us per batch 
       f"(reference, CPU of 2012: linear search 8.2e-3, DVP-tree arity 4 1.59e-4)", flush=True)
 pts = np.random.default_rng(0).random((n, D)); qq = np.random.default_rng(1).random((B, D))
 t0 = time.time(); O.nn1(qq, pts, fast=True); dt = time.time() - t0
-print(f"CPU oracle (this box, 1 core, -O3): {dt*1e6/B/n:.3e} us per query per vertex", flush=True)
+print(f"CPU oracle linear search (this box, 1 core, -O3): {dt*1e6/B/n:.3e} us per query per vertex", flush=True)
+ti, td, tb, tq = O.vptree_nn1(qq, pts, fast=True)
+print(f"CPU static vantage-point tree (this box, 1 core, -O3): {tq*1e6/B/n:.3e} us per query per vertex "
+      f"({tq*1e6/B:.1f} us per query, build {tb*1e3:.1f} ms)", flush=True)

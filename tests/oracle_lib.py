@@ -101,6 +101,7 @@ def load(fast=False):
     lib.orc_prm_copy.argtypes = [dp, u32p, u32p, dp, dp, u32p, C.POINTER(C.c_uint8), u32p]
     lib.orc_birrt_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(BiRrtOut)]
     lib.orc_birrt_copy.argtypes = [dp, u32p, dp, u32p, u32p, C.POINTER(C.c_uint8)]
+    lib.orc_vptree_nn1.argtypes = [dp, C.c_uint32, dp, C.c_uint64, C.c_int, u32p, dp, dp, dp]
     lib.orc_rrt_copy.argtypes = [dp, u32p, u32p, C.POINTER(C.c_uint8), dp]
     _libs[name] = lib
     return lib
@@ -251,6 +252,19 @@ def nn1(q, pts, fast=False):
     dist = np.zeros(B)
     lib.orc_nn1(T.dptr(q), B, T.dptr(pts), pts.shape[0], D, T.u32ptr(idx), T.dptr(dist))
     return idx, dist
+
+
+def vptree_nn1(q, pts, fast=False):
+    """Exact 1-NN through the static vantage-point tree: (idx, dist, build seconds, query seconds)."""
+    lib = load(fast)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    B, D = q.shape
+    idx = np.zeros(B, dtype=np.uint32)
+    dist = np.zeros(B)
+    tb, tq = C.c_double(), C.c_double()
+    lib.orc_vptree_nn1(T.dptr(q), B, T.dptr(pts), pts.shape[0], D, T.u32ptr(idx), T.dptr(dist), C.byref(tb), C.byref(tq))
+    return idx, dist, tb.value, tq.value
 
 
 def knn(q, pts, k, radius=np.inf, fast=False):

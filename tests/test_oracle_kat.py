@@ -263,3 +263,17 @@ def test_flexible_beam_force_closed_form(oracle):
     teth.ops = list(pend.ops) + [S.flexible_beam_op(2, T.make_pose((L, 0.0, 0.0), q), rest, k, kt)]
     rc, pd3, M3, f3 = oracle.OracleScene(teth).state_derivative(x, u)
     assert np.allclose(f3 - f0, kt * phi, rtol=1e-10)
+
+
+def test_vantage_point_tree_equals_linear_search(oracle):
+    """The tree-based CPU yardstick (oracle/vp_tree.hpp) is exact: same neighbours and distances as the linear search,
+    including a deliberate tie."""
+    rng = np.random.default_rng(8)
+    for D, n in ((3, 500), (6, 4000), (12, 3000)):
+        pts = rng.uniform(-1, 1, size=(n, D))
+        pts[n // 2] = pts[7]            # duplicate point: the lower index must win
+        q = rng.uniform(-1, 1, size=(200, D))
+        q[0] = pts[7]
+        li, ld = oracle.nn1(q, pts)
+        ti, td, _, _ = oracle.vptree_nn1(q, pts)
+        assert np.array_equal(li, ti) and np.array_equal(ld, td)
