@@ -85,3 +85,59 @@ def test_full_size_rrt_run_invariants(L, ctx):
     pl2.solve_planning_query()
     t2 = pl2.tree(0)
     assert np.array_equal(t2["parent"], first[0]) and np.array_equal(t2["pos"], first[1])
+
+
+def _components(n, eu, ev):
+    root = np.arange(n)
+
+    def find(a):
+        while root[a] != a:
+            root[a] = root[root[a]]
+            a = root[a]
+        return a
+
+    for a, b in zip(eu, ev):
+        ra, rb = find(int(a)), find(int(b))
+        if ra != rb:
+            root[rb] = ra
+    return np.array([find(i) for i in range(n)])
+
+
+def test_rrtstar_and_prm_invariants_at_scale(L, ctx):
+    """6-DOF chain / 50 obstacles in the quasi-static space, sizes the oracle needs minutes for: RRT* cost bookkeeping
+    (accumulated cost = predecessor's + edge length, the start is the only root, costs dominate straight-line
+    distances) and PRM roadmap bookkeeping (the union-find roots partition the vertices exactly like the edge list
+    does, densities in [0, 1], every loop iteration accounted for)."""
+    c3 = scenarios.make_c3(world_seed=1)
+    sc = L.Scene(ctx, c3)
+    lo, hi, mi = c3.meta["lower"], c3.meta["upper"], c3.meta["min_interval"]
+    qs = L.make_qs_space(6, lo, hi, mi)
+    ps = L.RrtStarPlanner(sc, [c3.rrt_params(seed=40 + i, max_vertices=15000) for i in range(4)], qs)
+    ps.solve_planning_query()
+    for i in range(4):
+        st, g = ps.all_stats[i], ps.graph(i)
+        n = int(st.num_vertices)
+        pred, dist, pos = g["pred"], g["dist"], g["pos"]
+        assert n == 15002 and pred[0] == 0 and dist[0] == 0.0
+        conn = np.flatnonzero((pred != 0xFFFFFFFF) & (np.arange(n) != 0))
+        seg = np.sqrt(((pos[conn] - pos[pred[conn]]) ** 2).sum(axis=1))
+        assert np.all(np.isfinite(dist[conn])) and np.all(dist[pred[conn]] < dist[conn])      # costs grow along the tree
+        assert np.all(np.abs(dist[conn] - (dist[pred[conn]] + seg)) <= 0.05 * seg + 1e-12)    # within the connection tol.
+        # triangle inequality, up to the connection tolerance (an edge's weight is the distance actually travelled)
+        assert np.all(dist[conn] >= 0.95 * np.sqrt(((pos[conn] - pos[0]) ** 2).sum(axis=1)) - 1e-9)
+        assert st.rewires > 1000 and st.num_solutions >= 1 and st.best_cost == dist[1]
+    ps.close()
+    pp = L.PrmPlanner(sc, [c3.prm_params(seed=60 + i, max_vertices=8000, sampling_radius=1.0) for i in range(8)], qs)
+    pp.solve_planning_query()
+    for i in range(8):
+        st, g = pp.all_stats[i], pp.graph(i)
+        n, ne = int(st.num_vertices), int(st.num_edges)
+        assert n == 8002 and ne == len(g["edge_u"]) and np.all(g["edge_w"] > 0)
+        assert np.all(g["edge_u"] < g["edge_v"])             # an edge joins an older vertex to the newest one
+        comp = _components(n, g["edge_u"], g["edge_v"])
+        assert len(np.unique(comp)) == st.num_components
+        mine = _components(n, np.arange(n), g["cc_root"])     # the planner's parent pointers define the same partition
+        assert np.array_equal(np.unique(comp, return_inverse=True)[1], np.unique(mine, return_inverse=True)[1])
+        assert np.all((g["density"] >= 0.0) & (g["density"] <= 1.0))
+        k = np.bincount(g["kind"], minlength=3)
+        assert k.sum() == st.loop_iterations and k[0] + k[1] == n - 2
