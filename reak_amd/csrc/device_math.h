@@ -104,6 +104,16 @@ RKH_DI void beam_force(d3 pos1, d4 q1, d3 pos2, d4 q2, double rest, double k, do
   *T = (kt * angle) * axis;
 }
 
+// the same beam on its anchor 2 (a chain frame): flexible_beam.cpp:178,184-185
+RKH_DI void beam_force_anchor2(d3 pos1, d4 q1, d3 pos2, d4 q2, double rest, double k, double kt, d3* F, d3* T) {
+  const d3 diff = pos1 - pos2;
+  const d3 diff_a2 = qrot(qinv(q2), diff) + mk3(rest, 0.0, 0.0);
+  d3 F1, T1;
+  beam_force(pos1, q1, pos2, q2, rest, k, kt, &F1, &T1);  // for the torsion term (angle * axis of anchor 1's frame)
+  *F = k * diff_a2;
+  *T = mk3(0, 0, 0) - T1;
+}
+
 // wave64 broadcast of a double from lane `src`
 RKH_DI double bcast(double v, int src) { return __shfl(v, src, 64); }
 

@@ -445,6 +445,8 @@ rkh_status enqueue_round(rkh_planner* p) {
     case 8: launch_fixup<8>(p, batch_ub); break;
     case 12: launch_fixup<12>(p, batch_ub); break;
     case 16: launch_fixup<16>(p, batch_ub); break;
+    case 24: launch_fixup<24>(p, batch_ub); break;
+    case 32: launch_fixup<32>(p, batch_ub); break;
     default: set_error("planner: unsupported state dimension"); return RKH_ERR_UNSUPPORTED;
   }
   // 4. commit the valid prefix
@@ -482,10 +484,6 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
                                         const rkh_rrt_params* prms, uint32_t n_problems, rkh_planner** out) {
   if (!scene || (!space && !qspace) || !prms || !out || n_problems < 1) return RKH_ERR_BAD_ARG;
   const int space_dof = space ? space->n_dof : qspace->n_dof;
-  if (space && scene->host.n_branches > 0) {
-    set_error("rkh_planner_create: the dynamics kernels support a single serial chain (use the quasi-static space)");
-    return RKH_ERR_UNSUPPORTED;
-  }
   if (space_dof != scene->host.n_dof) {
     set_error("rkh_planner_create: the space's n_dof does not match the scene");
     return RKH_ERR_BAD_ARG;
@@ -539,13 +537,16 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   if (const char* e = getenv("RKH_LANE_THRESHOLD")) p->lane_threshold = uint32_t(std::max(0, atoi(e)));
   if (const char* e = getenv("RKH_LANES_PER_EDGE")) {
     p->lanes_per_edge = (atoi(e) == 1) ? 1 : ((atoi(e) == 16) ? 16 : (atoi(e) == 0 ? 0 : 64));
-  } else if (p->n_dof <= 6) {
+  } else if (p->n_dof <= 6 && scene_fits_lane_kernel(scene->host)) {
     p->lanes_per_edge = 0;  // automatic, per round
   } else {
     // one wavefront per candidate is the latency-optimal mapping; once a round can offer more waves than the chip
     // has slots (256 CUs x 4 SIMDs x 2 waves) four candidates share a wave
     p->lanes_per_edge = (uint64_t(n_problems) * 2 * p->b_max > 4096) ? 16 : 64;
   }
+  if ((p->lanes_per_edge == 1 || p->lanes_per_edge == 0) && !(p->n_dof <= 7 && scene_fits_lane_kernel(scene->host)))
+    p->lanes_per_edge = 64;  // the two-lanes-per-edge kernel does not take this scene
+  if (p->lanes_per_edge == 16 && 2 * p->n_dof > 16) p->lanes_per_edge = 64;  // a 16-lane group holds at most 16 components
   if (const char* e = getenv("RKH_PROFILE_NN")) p->profile_nn = atoi(e) != 0;
   // candidates per round = batch_factor * sqrt(n): a single problem is latency-bound (bigger batches, fewer rounds), a
   // large batch of problems fills the chip anyway and prefers less discarded speculation (measured optimum 1.25)

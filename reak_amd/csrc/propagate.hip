@@ -54,7 +54,7 @@ struct __attribute__((aligned(16))) GroupWs {  // per-edge LDS workspace
   double Epos[N][3], Equat[N][4];   // joint end frames (jacobian parents)
   double Lpos[N][3], Lquat[N][4];   // link end frames (inertia frames)
   double FT[N][6];                  // inertia_3D d'Alembert force / torque (to be subtracted)
-  double BFT[6];                    // flexible beam force / torque on the last link's end frame (zero without a beam)
+  double BFT[2][6];                 // flexible beam force / torque on its two anchor frames (zero without a beam)
   double Tcm[N][N][6];              // [body][coord] jacobian column (v, w)
   double Mf[N][N];                  // Tcm^T (Mcm Tcm) before symmetrisation
   double M[N][N];                   // symmetric M, overwritten by its Cholesky factor
@@ -198,6 +198,14 @@ __device__ double state_derivative(const SceneDev* __restrict__ sc_beam, const C
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       const int jb = j * 32;
+      if (sc_beam->branch_start[j]) {  // a new branch: base frame * mount pose (rigid_link_3D::doMotion from frame 0)
+        const d4 bq = ld4(base + 3);
+        pos = ld3(base) + mul(rotmat(bq), ld3(sc_beam->mount_pos[j]));
+        Q = qmul(bq, ld4(sc_beam->mount_quat[j]));
+        w = mk3(0, 0, 0);
+        alpha = mk3(0, 0, 0);
+        acc = ld3(base + 7);
+      }
       const d3 axis = cget3(cp, jb + JC_AXIS);
       const d3 axis_n = cget3(cp, jb + JC_AXISN);
       const double c2 = ws.cs[j][0], s2 = ws.cs[j][1];
@@ -234,14 +242,26 @@ __device__ double state_derivative(const SceneDev* __restrict__ sc_beam, const C
       st3(lead ? ws.FT[j] : sink, Fi);
       st3(lead ? ws.FT[j] + 3 : sink, Ti);
     }
+  }
+  __syncthreads();
+  {
     // flexible_beam_3D::doForce (listed last in the chain, so it runs first in the reverse pass and its force is the
-    // first term of the tip frame's accumulators)
-    d3 BF = mk3(0, 0, 0), BT = mk3(0, 0, 0);
-    if (sc_beam->beam_on)
-      beam_force(pos, Q, ld3(sc_beam->beam_pos), ld4(sc_beam->beam_quat), sc_beam->beam_rest, sc_beam->beam_k,
-                 sc_beam->beam_kt, &BF, &BT);
-    st3(lead ? ws.BFT : sink, BF);
-    st3(lead ? ws.BFT + 3 : sink, BT);
+    // first term of its anchor frames' accumulators); anchors are link end frames (or a world anchor for anchor 2)
+    d3 BF1 = mk3(0, 0, 0), BT1 = mk3(0, 0, 0), BF2 = mk3(0, 0, 0), BT2 = mk3(0, 0, 0);
+    if (sc_beam->beam_on) {
+      const int j1 = sc_beam->beam_j1, j2 = sc_beam->beam_j2;
+      const d3 p1 = ld3(ws.Lpos[j1]);
+      const d4 q1 = ld4(ws.Lquat[j1]);
+      const d3 p2 = j2 >= 0 ? ld3(ws.Lpos[j2]) : ld3(sc_beam->beam_pos);
+      const d4 q2 = j2 >= 0 ? ld4(ws.Lquat[j2]) : ld4(sc_beam->beam_quat);
+      beam_force(p1, q1, p2, q2, sc_beam->beam_rest, sc_beam->beam_k, sc_beam->beam_kt, &BF1, &BT1);
+      if (j2 >= 0) beam_force_anchor2(p1, q1, p2, q2, sc_beam->beam_rest, sc_beam->beam_k, sc_beam->beam_kt, &BF2, &BT2);
+    }
+    __syncthreads();
+    st3(lead ? ws.BFT[0] : sink, BF1);
+    st3(lead ? ws.BFT[0] + 3 : sink, BT1);
+    st3(lead ? ws.BFT[1] : sink, BF2);
+    st3(lead ? ws.BFT[1] + 3 : sink, BT2);
   }
   __syncthreads();
   RKH_STAMP(1)
@@ -254,6 +274,7 @@ __device__ double state_derivative(const SceneDev* __restrict__ sc_beam, const C
       c -= b + 1;
       ++b;
     }
+    if (c < sc_beam->branch_first[b]) continue;  // joint c is not upstream of body b (another branch)
     const d3 cp = ld3(ws.Epos[c]);
     const d4 cq = ld4(ws.Equat[c]);
     const d3 bp = ld3(ws.Lpos[b]);
@@ -276,11 +297,25 @@ __device__ double state_derivative(const SceneDev* __restrict__ sc_beam, const C
   // ---- tip -> base sweep (kte_map_chain::doForce in reverse op order), group-uniform
   double f_mine = 0.0;  // lane i < N keeps generalized force i
   {
-    d3 LF = mk3(0, 0, 0) + ld3(ws.BFT), LT = mk3(0, 0, 0) + ld3(ws.BFT + 3);
+    d3 LF = mk3(0, 0, 0), LT = mk3(0, 0, 0);
+    const int bj1 = sc_beam->beam_on ? sc_beam->beam_j1 : -1, bj2 = sc_beam->beam_on ? sc_beam->beam_j2 : -1;
 #pragma unroll
     for (int j = N - 1; j >= 0; --j) {
       const int jb = j * 32;
       const d3 axis = cget3(cp, jb + JC_AXIS);
+      if (j + 1 < N && sc_beam->branch_start[j + 1]) {  // the joint above started another branch: this link is a tip
+        LF = mk3(0, 0, 0);
+        LT = mk3(0, 0, 0);
+      }
+      // the beam acted first on its anchor frames (reverse op order): (0 + beam) + what the child joint passes down
+      if (j == bj1) {
+        LF = LF + ld3(ws.BFT[0]);
+        LT = LT + ld3(ws.BFT[0] + 3);
+      }
+      if (j == bj2) {
+        LF = LF + ld3(ws.BFT[1]);
+        LT = LT + ld3(ws.BFT[1] + 3);
+      }
       // inertia_3D::doForce on the link end frame
       LF = LF - ld3(ws.FT[j]);
       LT = LT - ld3(ws.FT[j] + 3);
@@ -309,17 +344,23 @@ __device__ double state_derivative(const SceneDev* __restrict__ sc_beam, const C
 
   // ---- Mf = Tcm^T (Mcm Tcm), one lane per entry (i,j), summation order of
   //      mat_alg_symmetric.hpp:551-566 (Mcm*Tcm) and mat_operators.hpp:104-114 (dense product)
-  for (int e = gl; e < N * N; e += GL) {
+  // (the loop is uniform -- lanes without an entry in the last pass recompute the last entry and do not store -- and the
+  // v_readlane reads of the chain parameters sit outside the per-lane condition: a readlane must not pick a lane that
+  // was masked off when a run-time-indexed copy of the parameter registers was made)
+  for (int e0 = 0; e0 < N * N; e0 += GL) {
+    const bool e_valid = e0 + gl < N * N;
+    const int e = e_valid ? e0 + gl : N * N - 1;
     const int i = e / N, jx = e % N;
     double s = 0.0;
     if (i == jx) s = s + jl[i].joint_inertia;  // inertia_gen rows: Tcm = 1, Mcm = rotor inertia
 #pragma unroll
     for (int b = 0; b < N; ++b) {
-      if (b >= i && b >= jx) {
-        const int bb = b * 32;
-        const double mass = cget(cp, bb + JC_MASS);
-        const double inertia[6] = {cget(cp, bb + JC_INER), cget(cp, bb + JC_INER + 1), cget(cp, bb + JC_INER + 2),
-                                   cget(cp, bb + JC_INER + 3), cget(cp, bb + JC_INER + 4), cget(cp, bb + JC_INER + 5)};
+      const int bb = b * 32;
+      const double mass = cget(cp, bb + JC_MASS);
+      const double inertia[6] = {cget(cp, bb + JC_INER), cget(cp, bb + JC_INER + 1), cget(cp, bb + JC_INER + 2),
+                                 cget(cp, bb + JC_INER + 3), cget(cp, bb + JC_INER + 4), cget(cp, bb + JC_INER + 5)};
+      const int first_b = sc_beam->branch_first[b];
+      if (b >= i && b >= jx && i >= first_b && jx >= first_b) {
         const double* Ti = ws.Tcm[b][i];
         const double* Tj = ws.Tcm[b][jx];
         s = s + Ti[0] * (mass * Tj[0]);
@@ -331,7 +372,7 @@ __device__ double state_derivative(const SceneDev* __restrict__ sc_beam, const C
         s = s + Ti[5] * P.z;
       }
     }
-    ws.Mf[i][jx] = s;
+    if (e_valid) ws.Mf[i][jx] = s;
   }
   __syncthreads();
   // mat<symmetric>(general): 0.5 * (M(j,i) + M(i,j)), j < i  (mat_alg_symmetric.hpp:183-187)
@@ -685,11 +726,12 @@ __global__ __launch_bounds__(64) void state_derivative_kernel(const SceneDev* __
   if (singular && lane == 0) atomicExch(err_flag, int(RKH_ERR_SINGULAR));
   // exports for the kernel-level parity tests: the symmetric M is rebuilt from Mf (ws.M now holds its
   // Cholesky factor); the bias force was parked in ws.tmp by state_derivative.
-  if (M && lane < N * N) {
-    const int i = lane / N, j = lane % N;
-    const int lo = i < j ? i : j, hi = i < j ? j : i;
-    M[uint64_t(e) * N * N + lane] = (i == j) ? ws.Mf[i][i] : 0.5 * (ws.Mf[lo][hi] + ws.Mf[hi][lo]);
-  }
+  if (M)
+    for (int t = lane; t < N * N; t += 64) {
+      const int i = t / N, j = t % N;
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      M[uint64_t(e) * N * N + t] = (i == j) ? ws.Mf[i][i] : 0.5 * (ws.Mf[lo][hi] + ws.Mf[hi][lo]);
+    }
   if (f && lane < N) f[uint64_t(e) * N + lane] = ws.tmp[lane];
 }
 
@@ -919,8 +961,9 @@ __global__ __launch_bounds__(64) void min_distance_kernel(const SceneDev* __rest
     case 4: { constexpr int N = 4; CALL; } break; \
     case 6: { constexpr int N = 6; CALL; } break; \
     case 7: { constexpr int N = 7; CALL; } break; \
+    case 12: { constexpr int N = 12; CALL; } break; \
     default:                         \
-      set_error("propagate: chains with this number of joints are not instantiated (1,2,3,4,6,7)"); \
+      set_error("propagate: chains with this number of joints are not instantiated (1,2,3,4,6,7,12)"); \
       return RKH_ERR_UNSUPPORTED;    \
   }
 

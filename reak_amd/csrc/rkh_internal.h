@@ -113,7 +113,7 @@ struct SceneDev {
   int32_t n_dof;
   int32_t n_robot;   // robot shapes (anchored)
   int32_t n_env;     // environment shapes
-  int32_t beam_on;   // 1: a flexible_beam_3D ties the last link's end frame to a world anchor
+  int32_t beam_on;   // 1: the chain carries a flexible_beam_3D (see beam_j1 / beam_j2)
   double base_pos[3];
   double base_quat[4];
   double base_acc[3];
@@ -128,7 +128,10 @@ struct SceneDev {
   // starts from the chain base through a fixed mount (rigid_link_3D from frame 0; identity if the joint sits on the base)
   int32_t branch_start[kMaxDof];
   int32_t n_branches;  // joints with branch_start (0 for a plain serial chain)
+  int32_t beam_j1;     // the beam's anchor 1 is the link end frame of this joint
+  int32_t beam_j2;     // anchor 2: link end frame of this joint, or -1 = the world anchor (beam_pos, beam_quat)
   int32_t pad2;
+  int32_t branch_first[kMaxDof];  // first joint of the branch joint j belongs to
   double mount_pos[kMaxDof][3];
   double mount_quat[kMaxDof][4];
   // flexible_beam_3D (flexible_beam.cpp:155-193): rest length, stiffness, torsion stiffness, world anchor pose
@@ -236,6 +239,10 @@ rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev*
                             const EdgeIO* io_b = nullptr, uint32_t grid_b = 0, int lanes_per_edge = 64,
                             const EdgeIO* tab_a = nullptr, const EdgeIO* tab_b = nullptr, uint32_t n_problems = 1,
                             double* d_lane_ws = nullptr, KernelGate gate = KernelGate());
+// the two-lanes-per-edge kernel handles one serial chain, with at most a tip-to-world beam
+inline bool scene_fits_lane_kernel(const SceneDev& S) {
+  return S.n_branches == 0 && (!S.beam_on || (S.beam_j1 == S.n_dof - 1 && S.beam_j2 < 0));
+}
 // one lane per edge (propagate_lane.hip); d_ws: propagate_lanes_workspace_bytes() of device memory
 size_t propagate_lanes_workspace_bytes(int n_dof, uint32_t edges_a, uint32_t edges_b, uint32_t n_problems);
 rkh_status launch_propagate_lanes(hipStream_t s, int n_dof, const SceneDev* d_scene, const DynDev& dyn, const EdgeIO& io,

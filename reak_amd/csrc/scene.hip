@@ -142,6 +142,7 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
       ++S.n_branches;
       branch_first = j;
     }
+    S.branch_first[j] = branch_first;
     const uint32_t branch_mask = ((j + 1 >= 32 ? 0xFFFFFFFFu : ((1u << (j + 1)) - 1u))) & ~((1u << branch_first) - 1u);
     const bool ok = act.kind == RKH_KTE_DRIVING_ACTUATOR_GEN && gen.kind == RKH_KTE_INERTIA_GEN &&
                     rev.kind == RKH_KTE_REVOLUTE_JOINT_3D && lnk.kind == RKH_KTE_RIGID_LINK_3D &&
@@ -179,12 +180,20 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
   }
   if (has_beam) {
     const rkh_kte_op& bm = prog[n_ops];
-    if (bm.base_frame != link_end_frame[n - 1] || bm.end_frame != -1 || S.n_branches > 0) {
+    int j1 = -1, j2 = -1;
+    for (int j = 0; j < n; ++j) {
+      if (link_end_frame[j] == bm.base_frame) j1 = j;
+      if (bm.end_frame >= 0 && link_end_frame[j] == bm.end_frame) j2 = j;
+    }
+    if (j1 < 0 || (bm.end_frame >= 0 && j2 < 0) || j1 == j2) {
       delete sc;
-      set_error("rkh_scene_create: the flexible beam must tie the last link's end frame to a world anchor (end_frame = -1)");
+      set_error("rkh_scene_create: the flexible beam's anchors must be link end frames of the chain (anchor 2 may be a "
+                "world anchor, end_frame = -1)");
       return RKH_ERR_UNSUPPORTED;
     }
     S.beam_on = 1;
+    S.beam_j1 = j1;
+    S.beam_j2 = j2;
     S.beam_rest = bm.axis[0];
     S.beam_k = bm.axis[1];
     S.beam_kt = bm.axis[2];
@@ -287,13 +296,7 @@ struct DevBuf {  // scoped device scratch
   ~DevBuf() { if (p) hipFree(p); }
   template <typename T> T* as() { return static_cast<T*>(p); }
 };
-rkh_status reject_branches(const rkh_scene* scene) {  // the dynamics kernels assume one serial chain
-  if (scene->host.n_branches > 0) {
-    set_error("dynamics kernels support a single serial chain; this scene has branches (quasi-static entry points only)");
-    return RKH_ERR_UNSUPPORTED;
-  }
-  return RKH_OK;
-}
+rkh_status reject_branches(const rkh_scene*) { return RKH_OK; }  // the wave-per-edge dynamics kernels take branching chains
 rkh_status check_err_flag(rkh_scene* scene) {
   int flag = 0;
   RKH_HIP(hipMemcpy(&flag, scene->d_err, sizeof(int), hipMemcpyDeviceToHost));
@@ -389,6 +392,8 @@ rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const dou
   io.err_flag = scene->d_err;
   int lanes = 64;  // RKH_LANES_PER_EDGE = 64 | 16 | 1 selects the kernel mapping (identical results)
   if (const char* ev = getenv("RKH_LANES_PER_EDGE")) lanes = (atoi(ev) == 1) ? 1 : (atoi(ev) == 16 ? 16 : 64);
+  if (lanes == 1 && !(n <= 7 && scene_fits_lane_kernel(scene->host))) lanes = 64;  // not a scene for that mapping
+  if (lanes == 16 && 2 * n > 16) lanes = 64;
   DevBuf dws;
   if (lanes == 1) RKH_HIP(hipMalloc(&dws.p, propagate_lanes_workspace_bytes(n, B, 0, 1)));
   st = launch_propagate(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, dyn, io, B, nullptr, 0,

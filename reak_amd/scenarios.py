@@ -254,7 +254,7 @@ def make_c3(world_seed=1, min_interval=0.05):
     return scn
 
 
-def make_c4(world_seed=1, n_obstacles=200, capsule_radius=0.05, mount_y=0.35, min_interval=0.05):
+def make_c4(world_seed=1, n_obstacles=200, capsule_radius=0.05, mount_y=0.35, min_interval=0.05, beam=None):
     """BASELINE config C4 (kinematic part): 12-DOF dual arm -- two CRS-like 6-R arms on fixed mounts (rigid links from
     the chain base) at y = -/+ mount_y -- and 200 convex obstacles, planned in the quasi-static joint space (PRM).
     The reference's proximity module has closed-form pairs only (no meshes / GJK), so the obstacles are its spheres,
@@ -293,6 +293,16 @@ def make_c4(world_seed=1, n_obstacles=200, capsule_radius=0.05, mount_y=0.35, mi
             shapes.append(s)
             prev = frame + 1
             frame += 2
+    tips = []
+    for op in ops:
+        if op.kind == T.KTE_INERTIA_3D:
+            tips.append(op.end_frame)
+    if beam is not None:  # flexible_beam_3D between the two end effectors (BASELINE C4: k = 1e4 N/m, k_theta = 1e2)
+        b = T.KteOp(kind=T.KTE_FLEXIBLE_BEAM_3D, coord=-1, base_frame=tips[n1 - 1], end_frame=tips[2 * n1 - 1], joint_op=-1,
+                    upstream=0)
+        b.axis[:] = list(beam)
+        b.offset = T.make_pose()
+        ops.append(b)
     base = T.ChainBase()
     base.pose = T.make_pose()
     base.acceleration[:] = [0.0, 0.0, 9.81]
@@ -320,7 +330,13 @@ def make_c4(world_seed=1, n_obstacles=200, capsule_radius=0.05, mount_y=0.35, mi
         kinds.append(kind)
     n = 2 * n1
     goal = np.array([1.2, 0.8, -0.7, 0.4, 0.6, -0.3, -1.0, 0.7, -0.9, -0.5, 0.5, 0.4])
-    return Scenario(name="C4", ops=ops, base=base, shapes=shapes, dyn=None, n_dof=n, n_frames=frame,
+    dyn = T.DynSpace()   # the steerable dynamic space of C2, for both arms
+    dyn.n_dof, dyn.steps_per_edge, dyn.dt = n, 20, 1e-3
+    dyn.kp, dyn.kd, dyn.u_max, dyn.goal_tol = 50.0, 10.0, 50.0, 1e-3
+    for j in range(n):
+        dyn.lower[2 * j], dyn.upper[2 * j] = -np.pi, np.pi
+        dyn.lower[2 * j + 1], dyn.upper[2 * j + 1] = -2.0, 2.0
+    return Scenario(name="C4", ops=ops, base=base, shapes=shapes, dyn=dyn, n_dof=n, n_frames=frame,
                     start=np.zeros(n), goal=goal,
                     meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi), "min_interval": min_interval,
                           "world_seed": world_seed, "n_obstacles": n_obstacles, "obstacle_kinds": kinds})

@@ -530,9 +530,6 @@ def test_c4_dual_arm_quasi_static(L, ctx, oracle):
     pm = L.PrmPlanner(sc, pp, qs)
     st = pm.solve_planning_query()
     _prm_same(st, pm.graph(), ro, rg)
-    # the dynamics entry points refuse a branching scene
-    with pytest.raises(Exception):
-        sc.state_derivative(np.zeros((1, 24)), np.zeros((1, 12)))
 
 
 # ------------------------------------------------------------------ bidirectional RRT (a7, rr_tree.hpp:256-317)
@@ -657,3 +654,43 @@ def test_large_batch_in_auto_mode_matches_oracle(L, ctx, oracle, c2):
         assert np.array_equal(tree["nn_seq"], rtree["nn_seq"]) and np.array_equal(tree["accept"], rtree["accept"])
         assert np.array_equal(tree["parent"], rtree["parent"])
         assert np.allclose(tree["pos"], rtree["pos"], rtol=STATE_RTOL, atol=1e-12)
+
+
+# ------------------------------------------------------------------ C4 dynamics: branching chain + inter-arm beam
+def test_c4_dual_arm_dynamics_with_flexible_beam(L, ctx, oracle):
+    """12-DOF dual arm with the flexible_beam_3D between the two end effectors (k = 1e4 N/m, k_theta = 1e2): block-
+    diagonal mass matrix, bias forces with the beam on both tips, steer kernel and a short dynamic RRT in the 24-D state
+    space against the oracle."""
+    import copy
+
+    scn = scenarios.make_c4(world_seed=1, beam=(0.7, 1e4, 1e2))
+    sc, osc = L.Scene(ctx, scn), oracle.OracleScene(scn)
+    rng = np.random.default_rng(12)
+    lo = np.array([scn.dyn.lower[i] for i in range(24)])
+    hi = np.array([scn.dyn.upper[i] for i in range(24)])
+    x = rng.uniform(lo, hi, size=(64, 24))
+    u = rng.uniform(-40, 40, size=(64, 12))
+    rc, rpd, rM, rf = osc.state_derivative(x, u)
+    pd, M, f = sc.state_derivative(x, u)
+    assert rc == 0
+    assert np.max(np.abs(M - rM)) <= 1e-12 * np.abs(rM).max() and np.abs(rM[:, :6, 6:]).max() == 0.0
+    assert np.allclose(f, rf, rtol=1e-10, atol=1e-7) and np.allclose(pd, rpd, rtol=1e-9, atol=1e-7)
+    nobeam = oracle.OracleScene(scenarios.make_c4(world_seed=1))
+    assert np.abs(nobeam.state_derivative(x, u)[3] - rf).max() > 100.0     # the beam loads both arms
+    a = x * 0.4
+    a = a[osc.min_distance(a) > 0.01][:24]
+    b = rng.uniform(lo, hi, size=(a.shape[0], 24))
+    out, steps, _ = sc.steer_position_toward(a, b)
+    rc, rout, rsteps, _ = osc.steer(a, b)
+    assert np.array_equal(steps, rsteps) and np.allclose(out, rout, rtol=1e-9, atol=1e-9)
+    dyn_scn = copy.copy(scn)
+    dyn_scn.start = np.zeros(24)
+    dyn_scn.goal = np.zeros(24)
+    dyn_scn.goal[0::2] = scn.goal
+    prm = dyn_scn.rrt_params(seed=2, max_vertices=120)
+    rc, ro, rtree = osc.rrt_dyn(prm)
+    pl = L.RrtPlanner(sc, prm)
+    st = pl.solve_planning_query()
+    assert (st.num_vertices, st.iterations) == (ro.num_vertices, ro.iterations)
+    assert np.array_equal(pl.tree()["parent"], rtree["parent"])
+    assert np.allclose(pl.tree()["pos"], rtree["pos"], rtol=1e-9, atol=1e-9)
