@@ -34,7 +34,7 @@ enum rkh_kte_kind {
   /* flexible_beam_3D without an object frame (ctrl/mbd_kte/flexible_beam.cpp:155-193): a linear + torsional spring
    * between two anchors.  base_frame = mAnchor1 (a chain frame); end_frame = mAnchor2 (a chain frame) or -1 for an
    * anchor fixed in the world at pose `offset`; axis[0] = mRestLength, axis[1] = mStiffness, axis[2] = mTorsionStiffness.
-   * The HIP kernels support one beam, listed last in the chain, from the last link's end frame to a world anchor. */
+   * The HIP kernels support one beam, listed last in the chain, between link end frames (or to a world anchor). */
   RKH_KTE_FLEXIBLE_BEAM_3D = 6
 };
 
