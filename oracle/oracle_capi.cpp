@@ -2,6 +2,8 @@
 // Flat C entry points over the restatement so tests/ and bench.py's cpu_baseline leg can drive it
 // through ctypes.  Built by oracle/Makefile into oracle/liboracle.so (git-ignored).
 #include <chrono>
+#include <iomanip>
+#include <sstream>
 #include <cstring>
 #include <random>
 
@@ -457,6 +459,35 @@ int orc_vptree_nn1(const double* q, uint32_t B, const double* pts, uint64_t n, i
   if (build_seconds) *build_seconds = std::chrono::duration<double>(t1 - t0).count();
   if (query_seconds) *query_seconds = std::chrono::duration<double>(t2 - t1).count();
   return 0;
+}
+
+
+// ---- report text through a real iostream (pins reak_amd/reports.py):
+// any_mg_vertex_printer::operator() R/ctrl/path_planning/any_motion_graphs.hpp:666-700 and the file name of
+// vlist_sbmp_report::draw_motion_graph R/ctrl/path_planning/vlist_sbmp_report.hpp:105-107
+int64_t orc_format_vlist(const double* pos, uint64_t n, int D, const double* dist_accum, const double* density,
+                         char* out, uint64_t cap, char* name, uint64_t name_cap) {
+  std::ostringstream ss;
+  for (uint64_t v = 0; v < n; ++v) {
+    for (int i = 0; i < D; ++i) ss << " " << std::setw(10) << pos[v * D + i];
+    if (dist_accum) ss << " " << std::setw(10) << dist_accum[v];
+    if (density) ss << " " << std::setw(10) << density[v];
+    ss << std::endl;
+  }
+  std::stringstream nm;
+  nm << std::setw(6) << std::setfill('0') << n;
+  const std::string text = ss.str(), fname = "vlist_" + nm.str();
+  if (name && fname.size() + 1 <= name_cap) std::memcpy(name, fname.c_str(), fname.size() + 1);
+  if (out && text.size() <= cap) std::memcpy(out, text.data(), text.size());
+  return int64_t(text.size());
+}
+// least_cost_sbmp_report progress line, basic_sbmp_reporters.hpp:532-534
+int64_t orc_format_cost_line(uint64_t n, double best, char* out, uint64_t cap) {
+  std::ostringstream ss;
+  ss << std::size_t(n) << " " << best << std::endl;
+  const std::string text = ss.str();
+  if (out && text.size() <= cap) std::memcpy(out, text.data(), text.size());
+  return int64_t(text.size());
 }
 
 // copy the arrays of the last RRT run
