@@ -35,7 +35,12 @@ enum rkh_kte_kind {
    * between two anchors.  base_frame = mAnchor1 (a chain frame); end_frame = mAnchor2 (a chain frame) or -1 for an
    * anchor fixed in the world at pose `offset`; axis[0] = mRestLength, axis[1] = mStiffness, axis[2] = mTorsionStiffness.
    * The HIP kernels support one beam, listed last in the chain, between link end frames (or to a world anchor). */
-  RKH_KTE_FLEXIBLE_BEAM_3D = 6
+  RKH_KTE_FLEXIBLE_BEAM_3D = 6,
+  /* Planar chains (position level: quasi-static free spaces).  Poses are pose_2D<double> carried in rkh_pose as
+   * pos[0..1] = Position and quat[0..1] = rot_mat_2D::q = (cos, sin) (core/kinetostatics/rotations_2D.hpp:89);
+   * a chain is planar when its joints are REVOLUTE_JOINT_2D, and then all its links and shapes must be 2D. */
+  RKH_KTE_REVOLUTE_JOINT_2D = 7,    /* ctrl/mbd_kte/revolute_joint.cpp:30-56     : coord, base, end           */
+  RKH_KTE_RIGID_LINK_2D = 8         /* ctrl/mbd_kte/rigid_link.cpp:87-99         : base, end, pose offset     */
 };
 
 typedef struct rkh_kte_op {
@@ -63,7 +68,11 @@ typedef struct rkh_chain_base {
 enum rkh_shape_kind {
   RKH_SHAPE_SPHERE = 1,    /* dims[0] = radius                              */
   RKH_SHAPE_BOX = 2,       /* dims[0..2] = full side lengths (mDimensions)  */
-  RKH_SHAPE_CCYLINDER = 3  /* dims[0] = length, dims[1] = radius (capped_cylinder, axis = local z) */
+  RKH_SHAPE_CCYLINDER = 3, /* dims[0] = length, dims[1] = radius (capped_cylinder, axis = local z) */
+  /* shape_2D subclasses (geometry/shapes/{circle,rectangle,capped_rectangle}.hpp), pose = pose_2D (see above) */
+  RKH_SHAPE_CIRCLE = 4,    /* dims[0] = radius                                                      */
+  RKH_SHAPE_RECTANGLE = 5, /* dims[0..1] = full side lengths (mDimensions)                          */
+  RKH_SHAPE_CRECT = 6      /* capped_rectangle: dims[0] = length along local x, dims[1] = width = cap diameter */
 };
 
 typedef struct rkh_shape {

@@ -174,6 +174,13 @@ void orc_fk(void* h, const double* x, int B, double* frames) {
     s->chain.apply_kinematics(x + std::size_t(b) * 2 * n);
     for (int k = 0; k < nf; ++k) {
       double* o = frames + (std::size_t(b) * nf + k) * 7;
+      if (s->chain.planar) {  // pose_2D: (x, y, 0) and (cos, sin, 0, 0)
+        o[0] = s->chain.frames2[k].Position[0];
+        o[1] = s->chain.frames2[k].Position[1];
+        o[3] = s->chain.frames2[k].Rotation.q[0];
+        o[4] = s->chain.frames2[k].Rotation.q[1];
+        continue;
+      }
       for (int i = 0; i < 3; ++i) o[i] = s->chain.frames[k].Position[i];
       for (int i = 0; i < 4; ++i) o[3 + i] = s->chain.frames[k].Q.q[i];
     }
@@ -193,6 +200,18 @@ double orc_pair_distance(const rkh_shape* a, const rkh_shape* b) {
   std::vector<rkh_shape> sh = {*a, *b};
   sh[0].anchor = 0;  // model 1
   sh[1].anchor = -1; // model 2
+  if (sh[0].kind >= RKH_SHAPE_CIRCLE || sh[1].kind >= RKH_SHAPE_CIRCLE) {  // planar pair (proxy_query_pair_2D)
+    std::vector<ProxFinder2> f2;
+    createProxFinderList2D(sh, {0}, {1}, f2);
+    if (f2.empty()) return std::numeric_limits<double>::quiet_NaN();
+    std::vector<ShapeG2> g2(2);
+    for (int i = 0; i < 2; ++i) {
+      g2[i].kind = sh[i].kind;
+      g2[i].g = to_pose2(sh[i].pose);
+      for (int k = 0; k < 2; ++k) g2[i].dims[k] = sh[i].dims[k];
+    }
+    return computeProximity2D(f2[0], g2).mDistance;
+  }
   std::vector<ProxFinder> f;
   createProxFinderList(sh, {0}, {1}, f);
   if (f.empty()) return std::numeric_limits<double>::quiet_NaN();

@@ -15,6 +15,7 @@
 
 #include "../include/rkh_types.h"
 #include "reak_math.hpp"
+#include "reak_planar.hpp"
 
 namespace oracle {
 
@@ -42,6 +43,8 @@ struct KteChain {
   int n_coords = 0, n_frames = 0;
   std::vector<GenCoord> coords;
   std::vector<Frame> frames;
+  std::vector<Pose2> frames2;   // planar chains: frame_2D Position / Rotation per frame index
+  bool planar = false;
   std::vector<double> drive;    // driving_actuator_gen::mDriveForce per coord (system input)
   std::vector<JacGen3D> jac;    // per coord: the revolute joint's mJacobian
   std::vector<int> gen_inertias, inertias_3D;  // op indices, registration order of mass_matrix_calc
@@ -56,6 +59,8 @@ struct KteChain {
     }
     coords.assign(n_coords, GenCoord());
     frames.assign(n_frames, Frame());
+    frames2.assign(n_frames, Pose2());
+    for (const auto& op : ops) planar = planar || op.kind == RKH_KTE_REVOLUTE_JOINT_2D;
     drive.assign(n_coords, 0.0);
     jac.assign(n_coords, JacGen3D());
     for (int i = 0; i < n_ops; ++i) {
@@ -71,6 +76,7 @@ struct KteChain {
     f.Q = Quat(base.pose.quat[0], base.pose.quat[1], base.pose.quat[2], base.pose.quat[3]);
     f.Acceleration = V3(base.acceleration[0], base.acceleration[1], base.acceleration[2]);
     frames[0] = f;
+    frames2[0] = to_pose2(base.pose);
   }
 
   // kte_map_chain::doMotion: kte_map_chain.hpp:71-76
@@ -79,6 +85,16 @@ struct KteChain {
       switch (op.kind) {
         case RKH_KTE_REVOLUTE_JOINT_3D: revolute_doMotion(op); break;
         case RKH_KTE_RIGID_LINK_3D: link_doMotion(op); break;
+        case RKH_KTE_REVOLUTE_JOINT_2D:  // revolute_joint_2D::doMotion, revolute_joint.cpp:30-47 (pose part)
+          frames2[op.end_frame].Position = frames2[op.base_frame].Position;
+          frames2[op.end_frame].Rotation = frames2[op.base_frame].Rotation * rot_from_angle(coords[op.coord].q);
+          break;
+        case RKH_KTE_RIGID_LINK_2D: {  // rigid_link_2D::doMotion, rigid_link.cpp:87-99 (pose part)
+          const Pose2 off = to_pose2(op.offset);
+          frames2[op.end_frame].Position = frames2[op.base_frame].Position + frames2[op.base_frame].Rotation * off.Position;
+          frames2[op.end_frame].Rotation = frames2[op.base_frame].Rotation * off.Rotation;
+          break;
+        }
         default: break;  // inertia_*::doMotion (inertia.cpp:36-45,100-109) and actuators only store
       }
     }

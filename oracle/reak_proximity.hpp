@@ -326,12 +326,25 @@ struct ProxyEnv {
   std::vector<rkh_shape> shapes;
   std::vector<int> robot, env;
   std::vector<ProxFinder> finders;
+  std::vector<ProxFinder2> finders2;  // planar scenes: proxy_query_pair_2D
+  bool planar = false;
   long n_pair_tests = 0;
 
   ProxyEnv() {}
   ProxyEnv(const rkh_shape* s, int n) : shapes(s, s + n) {
     for (int i = 0; i < n; ++i) (shapes[i].anchor >= 0 ? robot : env).push_back(i);
-    createProxFinderList(shapes, robot, env, finders);
+    for (int i = 0; i < n; ++i) planar = planar || shapes[i].kind >= RKH_SHAPE_CIRCLE;
+    if (planar) createProxFinderList2D(shapes, robot, env, finders2);
+    else createProxFinderList(shapes, robot, env, finders);
+  }
+  void resolve2(const KteChain& chain, std::vector<ShapeG2>& g) const {
+    g.resize(shapes.size());
+    for (std::size_t i = 0; i < shapes.size(); ++i) {
+      g[i].kind = shapes[i].kind;
+      for (int k = 0; k < 2; ++k) g[i].dims[k] = shapes[i].dims[k];
+      const Pose2 local = to_pose2(shapes[i].pose);
+      g[i].g = shapes[i].anchor >= 0 ? global_pose2(&chain.frames2[shapes[i].anchor], local) : local;
+    }
   }
   // Resolve every shape's global pose from the chain frames (pose_3D::getGlobalPose, pose_3D.hpp:102-110)
   void resolve(const KteChain& chain, std::vector<ShapeG>& g) const {
@@ -351,6 +364,11 @@ struct ProxyEnv {
     }
   }
   double min_distance(const KteChain& chain) {
+    if (planar) {
+      std::vector<ShapeG2> g2;
+      resolve2(chain, g2);
+      return findMinimumDistance2D(finders2, g2, &n_pair_tests);
+    }
     std::vector<ShapeG> g;
     resolve(chain, g);
     return findMinimumDistance(finders, g, &n_pair_tests);

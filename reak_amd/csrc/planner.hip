@@ -687,6 +687,10 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
 rkh_status rkh_planner_create_batch(rkh_scene* scene, const rkh_dyn_space* space, const rkh_rrt_params* prms,
                                     uint32_t n_problems, rkh_planner** out) {
   if (!space) return RKH_ERR_BAD_ARG;
+  if (scene && scene->host.planar) {
+    set_error("planar (2D) chains are built at position level: quasi-static spaces only, no dynamics");
+    return RKH_ERR_UNSUPPORTED;
+  }
   return planner_create_common(scene, space, nullptr, prms, n_problems, out);
 }
 

@@ -31,6 +31,7 @@
 
 #include "device_math.h"
 #include "proximity_device.h"
+#include "proximity_planar_device.h"
 #include "rkh_internal.h"
 
 namespace rkh {
@@ -438,6 +439,86 @@ __device__ double state_derivative(const SceneDev* __restrict__ sc_beam, const C
   return out;
 }
 
+// Planar scenes (SceneDev::planar): revolute_joint_2D / rigid_link_2D kinematics (revolute_joint.cpp:30-47,
+// rigid_link.cpp:87-99), pose_2D::getGlobalPose of the robot shapes, then proxy_query_pair_2D::findMinimumDistance
+// (proxy_query_model.cpp:163-189) replayed in finder order: every lane computes one pair's cull value and distance,
+// and the sequence "skip if cull > running minimum, else take the minimum" is resolved lane by lane.
+template <int N, int GL, typename WS>
+__device__ double proximity_min_planar(const SceneDev* __restrict__ sc, const CPack<N>& cp, const double* __restrict__ base,
+                                       const ShapeDev* __restrict__ env_lds, const PairDev* __restrict__ pairs, int n_pairs,
+                                       WS& ws, int gl, int gb) {
+  for (int jj = gl; jj < N; jj += GL) {
+    double sn, cs;
+    sincos(ws.x[2 * jj], &sn, &cs);
+    ws.cs[jj][0] = cs;
+    ws.cs[jj][1] = sn;
+  }
+  __syncthreads();
+  {
+    d2 pos = mk2(base[0], base[1]);
+    d2 R = mk2(base[3], base[4]);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int jb = j * 32;
+      const d2 ER = rmul(R, mk2(ws.cs[j][0], ws.cs[j][1]));
+      if (gl == 0) {
+        ws.Epos[j][0] = pos.x;
+        ws.Epos[j][1] = pos.y;
+        ws.Equat[j][0] = ER.x;
+        ws.Equat[j][1] = ER.y;
+      }
+      pos = pos + rrot(ER, mk2(cget(cp, jb + JC_OFFP), cget(cp, jb + JC_OFFP + 1)));
+      R = rmul(ER, mk2(cget(cp, jb + JC_OFFQ), cget(cp, jb + JC_OFFQ + 1)));
+    }
+  }
+  __syncthreads();
+  for (int r = gl; r < sc->n_robot; r += GL) {
+    const ShapeDev& sh = sc->robot[r];
+    const int j = sh.link;
+    const d2 pp = mk2(ws.Epos[j][0], ws.Epos[j][1]);
+    const d2 pr = mk2(ws.Equat[j][0], ws.Equat[j][1]);
+    const d2 gp = pp + rrot(pr, mk2(sh.pos[0], sh.pos[1]));
+    const d2 gr = rmul(pr, mk2(sh.quat[0], sh.quat[1]));
+    ws.Rpos[r][0] = gp.x;
+    ws.Rpos[r][1] = gp.y;
+    ws.Rquat[r][0] = gr.x;
+    ws.Rquat[r][1] = gr.y;
+  }
+  __syncthreads();
+  double min_dist = INFINITY;
+  for (int p0 = 0; p0 < n_pairs; p0 += GL) {
+    const int p = p0 + gl;
+    double d = INFINITY, c = INFINITY;
+    if (p < n_pairs) {
+      const PairDev pr = pairs[p];
+      const ShapeDev& rs = sc->robot[pr.robot];
+      const ShapeDev& es = env_lds[pr.env];
+      ShapeP A, Bv;
+      A.kind = rs.kind;
+      A.pos = mk2(ws.Rpos[pr.robot][0], ws.Rpos[pr.robot][1]);
+      A.rot = mk2(ws.Rquat[pr.robot][0], ws.Rquat[pr.robot][1]);
+      A.d0 = rs.dims[0]; A.d1 = rs.dims[1];
+      Bv.kind = es.kind;
+      Bv.pos = mk2(es.pos[0], es.pos[1]);
+      Bv.rot = mk2(es.quat[0], es.quat[1]);
+      Bv.d0 = es.dims[0]; Bv.d1 = es.dims[1];
+      const ShapeP& s1 = pr.s1_is_robot ? A : Bv;
+      const ShapeP& s2 = pr.s1_is_robot ? Bv : A;
+      const double r1 = pr.s1_is_robot ? rs.brad : es.brad;
+      const double r2 = pr.s1_is_robot ? es.brad : rs.brad;
+      c = norm_2(to_parent(s2, mk2(0.0, 0.0)) - to_parent(s1, mk2(0.0, 0.0))) - r1 - r2;
+      d = pair_distance_planar(pr.routine, s1, s2);
+    }
+    const int cnt = (n_pairs - p0 < GL) ? (n_pairs - p0) : GL;
+    for (int l = 0; l < cnt; ++l) {
+      const double cl = __shfl(c, gb + l, 64), dl = __shfl(d, gb + l, 64);
+      if (p0 + l == 0) min_dist = dl;                       // the first finder is always computed
+      else if (!(cl > min_dist) && dl < min_dist) min_dist = dl;
+    }
+  }
+  return min_dist;
+}
+
 // Proximity of the configuration in ws.x (joint angles): minimum distance over computed pairs.
 // With cull_positive, pairs whose bounding spheres are apart are skipped (they cannot make the verdict
 // "colliding"; proxy_query_model.cpp:386-389 culls the same way against the running minimum) and the scan
@@ -447,6 +528,7 @@ __device__ double proximity_min(const SceneDev* __restrict__ sc, const CPack<N>&
                                 const double* __restrict__ base, const ShapeDev* __restrict__ env_lds,
                                 const PairDev* __restrict__ pairs, int n_pairs, WS& ws,
                                 double* __restrict__ sink, int gl, int gb, bool cull_positive, bool group_done) {
+  if (sc->planar) return proximity_min_planar<N, GL>(sc, cp, base, env_lds, pairs, n_pairs, ws, gl, gb);
   const bool lead = (gl == 0);
   // half-angle sin/cos, one joint per lane (strided: a 16-lane group may carry more than 16 / 2 joints)
   for (int jj = gl; jj < N; jj += GL) {

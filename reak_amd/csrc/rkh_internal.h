@@ -130,7 +130,7 @@ struct SceneDev {
   int32_t n_branches;  // joints with branch_start (0 for a plain serial chain)
   int32_t beam_j1;     // the beam's anchor 1 is the link end frame of this joint
   int32_t beam_j2;     // anchor 2: link end frame of this joint, or -1 = the world anchor (beam_pos, beam_quat)
-  int32_t pad2;
+  int32_t planar;      // 1: planar chain (revolute_joint_2D / rigid_link_2D, 2D shapes): poses carry (x, y) and (cos, sin)
   int32_t branch_first[kMaxDof];  // first joint of the branch joint j belongs to
   double mount_pos[kMaxDof][3];
   double mount_quat[kMaxDof][4];

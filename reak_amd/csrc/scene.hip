@@ -72,11 +72,130 @@ rkh_status build_dyn_dev(const rkh_dyn_space& sp, double fraction, DynDev* out) 
 
 }  // namespace rkh
 
+static rkh_status upload_scene(rkh_ctx* ctx, rkh_scene* sc, const std::vector<PairDev>& pairs, rkh_scene** out) {
+  const SceneDev& S = sc->host;
+  sc->n_pairs = int(pairs.size());
+  RKH_HIP(hipSetDevice(ctx->device));
+  RKH_HIP(hipMalloc(&sc->d_scene, sizeof(SceneDev)));
+  RKH_HIP(hipMemcpy(sc->d_scene, &S, sizeof(SceneDev), hipMemcpyHostToDevice));
+  RKH_HIP(hipMalloc(&sc->d_pairs, std::max<size_t>(1, pairs.size()) * sizeof(PairDev)));
+  if (!pairs.empty()) RKH_HIP(hipMemcpy(sc->d_pairs, pairs.data(), pairs.size() * sizeof(PairDev), hipMemcpyHostToDevice));
+  RKH_HIP(hipMalloc(&sc->d_err, sizeof(int)));
+  RKH_HIP(hipMemset(sc->d_err, 0, sizeof(int)));
+  *out = sc;
+  return RKH_OK;
+}
+
+// Planar chain (manip_3R_arm.cpp:75-150 pattern): {revolute_joint_2D, rigid_link_2D} per joint, 2D shapes only.
+// Position level: the scene serves the quasi-static entry points; the dynamics entry points refuse it.
+static rkh_status create_planar_scene(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, const rkh_chain_base* base,
+                                      const rkh_shape* shapes, int n_shapes, rkh_scene** out) {
+  const int n = n_ops / 2;
+  if (n_ops % 2 != 0 || n < 1 || n > kMaxDof) {
+    set_error("rkh_scene_create: a planar chain is a sequence of {revolute_joint_2D, rigid_link_2D} pairs");
+    return RKH_ERR_UNSUPPORTED;
+  }
+  rkh_scene* sc = new rkh_scene();
+  sc->ctx = ctx;
+  SceneDev& S = sc->host;
+  std::memset(&S, 0, sizeof(S));
+  S.n_dof = n;
+  S.planar = 1;
+  for (int i = 0; i < 2; ++i) {
+    S.base_pos[i] = base->pose.pos[i];
+    S.base_quat[i] = base->pose.quat[i];
+  }
+  std::vector<int> joint_end_frame(n);
+  int prev_end = 0;
+  for (int j = 0; j < n; ++j) {
+    const rkh_kte_op& rev = prog[2 * j], &lnk = prog[2 * j + 1];
+    if (rev.kind != RKH_KTE_REVOLUTE_JOINT_2D || lnk.kind != RKH_KTE_RIGID_LINK_2D || rev.coord != j ||
+        rev.base_frame != prev_end || lnk.base_frame != rev.end_frame) {
+      delete sc;
+      set_error("rkh_scene_create: planar op pair " + std::to_string(j) + " does not continue the serial chain");
+      return RKH_ERR_UNSUPPORTED;
+    }
+    prev_end = lnk.end_frame;
+    joint_end_frame[j] = rev.end_frame;
+    JointDev& J = S.joints[j];
+    for (int i = 0; i < 2; ++i) {
+      J.off_pos[i] = lnk.offset.pos[i];
+      J.off_quat[i] = lnk.offset.quat[i];
+    }
+    S.mount_quat[j][0] = 1.0;
+  }
+  for (int i = 0; i < n_shapes; ++i) {
+    const rkh_shape& s = shapes[i];
+    if (s.kind < RKH_SHAPE_CIRCLE || s.kind > RKH_SHAPE_CRECT) {
+      delete sc;
+      set_error("rkh_scene_create: a planar chain takes 2D shapes only (circle, rectangle, capped_rectangle)");
+      return RKH_ERR_UNSUPPORTED;
+    }
+    ShapeDev d;
+    std::memset(&d, 0, sizeof(d));
+    d.kind = s.kind;
+    for (int k = 0; k < 2; ++k) {
+      d.pos[k] = s.pose.pos[k];
+      d.quat[k] = s.pose.quat[k];
+      d.dims[k] = s.dims[k];
+    }
+    // circle.cpp:31-33 ; rectangle.cpp:31-33 and capped_rectangle.cpp:31-33: norm_2(mDimensions) * 0.5
+    d.brad = (s.kind == RKH_SHAPE_CIRCLE) ? s.dims[0] : std::sqrt((0.0 + s.dims[0] * s.dims[0]) + s.dims[1] * s.dims[1]) * 0.5;
+    if (s.anchor >= 0) {
+      int link = -1;
+      for (int j = 0; j < n; ++j)
+        if (joint_end_frame[j] == s.anchor) link = j;
+      if (link < 0 || S.n_robot >= 2 * kMaxDof) {
+        delete sc;
+        set_error("rkh_scene_create: robot shapes must be anchored on a revolute joint's end frame");
+        return RKH_ERR_UNSUPPORTED;
+      }
+      d.link = link;
+      S.robot[S.n_robot++] = d;
+    } else {
+      if (S.n_env >= kMaxEnvShapes) {
+        delete sc;
+        set_error("rkh_scene_create: too many environment shapes");
+        return RKH_ERR_CAPACITY;
+      }
+      d.link = -1;
+      S.env[S.n_env++] = d;
+    }
+  }
+  // proxy_query_pair_2D::createProxFinderList (proxy_query_model.cpp:75-161), kept in its i-major / j-minor order:
+  // findMinimumDistance (:163-189) culls against the running minimum with a radius the capped rectangle's caps
+  // reach beyond, so the result depends on the order and the device replays the sequence
+  std::vector<PairDev> pairs;
+  for (int i = 0; i < S.n_robot; ++i)
+    for (int j = 0; j < S.n_env; ++j) {
+      const int ki = S.robot[i].kind, kj = S.env[j].kind;
+      PairDev p;
+      std::memset(&p, 0, sizeof(p));
+      p.robot = uint16_t(i);
+      p.env = uint16_t(j);
+      if (ki == RKH_SHAPE_CIRCLE || kj == RKH_SHAPE_CIRCLE) {
+        p.s1_is_robot = (ki == RKH_SHAPE_CIRCLE) ? 1 : 0;  // the circle is shape1
+        const int ko = p.s1_is_robot ? kj : ki;
+        p.routine = (ko == RKH_SHAPE_CIRCLE) ? 11 : (ko == RKH_SHAPE_CRECT ? 12 : 13);
+      } else if (ki == RKH_SHAPE_CRECT || kj == RKH_SHAPE_CRECT) {
+        p.s1_is_robot = (ki == RKH_SHAPE_CRECT) ? 1 : 0;  // the capped rectangle is shape1
+        const int ko = p.s1_is_robot ? kj : ki;
+        p.routine = (ko == RKH_SHAPE_CRECT) ? 14 : 15;
+      } else {
+        p.s1_is_robot = 1;  // rectangle-rectangle: model1's shape is shape1
+        p.routine = 16;
+      }
+      pairs.push_back(p);
+    }
+  return upload_scene(ctx, sc, pairs, out);
+}
+
 extern "C" {
 
 rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, const rkh_chain_base* base,
                             const rkh_shape* shapes, int n_shapes, rkh_scene** out) {
   if (!ctx || !prog || !base || !out || n_ops < 1 || (n_shapes > 0 && !shapes)) return RKH_ERR_BAD_ARG;
+  if (prog[0].kind == RKH_KTE_REVOLUTE_JOINT_2D) return create_planar_scene(ctx, prog, n_ops, base, shapes, n_shapes, out);
   const bool has_beam = n_ops > 1 && prog[n_ops - 1].kind == RKH_KTE_FLEXIBLE_BEAM_3D;
   if (has_beam) --n_ops;  // the beam is validated below, after the chain
   // parse: [optional mount link from frame 0] {actuator, inertia_gen, revolute, link, inertia_3D} ...
@@ -265,16 +384,7 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
       pairs.push_back(p);
     }
   std::stable_sort(pairs.begin(), pairs.end(), [](const PairDev& a, const PairDev& b) { return a.routine < b.routine; });
-  sc->n_pairs = int(pairs.size());
-  RKH_HIP(hipSetDevice(ctx->device));
-  RKH_HIP(hipMalloc(&sc->d_scene, sizeof(SceneDev)));
-  RKH_HIP(hipMemcpy(sc->d_scene, &S, sizeof(SceneDev), hipMemcpyHostToDevice));
-  RKH_HIP(hipMalloc(&sc->d_pairs, std::max<size_t>(1, pairs.size()) * sizeof(PairDev)));
-  if (!pairs.empty()) RKH_HIP(hipMemcpy(sc->d_pairs, pairs.data(), pairs.size() * sizeof(PairDev), hipMemcpyHostToDevice));
-  RKH_HIP(hipMalloc(&sc->d_err, sizeof(int)));
-  RKH_HIP(hipMemset(sc->d_err, 0, sizeof(int)));
-  *out = sc;
-  return RKH_OK;
+  return upload_scene(ctx, sc, pairs, out);
 }
 
 rkh_status rkh_scene_destroy(rkh_scene* scene) {
@@ -296,7 +406,14 @@ struct DevBuf {  // scoped device scratch
   ~DevBuf() { if (p) hipFree(p); }
   template <typename T> T* as() { return static_cast<T*>(p); }
 };
-rkh_status reject_branches(const rkh_scene*) { return RKH_OK; }  // the wave-per-edge dynamics kernels take branching chains
+// dynamics entry points: branching chains are fine (wave-per-edge kernels); planar chains are position level only
+rkh_status reject_branches(const rkh_scene* scene) {
+  if (scene->host.planar) {
+    set_error("planar (2D) chains are built at position level: quasi-static spaces only, no dynamics");
+    return RKH_ERR_UNSUPPORTED;
+  }
+  return RKH_OK;
+}
 rkh_status check_err_flag(rkh_scene* scene) {
   int flag = 0;
   RKH_HIP(hipMemcpy(&flag, scene->d_err, sizeof(int), hipMemcpyDeviceToHost));

@@ -243,6 +243,88 @@ def make_c1(world_seed=1, n_obstacles=10, min_interval=0.05):
     return scn
 
 
+def make_c1_planar(world_seed=1, n_obstacles=10, min_interval=0.05, link_width=0.08):
+    """BASELINE config C1 with the reference's own 2D classes: the planar 3R arm of ctrl/kte_models/manip_3R_arm.cpp:45-152
+    (revolute_joint_2D / rigid_link_2D, link lengths 0.5, 0.5, 0.3), links = capped_rectangle of width 0.08 anchored on
+    the joints' end frames, obstacles = rectangle (0.2-0.5 m sides, centres uniform in [-1.5, 1.5]^2, uniform yaw),
+    rejected if they come near the start (stretched along +x) or goal (along +y) configuration."""
+    rng = np.random.Generator(np.random.PCG64(1000 + world_seed))
+    lengths = [0.5, 0.5, 0.3]
+    n = 3
+    ops, shapes = [], []
+    for j in range(n):
+        ops.append(T.KteOp(kind=T.KTE_REVOLUTE_JOINT_2D, coord=j, base_frame=2 * j, end_frame=2 * j + 1, joint_op=-1))
+        l = T.KteOp(kind=T.KTE_RIGID_LINK_2D, coord=-1, base_frame=2 * j + 1, end_frame=2 * j + 2, joint_op=-1)
+        l.offset = T.make_pose_2d((lengths[j], 0.0))
+        ops.append(l)
+        s = T.Shape(kind=T.SHAPE_CRECT, anchor=2 * j + 1)
+        s.pose = T.make_pose_2d((0.5 * lengths[j], 0.0))
+        s.dims[:] = [lengths[j], link_width, 0.0]
+        shapes.append(s)
+    base = T.ChainBase()
+    base.pose = T.make_pose_2d()
+    placed = 0
+    while placed < n_obstacles:
+        c = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.5, 1.5), 0.0])
+        d = np.array([rng.uniform(0.2, 0.5), rng.uniform(0.2, 0.5)])
+        yaw = rng.uniform(-np.pi, np.pi)
+        brad = 0.5 * np.hypot(d[0], d[1])
+        if _dist_point_segment(c, np.zeros(3), np.array([1.3, 0, 0])) < brad + 0.1:
+            continue
+        if _dist_point_segment(c, np.zeros(3), np.array([0, 1.3, 0])) < brad + 0.1:
+            continue
+        s = T.Shape(kind=T.SHAPE_RECTANGLE, anchor=-1)
+        s.pose = T.make_pose_2d(c[:2], yaw)
+        s.dims[:] = [float(d[0]), float(d[1]), 0.0]
+        shapes.append(s)
+        placed += 1
+    dyn = T.DynSpace()
+    dyn.n_dof = n
+    return Scenario(name="C1-planar", ops=ops, base=base, shapes=shapes, dyn=dyn, n_dof=n, n_frames=2 * n + 1,
+                    start=np.zeros(n), goal=np.array([np.pi / 2, 0.0, 0.0]),
+                    meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi), "min_interval": min_interval})
+
+
+def make_planar_mixed(seed=1, n=4, n_obstacles=24):
+    """A planar n-joint arm with mixed 2D shapes on both sides (circles, capped rectangles and rectangles on the links;
+    all three kinds in the environment) and non-trivial link / shape poses: exercises every planar pair routine."""
+    rng = np.random.Generator(np.random.PCG64(9100 + seed))
+    ops, shapes = [], []
+    lengths = list(rng.uniform(0.25, 0.45, size=n))
+    for j in range(n):
+        ops.append(T.KteOp(kind=T.KTE_REVOLUTE_JOINT_2D, coord=j, base_frame=2 * j, end_frame=2 * j + 1, joint_op=-1))
+        l = T.KteOp(kind=T.KTE_RIGID_LINK_2D, coord=-1, base_frame=2 * j + 1, end_frame=2 * j + 2, joint_op=-1)
+        l.offset = T.make_pose_2d((lengths[j], rng.uniform(-0.03, 0.03)), rng.uniform(-0.2, 0.2))
+        ops.append(l)
+        kind = [T.SHAPE_CRECT, T.SHAPE_CIRCLE, T.SHAPE_RECTANGLE][j % 3]
+        s = T.Shape(kind=kind, anchor=2 * j + 1)
+        s.pose = T.make_pose_2d((0.5 * lengths[j], 0.0), 0.0 if kind == T.SHAPE_CRECT else rng.uniform(-0.3, 0.3))
+        s.dims[:] = {T.SHAPE_CRECT: [lengths[j], 0.06, 0.0], T.SHAPE_CIRCLE: [0.07, 0.0, 0.0],
+                     T.SHAPE_RECTANGLE: [lengths[j] * 0.8, 0.07, 0.0]}[kind]
+        shapes.append(s)
+    base = T.ChainBase()
+    base.pose = T.make_pose_2d((0.05, -0.02), 0.3)
+    placed = 0
+    while placed < n_obstacles:
+        c = rng.uniform(-1.6, 1.6, size=2)
+        if np.hypot(*c) < 0.55:
+            continue
+        kind = [T.SHAPE_RECTANGLE, T.SHAPE_CIRCLE, T.SHAPE_CRECT][placed % 3]
+        s = T.Shape(kind=kind, anchor=-1)
+        s.pose = T.make_pose_2d(c, rng.uniform(-np.pi, np.pi))
+        s.dims[:] = {T.SHAPE_RECTANGLE: [rng.uniform(0.15, 0.4), rng.uniform(0.15, 0.4), 0.0],
+                     T.SHAPE_CIRCLE: [rng.uniform(0.06, 0.18), 0.0, 0.0],
+                     T.SHAPE_CRECT: [rng.uniform(0.15, 0.4), rng.uniform(0.06, 0.16), 0.0]}[kind]
+        shapes.append(s)
+        placed += 1
+    dyn = T.DynSpace()
+    dyn.n_dof = n
+    goal = rng.uniform(-1.2, 1.2, size=n)
+    return Scenario(name=f"planar{n}", ops=ops, base=base, shapes=shapes, dyn=dyn, n_dof=n, n_frames=2 * n + 1,
+                    start=np.zeros(n), goal=goal,
+                    meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi), "min_interval": 0.05})
+
+
 def make_c3(world_seed=1, min_interval=0.05):
     """BASELINE config C3/C5: the 6-DOF chain and 50-obstacle world of C2, planned in the quasi-static joint space
     (manip_quasi_static_env) with RRT* and star_neighborhood k-NN rewiring."""

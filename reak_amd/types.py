@@ -1,5 +1,6 @@
 """ctypes mirrors of include/rkh_types.h (the POD scene description that crosses the C-ABI)."""
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -13,11 +14,16 @@ KTE_REVOLUTE_JOINT_3D = 3
 KTE_RIGID_LINK_3D = 4
 KTE_INERTIA_3D = 5
 KTE_FLEXIBLE_BEAM_3D = 6
+KTE_REVOLUTE_JOINT_2D = 7
+KTE_RIGID_LINK_2D = 8
 
 # rkh_shape_kind
 SHAPE_SPHERE = 1
 SHAPE_BOX = 2
 SHAPE_CCYLINDER = 3
+SHAPE_CIRCLE = 4
+SHAPE_RECTANGLE = 5
+SHAPE_CRECT = 6
 
 
 class Pose(C.Structure):
@@ -86,6 +92,17 @@ def make_pose(pos=(0.0, 0.0, 0.0), quat=(1.0, 0.0, 0.0, 0.0)):
     p = Pose()
     p.pos[:] = [float(v) for v in pos]
     p.quat[:] = [float(v) for v in quat]
+    return p
+
+
+def make_pose_2d(pos=(0.0, 0.0), angle=0.0):
+    """pose_2D carried in rkh_pose: pos[0..1] = Position, quat[0..1] = rot_mat_2D::q = (cos, sin)."""
+    p = Pose()
+    p.pos[:] = [float(pos[0]), float(pos[1]), 0.0]
+    if angle == 0.0:
+        p.quat[:] = [1.0, 0.0, 0.0, 0.0]  # rot_mat_2D() default: identity
+    else:
+        p.quat[:] = [math.cos(angle), math.sin(angle), 0.0, 0.0]
     return p
 
 

@@ -67,12 +67,13 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "c2_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
-    make_c1_golden()
+    make_c1_golden(scenarios.make_c1(world_seed=1), "c1_golden.npz")
+    make_c1_golden(scenarios.make_c1_planar(world_seed=1), "c1_planar_golden.npz")
 
 
-def make_c1_golden():
-    """C1 (3-DOF planar arm, quasi-static space): RRT, RRT* and PRM graphs of the oracle, small sizes."""
-    c1 = scenarios.make_c1(world_seed=1)
+def make_c1_golden(c1, file_name):
+    """C1 (3-DOF planar arm, quasi-static space; once with the 3D KTEs / shapes, once with the reference's 2D classes):
+    RRT, RRT* and PRM graphs of the oracle, small sizes."""
     osc = oracle_lib.OracleScene(c1)
     lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
     out = {}
@@ -96,7 +97,7 @@ def make_c1_golden():
                                     o.num_components, o.publish_calls, o.merged_at_vertex, o.edges_checked], dtype=np.int64),
                prm_pos=g["pos"], prm_edge_u=g["edge_u"], prm_edge_v=g["edge_v"], prm_edge_w=g["edge_w"],
                prm_density=g["density"], prm_cc_root=g["cc_root"], prm_kind=g["kind"], prm_expanded=g["expanded"])
-    path = os.path.join(ROOT, "tests", "golden", "c1_golden.npz")
+    path = os.path.join(ROOT, "tests", "golden", file_name)
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 

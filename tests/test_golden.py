@@ -79,13 +79,17 @@ def test_hip_reproduces_golden(gold, c2):
 
 
 # ------------------------------------------------------------------ C1: quasi-static RRT / RRT* / PRM
-@pytest.fixture(scope="module")
-def gold1():
-    return np.load(GOLD_C1, allow_pickle=False)
+# two realisations of C1: the 3D KTEs / shapes, and the reference's own 2D classes (c1_planar_golden.npz)
+@pytest.fixture(scope="module", params=["3d", "planar"])
+def gold1(request):
+    name = "c1_golden.npz" if request.param == "3d" else "c1_planar_golden.npz"
+    g = dict(np.load(os.path.join(os.path.dirname(GOLD_C1), name), allow_pickle=False))
+    g["_variant"] = request.param
+    return g
 
 
-def _c1():
-    c1 = scenarios.make_c1(world_seed=1)
+def _c1(gold1):
+    c1 = scenarios.make_c1(world_seed=1) if gold1["_variant"] == "3d" else scenarios.make_c1_planar(world_seed=1)
     return c1, c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
 
 
@@ -107,7 +111,7 @@ def _check_c1(gold1, walk, rrt, star, prm):
 
 
 def test_oracle_reproduces_c1_golden(oracle, gold1):
-    c1, lo, hi, mi = _c1()
+    c1, lo, hi, mi = _c1(gold1)
     osc = oracle.OracleScene(c1)
     walk = osc.qs_move(lo, hi, mi, gold1["walk_a"], gold1["walk_b"], fraction=1.0)
     rc, o, tree = osc.rrt_qs(lo, hi, mi, c1.rrt_params(seed=1, max_vertices=800))
@@ -124,7 +128,7 @@ def test_oracle_reproduces_c1_golden(oracle, gold1):
 def test_hip_reproduces_c1_golden(gold1):
     from reak_amd import lib as L
 
-    c1, lo, hi, mi = _c1()
+    c1, lo, hi, mi = _c1(gold1)
     ctx = L.Context(0)
     sc = L.Scene(ctx, c1)
     qs = L.make_qs_space(3, lo, hi, mi)

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from reak_amd import scenarios
+from reak_amd import types as T
 
 pytestmark = pytest.mark.gpu
 
@@ -694,3 +695,104 @@ def test_c4_dual_arm_dynamics_with_flexible_beam(L, ctx, oracle):
     assert (st.num_vertices, st.iterations) == (ro.num_vertices, ro.iterations)
     assert np.array_equal(pl.tree()["parent"], rtree["parent"])
     assert np.allclose(pl.tree()["pos"], rtree["pos"], rtol=1e-9, atol=1e-9)
+
+
+# ------------------------------------------------------------------ planar chains: the reference's 2D classes (true C1)
+def _planar_checks(L, ctx, oracle, scn, n_cfg, rrt_vertices, seed):
+    n = scn.n_dof
+    sc, osc = L.Scene(ctx, scn), oracle.OracleScene(scn)
+    lo, hi, mi = scn.meta["lower"], scn.meta["upper"], scn.meta["min_interval"]
+    rng = np.random.default_rng(100 + seed)
+    q = rng.uniform(lo, hi, size=(n_cfg, n))
+    x = np.zeros((n_cfg, 2 * n)); x[:, 0::2] = q
+    d, rd = sc.min_distance(x), osc.min_distance(x)
+    assert np.allclose(d, rd, atol=1e-12)
+    far = np.abs(rd) > 1e-12
+    assert np.array_equal((d < 0)[far], (rd < 0)[far]) and 0.02 < (rd < 0).mean() < 0.98
+    a = q[rd > 0.0][:128]
+    b = rng.uniform(lo, hi, size=(a.shape[0], n))
+    out, nchk = sc.move_position_toward(lo, hi, mi, a, b, fraction=1.0)
+    rout, rnchk = osc.qs_move(lo, hi, mi, a, b, fraction=1.0)
+    assert np.array_equal(nchk, rnchk) and np.array_equal(out, rout)
+    qs = L.make_qs_space(n, lo, hi, mi)
+    prm = scn.rrt_params(seed=seed, max_vertices=rrt_vertices)
+    rc, ro, rtree = osc.rrt_qs(lo, hi, mi, prm)
+    pl = L.RrtPlanner(sc, prm, qs=qs)
+    st = pl.solve_planning_query()
+    assert (st.num_vertices, st.iterations, st.edges_checked, st.num_solutions) == (
+        ro.num_vertices, ro.iterations, ro.edges_checked, ro.num_solutions)
+    t = pl.tree()
+    assert np.array_equal(t["parent"], rtree["parent"]) and np.array_equal(t["pos"], rtree["pos"])
+    assert np.array_equal(t["nn_seq"], rtree["nn_seq"]) and np.array_equal(t["accept"], rtree["accept"])
+    return sc, osc, qs
+
+
+def test_c1_planar_arm_with_the_reference_2d_classes(L, ctx, oracle):
+    """BASELINE C1 as the reference builds it: revolute_joint_2D / rigid_link_2D chain, capped_rectangle links,
+    rectangle obstacles, proxy_query_pair_2D (with its order-dependent cull) -- distance queries, edge walks, RRT to
+    5000 vertices, RRT*, PRM and bidirectional RRT against the oracle."""
+    c1 = scenarios.make_c1_planar(world_seed=1)
+    sc, osc, qs = _planar_checks(L, ctx, oracle, c1, 600, 5000, 1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    prm = c1.rrt_params(seed=2, max_vertices=600)
+    rc, ro, rg = osc.rrtstar_qs(lo, hi, mi, prm)
+    ps = L.RrtStarPlanner(sc, prm, qs)
+    st = ps.solve_planning_query()
+    g = ps.graph()
+    assert (st.num_vertices, st.loop_iterations, st.rewires, st.num_solutions) == (ro.num_vertices, ro.loop_iterations,
+                                                                                 ro.rewires, ro.num_solutions)
+    assert np.array_equal(g["pred"], rg["pred"]) and np.array_equal(g["pos"], rg["pos"]) and np.array_equal(g["dist"], rg["dist"])
+    pp = c1.prm_params(seed=3, max_vertices=400, sampling_radius=1.0)
+    rc, ro, rgp = osc.prm_qs(lo, hi, mi, pp)
+    pm = L.PrmPlanner(sc, pp, qs)
+    stp = pm.solve_planning_query()
+    _prm_same(stp, pm.graph(), ro, rgp)
+    bp = c1.rrt_params(seed=4, max_vertices=1000, max_results=2)
+    rc, ro, rt = osc.birrt_qs(lo, hi, mi, bp)
+    pb = L.BiRrtPlanner(sc, bp, qs)
+    stb = pb.solve_planning_query()
+    assert (stb.num_vertices_1, stb.num_vertices_2, stb.loop_iterations, stb.num_solutions, stb.joins) == (
+        ro.n1, ro.n2, ro.loop_iterations, ro.num_solutions, ro.joins)
+    tb = pb.trees()
+    assert np.array_equal(tb["parent1"], rt["parent1"]) and np.array_equal(tb["pos2"], rt["pos2"]) and stb.best_cost == ro.best_cost
+
+
+@pytest.mark.parametrize("n,seed", [(4, 1), (2, 4), (7, 3)])
+def test_planar_chains_with_every_2d_pair_routine(L, ctx, oracle, n, seed):
+    """Circles, capped rectangles and rectangles on both sides (all six finders of proxy_query_pair_2D), oblique link
+    offsets and a turned base."""
+    scn = scenarios.make_planar_mixed(seed=seed, n=n)
+    _planar_checks(L, ctx, oracle, scn, 400, 800, seed)
+
+
+def test_planar_cull_order_is_the_references(L, ctx, oracle):
+    """The order-dependent verdict of proxy_query_pair_2D::findMinimumDistance (tests/test_oracle_kat.py works the
+    numbers): the same three shapes give 'free' or 'colliding' depending on the environment's order."""
+    ops = [T.KteOp(kind=T.KTE_REVOLUTE_JOINT_2D, coord=0, base_frame=0, end_frame=1, joint_op=-1),
+           T.KteOp(kind=T.KTE_RIGID_LINK_2D, coord=-1, base_frame=1, end_frame=2, joint_op=-1)]
+    ops[1].offset = T.make_pose_2d((0.2, 0.0))
+    link = T.Shape(kind=T.SHAPE_CRECT, anchor=1)
+    link.pose = T.make_pose_2d((0.1, 0.0))
+    link.dims[:] = [0.2, 6.0, 0.0]
+
+    def circle(pos, r):
+        s = T.Shape(kind=T.SHAPE_CIRCLE, anchor=-1)
+        s.pose = T.make_pose_2d(pos)
+        s.dims[:] = [r, 0.0, 0.0]
+        return s
+    far, near = circle((0.1, 3.11), 0.1), circle((3.2, 0.0), 0.05)
+    base = T.ChainBase()
+    base.pose = T.make_pose_2d()
+    for shapes, expect in (([link, far, near], 0.01), ([link, near, far], -0.05)):
+        scn = scenarios.Scenario(name="cull", ops=ops, base=base, shapes=shapes, dyn=T.DynSpace(), n_dof=1, n_frames=3,
+                                 start=np.zeros(1), goal=np.zeros(1), meta={})
+        d = L.Scene(ctx, scn).min_distance(np.zeros((1, 2)))[0]
+        assert d == oracle.OracleScene(scn).min_distance(np.zeros((1, 2)))[0]
+        assert d == pytest.approx(expect, rel=1e-9)
+
+
+def test_planar_scene_refuses_dynamics(L, ctx):
+    c1 = scenarios.make_c1_planar()
+    sc = L.Scene(ctx, c1)
+    with pytest.raises(L.RkhError):
+        sc.state_derivative(np.zeros((1, 6)), np.zeros((1, 3)))

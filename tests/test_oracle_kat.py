@@ -277,3 +277,98 @@ def test_vantage_point_tree_equals_linear_search(oracle):
         li, ld = oracle.nn1(q, pts)
         ti, td, _, _ = oracle.vptree_nn1(q, pts)
         assert np.array_equal(li, ti) and np.array_equal(ld, td)
+
+
+def _shape2(kind, pos, dims, angle=0.0):
+    s = T.Shape(kind=kind, anchor=-1)
+    s.pose = T.make_pose_2d(pos, angle)
+    s.dims[:] = [float(dims[0]), float(dims[1]) if len(dims) > 1 else 0.0, 0.0]
+    return s
+
+
+def test_planar_proximity_closed_forms(oracle):
+    """The 2D pair routines (prox_circle_*.cpp, prox_crect_*.cpp, prox_rectangle_rectangle.cpp) on configurations
+    worked by hand; the reference has no tests for them."""
+    lib = oracle.load()
+    pd = lambda a, b: lib.orc_pair_distance(C.byref(a), C.byref(b))
+    ci = lambda p, r: _shape2(T.SHAPE_CIRCLE, p, (r,))
+    re = lambda p, d, a=0.0: _shape2(T.SHAPE_RECTANGLE, p, d, a)
+    cr = lambda p, L, W, a=0.0: _shape2(T.SHAPE_CRECT, p, (L, W), a)
+    r2 = math.sqrt(2.0)
+    assert pd(ci((0, 0), 0.5), ci((2, 0), 0.25)) == pytest.approx(1.25, rel=1e-15)
+    assert pd(ci((0, 0), 0.5), ci((0, 0.5), 0.25)) == pytest.approx(-0.25, rel=1e-15)
+    # circle - rectangle: side, corner, and (reference behaviour) centre inside = unsigned distance to the boundary
+    assert pd(ci((2, 0), 0.5), re((0, 0), (2, 2))) == pytest.approx(0.5, rel=1e-15)
+    assert pd(ci((2, 2), 0.5), re((0, 0), (2, 2))) == pytest.approx(r2 - 0.5, rel=1e-15)
+    assert pd(ci((1.2, 0), 0.5), re((0, 0), (2, 2))) == pytest.approx(-0.3, rel=1e-12)
+    assert pd(ci((0.9, 0), 0.05), re((0, 0), (2, 2))) == pytest.approx(0.05, rel=1e-12)  # not -0.15: prox_circle_rectangle.cpp:84
+    assert pd(ci((2, 0), 0.5), re((0, 0), (2, 2), math.pi / 4)) == pytest.approx(2.0 - r2 - 0.5, rel=1e-12)
+    # circle - capped rectangle: along the side, beyond the cap
+    assert pd(ci((0.2, 1.0), 0.1), cr((0, 0), 1.0, 0.4)) == pytest.approx(1.0 - 0.1 - 0.2, rel=1e-15)
+    assert pd(ci((0.2, -1.0), 0.1), cr((0, 0), 1.0, 0.4)) == pytest.approx(0.7, rel=1e-15)
+    assert pd(ci((2.0, 0.0), 0.1), cr((0, 0), 1.0, 0.4)) == pytest.approx(1.5 - 0.2 - 0.1, rel=1e-15)
+    assert pd(ci((0.0, 2.0), 0.1), cr((0, 0), 1.0, 0.4, math.pi / 2)) == pytest.approx(1.5 - 0.2 - 0.1, rel=1e-12)
+    # capped rectangle - capped rectangle: crossed, parallel side by side, and the always-true OR of the parallel
+    # branch (prox_crect_crect.cpp:58-59) for two collinear, separated ones: reports 0 - W1/2 - W2/2
+    assert pd(cr((0, 0), 1.0, 0.2), cr((0, 1.0), 1.0, 0.4, math.pi / 2)) == pytest.approx(0.5 - 0.1 - 0.2, rel=1e-12)
+    assert pd(cr((0, 0), 1.0, 0.2), cr((0.3, 0.8), 1.0, 0.4)) == pytest.approx(0.8 - 0.1 - 0.2, rel=1e-12)
+    assert pd(cr((0, 0), 1.0, 0.2), cr((3.0, 0.0), 1.0, 0.4)) == pytest.approx(-0.3, rel=1e-12)
+    assert pd(cr((0, 0), 1.0, 0.2), cr((2.0, 1.0), 1.0, 0.2, math.pi / 4)) == pytest.approx(
+        math.hypot(2.0 - 0.5 * math.cos(math.pi / 4) - 0.5, 1.0 - 0.5 * math.sin(math.pi / 4)) - 0.2, rel=1e-12)
+    # capped rectangle - rectangle: parallel to a side, end-on, oblique against a corner, penetrating
+    assert pd(cr((0, 1.5), 1.0, 0.2), re((0, 0), (2, 2))) == pytest.approx(0.5 - 0.1, rel=1e-12)
+    # end-on and parallel to a side: the overlap test of the horizontal branch is a logical OR (prox_crect_rectangle.cpp:
+    # 90-91, always true), so the reference reports |y| - DY/2 - W/2 = -1.1 where the true distance is 0.4 (kept as is)
+    assert pd(cr((2.0, 0), 1.0, 0.2), re((0, 0), (2, 2))) == pytest.approx(-1.1, rel=1e-12)
+    assert pd(cr((2.0, 0), 1.0, 0.2, 0.3), re((0, 0), (2, 2))) == pytest.approx(
+        2.0 - 0.5 * math.cos(0.3) - 1.0 - 0.1, rel=1e-12)  # slightly turned: the end point against the side x = 1
+    assert pd(cr((0, 1.05), 1.0, 0.2), re((0, 0), (2, 2))) == pytest.approx(-0.05, rel=1e-10)
+    d = pd(cr((2.0, 2.0), 1.0, 0.2, -math.pi / 4), re((0, 0), (2, 2)))
+    assert d == pytest.approx(r2 - 0.1, rel=1e-12)  # the line's normal through the corner (1, 1)
+    d = pd(cr((2.0, 2.0), 1.0, 0.2, math.pi / 4), re((0, 0), (2, 2)))
+    assert d == pytest.approx(r2 - 0.5 - 0.1, rel=1e-12)  # its end point against the corner
+    # rectangle - rectangle: unsigned corner-to-boundary distance only
+    assert pd(re((0, 0), (2, 2)), re((3, 0), (1, 1))) == pytest.approx(1.5, rel=1e-12)
+    assert pd(re((0, 0), (2, 2)), re((3, 3), (2, 2))) == pytest.approx(r2, rel=1e-12)
+    assert pd(re((0, 0), (2, 2)), re((0.5, 0), (2, 2))) >= 0.0
+
+
+def test_planar_chain_kinematics_and_cull_sequence(oracle):
+    """revolute_joint_2D / rigid_link_2D against the 3R closed form, and proxy_query_pair_2D::findMinimumDistance's
+    order-dependent cull (the capped rectangle's bounding radius norm_2(dims)/2 is shorter than its reach)."""
+    from reak_amd import scenarios
+    scn = scenarios.make_c1_planar()
+    osc = oracle.OracleScene(scn)
+    rng = np.random.default_rng(3)
+    q = rng.uniform(-np.pi, np.pi, (16, 3))
+    x = np.zeros((16, 6))
+    x[:, 0::2] = q
+    fr = osc.fk(x)
+    L = [0.5, 0.5, 0.3]
+    for b in range(16):
+        a1, a2, a3 = q[b, 0], q[b, 0] + q[b, 1], q[b].sum()
+        ee = np.array([L[0] * math.cos(a1) + L[1] * math.cos(a2) + L[2] * math.cos(a3),
+                       L[0] * math.sin(a1) + L[1] * math.sin(a2) + L[2] * math.sin(a3)])
+        assert np.allclose(fr[b, 6, :2], ee, atol=1e-14)
+        assert np.allclose(fr[b, 5, 3:5], [math.cos(a3), math.sin(a3)], atol=1e-14)
+    # cull sequence: one wide link (caps of radius 3 around a 0.2 long centre line; bounding radius
+    # norm_2((0.2, 6)) / 2 = 3.000167 although the caps reach 3.1 along x) and two circles.  'far' clears the link's side
+    # by 0.01; 'near' penetrates the right cap by 0.05 but its cull value 3.10 - 3.000167 - 0.05 = 0.0498 exceeds 0.01.
+    # In the order (far, near) the reference skips 'near' and reports 0.01 (free); in the order (near, far) it reports
+    # -0.05 (colliding) and skips 'far' (cull value 0.0098 > -0.05).
+    ops = [T.KteOp(kind=T.KTE_REVOLUTE_JOINT_2D, coord=0, base_frame=0, end_frame=1, joint_op=-1),
+           T.KteOp(kind=T.KTE_RIGID_LINK_2D, coord=-1, base_frame=1, end_frame=2, joint_op=-1)]
+    ops[1].offset = T.make_pose_2d((0.2, 0.0))
+    link = T.Shape(kind=T.SHAPE_CRECT, anchor=1)
+    link.pose = T.make_pose_2d((0.1, 0.0))
+    link.dims[:] = [0.2, 6.0, 0.0]
+    far = _shape2(T.SHAPE_CIRCLE, (0.1, 3.11), (0.1,))
+    near = _shape2(T.SHAPE_CIRCLE, (3.2, 0.0), (0.05,))
+    base = T.ChainBase()
+    base.pose = T.make_pose_2d()
+    mk = lambda shapes: scenarios.Scenario(name="cull", ops=ops, base=base, shapes=shapes, dyn=T.DynSpace(), n_dof=1,
+                                           n_frames=3, start=np.zeros(1), goal=np.zeros(1), meta={})
+    d_seq = oracle.OracleScene(mk([link, far, near])).min_distance(np.zeros((1, 2)))[0]
+    d_rev = oracle.OracleScene(mk([link, near, far])).min_distance(np.zeros((1, 2)))[0]
+    assert d_seq == pytest.approx(0.01, rel=1e-9)
+    assert d_rev == pytest.approx(-0.05, rel=1e-9)
