@@ -53,6 +53,10 @@ RKH_DI double readlane_d(double v, int src_lane) {  // wave-uniform copy of lane
   return __hiloint2double(hi, lo);
 }
 
+RKH_DI float readlane_f(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
 RKH_DI m33 lane_axis_angle_rotmat(double ca, double sa, d3 ax) {  // axis_angle::getRotMat (rotations_3D.hpp:2160-2180)
   const double omc = 1.0 - ca;
   const double t11 = ca + omc * ax.x * ax.x, t22 = ca + omc * ax.y * ax.y, t33 = ca + omc * ax.z * ax.z;
@@ -328,6 +332,22 @@ __device__ __forceinline__ bool lane_proximity_free(const SceneDev* __restrict__
     t_prev = t_now;                                                 \
   }
   bool hit = !active;  // inactive lanes take no part in the scan
+  // Table loads are issued one stage ahead of their use (one wave per SIMD: nothing else covers a global-load latency):
+  // this lane's first robot shape and its cull record of the first obstacle chunk before the kinematics, every
+  // further robot shape at the top of the iteration before the one that uses it.
+  struct RobotConst {
+    d3 pos; d4 q; double d0, d1, d2, brad; int kind, link;
+  };
+  const int n_env = sc->n_env, n_robot = sc->n_robot;
+  auto load_robot = [&](int r0) {
+    const int r = (r0 + h < n_robot) ? r0 + h : (r0 < n_robot ? r0 : 0);
+    const ShapeDev& sh = sc->robot[r];
+    return RobotConst{ldg3(sh.pos), ldg4(sh.quat), sh.dims[0], sh.dims[1], sh.dims[2], sh.brad, sh.kind, sh.link};
+  };
+  RobotConst nxt = load_robot(0);
+  const int ol0 = (int(threadIdx.x & 63) < n_env) ? int(threadIdx.x & 63) : 0;
+  const float e0x = float(sc->env_cull[ol0][0]), e0y = float(sc->env_cull[ol0][1]), e0z = float(sc->env_cull[ol0][2]),
+              e0r = float(sc->env_cull[ol0][3]);
   {  // joint end frames: revolute_joint_3D / rigid_link_3D kinematics, position + orientation only
     d3 pos = ldg3(sc->base_pos);
     d4 Q = ldg4(sc->base_quat);
@@ -349,24 +369,24 @@ __device__ __forceinline__ bool lane_proximity_free(const SceneDev* __restrict__
       Q = qmul(EQ, ldg4(J.off_quat));
     }
   }
-  const int n_env = sc->n_env, n_robot = sc->n_robot;
   RKH_STAMP(5)
 #pragma unroll 1
   for (int r0 = 0; r0 < n_robot; r0 += 2) {
     if (__all(hit)) break;
     const int r = r0 + h;
     const bool have = r < n_robot;
+    const RobotConst sh = nxt;
+    nxt = load_robot(r0 + 2);
     // robot shape -> global pose (pose_3D::getGlobalPose, pose_3D.hpp:102-110)
-    const ShapeDev& sh = sc->robot[have ? r : r0];
     const int j = sh.link;
     const d3 Epos = mk3(RKH_LD(L_::ECP + 3 * j), RKH_LD(L_::ECP + 3 * j + 1), RKH_LD(L_::ECP + 3 * j + 2));
     const d4 EQ = d4{RKH_LD(L_::ECQ + 4 * j), RKH_LD(L_::ECQ + 4 * j + 1), RKH_LD(L_::ECQ + 4 * j + 2),
                      RKH_LD(L_::ECQ + 4 * j + 3)};
     ShapeG A;
     A.kind = sh.kind;
-    A.pos = Epos + qrot(EQ, ldg3(sh.pos));
-    A.q = qmul(EQ, ldg4(sh.quat));
-    A.d0 = sh.dims[0]; A.d1 = sh.dims[1]; A.d2 = sh.dims[2];
+    A.pos = Epos + qrot(EQ, sh.pos);
+    A.q = qmul(EQ, sh.q);
+    A.d0 = sh.d0; A.d1 = sh.d1; A.d2 = sh.d2;
     const d3 ca = pose_to_parent(A.pos, A.q, mk3(0, 0, 0));
     const double ra = sh.brad;
     const bool a_sphere = (sh.kind == RKH_SHAPE_SPHERE), a_ccyl = (sh.kind == RKH_SHAPE_CCYLINDER);
@@ -384,33 +404,41 @@ __device__ __forceinline__ bool lane_proximity_free(const SceneDev* __restrict__
       // lower bound on its distance is positive -- the bounding-sphere test of proxy_query_model.cpp:384-389 or, for
       // a capped-cylinder robot shape, the distance from the obstacle's bounding sphere to the cylinder's axis segment --
       // so the verdict "some pair is closer than 0" is unchanged.
-      const int ol = (o0 + (threadIdx.x & 63) < n_env) ? o0 + (threadIdx.x & 63) : o0;
-      const double ecx = sc->env_cull[ol][0], ecy = sc->env_cull[ol][1], ecz = sc->env_cull[ol][2], ecr = sc->env_cull[ol][3];
+      const int ol = (o0 + int(threadIdx.x & 63) < n_env) ? o0 + int(threadIdx.x & 63) : o0;
+      // The cull runs in fp32 with fused multiply-adds (it is a conservative filter, not part of the reference's
+      // arithmetic): records and the shape's segment are rounded to fp32 and the reach carries a 1 mm margin, three
+      // orders of magnitude above the rounding of the fp32 evaluation at these magnitudes (coordinates of a few metres).
+      float ecx = e0x, ecy = e0y, ecz = e0z, ecr = e0r;
+      if (o0 != 0) {  // further chunks of 64 obstacles (uniform branch)
+        ecx = float(sc->env_cull[ol][0]); ecy = float(sc->env_cull[ol][1]); ecz = float(sc->env_cull[ol][2]);
+        ecr = float(sc->env_cull[ol][3]);
+      }
+      const float cax = float(ca.x), cay = float(ca.y), caz = float(ca.z);
+      const float aax = float(a_ax.x), aay = float(a_ax.y), aaz = float(a_ax.z);
+      const float shl = float(seg_hl), srm = float(seg_rad_m) + 1e-3f;
       unsigned long long mask = 0ull;
       // four obstacles per iteration: four independent dependency chains (one wave per SIMD: nothing else hides the
-      // fp64 latency); spare slots of the last iteration repeat obstacle o0's record and are masked off
-      auto cull_one = [&](int i) -> bool {
-        const d3 cb = mk3(readlane_d(ecx, i & 63), readlane_d(ecy, i & 63), readlane_d(ecz, i & 63));
-        const double rb = readlane_d(ecr, i & 63);
-        // branch-free: a sphere / box robot shape is a segment of length 0 with its bounding radius
-        const d3 v = cb - ca;
-        double t = dot(v, a_ax);
-        t = t > seg_hl ? seg_hl : (t < -seg_hl ? -seg_hl : t);
-        // |w| - seg_rad - rb > 1e-9, tested on the squares (no sqrt; the margin dwarfs the rounding of either form)
-        const d3 wv = v - t * a_ax;
-        const double reach = seg_rad_m + rb;
-        const bool apart = dot(wv, wv) > reach * reach;
-        const bool keep = !apart && !(a_box && ((k_box >> (i & 63)) & 1ull));  // box-box: no finder in the reference
-        return keep && (i < on);
+      // latency); spare slots of the last iteration repeat obstacle o0's record and are masked off
+      // returns 1 when the pair survives (branch-free: selects only)
+      auto cull_one = [&](int i) -> unsigned {
+        const float vx = readlane_f(ecx, i & 63) - cax, vy = readlane_f(ecy, i & 63) - cay, vz = readlane_f(ecz, i & 63) - caz;
+        const float rb = readlane_f(ecr, i & 63);
+        // a sphere / box robot shape is a segment of length 0 with its bounding radius
+        float t = __builtin_fmaf(vz, aaz, __builtin_fmaf(vy, aay, vx * aax));
+        t = __builtin_fminf(__builtin_fmaxf(t, -shl), shl);
+        const float wx = __builtin_fmaf(-t, aax, vx), wy = __builtin_fmaf(-t, aay, vy), wz = __builtin_fmaf(-t, aaz, vz);
+        const float w2 = __builtin_fmaf(wz, wz, __builtin_fmaf(wy, wy, wx * wx));
+        const float reach = srm + rb;
+        return (w2 > reach * reach) ? 0u : 1u;
       };
 #pragma unroll 1
       for (int i = 0; i < on; i += 4) {
-        const bool k0 = cull_one(i), k1 = cull_one(i + 1), k2 = cull_one(i + 2), k3 = cull_one(i + 3);
-        mask |= (k0 ? 1ull : 0ull) << i;
-        mask |= (k1 ? 2ull : 0ull) << i;
-        mask |= (k2 ? 4ull : 0ull) << i;
-        mask |= (k3 ? 8ull : 0ull) << i;
+        const unsigned nib = cull_one(i) | (cull_one(i + 1) << 1) | (cull_one(i + 2) << 2) | (cull_one(i + 3) << 3);
+        mask |= (unsigned long long)nib << i;
       }
+      // obstacles past the end of the chunk; box-box has no finder in the reference (proxy_query_model.cpp:367)
+      mask &= (on == 64) ? ~0ull : ((1ull << on) - 1ull);
+      mask &= a_box ? ~k_box : ~0ull;
       if (hit || !have) mask = 0ull;
       RKH_STAMP(6)
       // survivors, kind by kind
