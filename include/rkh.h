@@ -79,6 +79,11 @@ rkh_status rkh_nn_queryk_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32
                                uint32_t* d_idx, double* d_dist, uint32_t* d_count);
 /* Fill the set with n uniform points of the unit hypercube directly on the device (synthetic
  * trees for the sweep microbenchmark); deterministic in seed. */
+/* Promise that every |coordinate| of the stored vertices and of all later queries is <= bound (for a hyperbox_topology:
+ * the largest |corner coordinate|, ctrl/topologies/hyperbox_topology.hpp:97-103).  Sweeps of 32 or more queries then run a
+ * single-precision pre-filter (packed fp32 VALU, or the fp32 matrix cores for more than 64 queries) in front of the exact
+ * fp64 test; results stay bit-identical.  bound = 0 (default) switches the pre-filters off. */
+rkh_status rkh_nn_set_coord_bound(rkh_nn* nn, double bound);
 rkh_status rkh_nn_fill_uniform(rkh_nn* nn, uint64_t n, uint64_t seed);
 /* One-shot: the next rkh_nn_query1_async records the two hipEvent_t (passed as void*) immediately before and after
  * its sweep kernel on the context stream (bench.py times the kernel itself, not the launch sequence). */

@@ -18,6 +18,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "rkh_internal.h"
 
@@ -296,6 +297,191 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_f32_kernel(NnArgs single, 
   }
 }
 
+// The pre-filter on the matrix cores, for large query batches (>= 128 queries per sweep and tree).  The squared distance
+// is expanded, s = |x|^2 - 2 x.q + |q|^2, so that the (rows x queries) block of estimates is a rank-Dp product:
+// v_mfma_f32_32x32x2_f32 with A = a 32-row slab of the float tile, B = -2 q for the wave's 32 queries and C = |x|^2 gives
+// c = |x|^2 - 2 x.q for 32 x 32 (row, query) pairs in Dp/2 instructions, at the packed-fp32 VALU rate but on the matrix
+// pipe, which leaves the VALU with one min-tree and one compare per 16 estimates.  A lane holds ONE query (column
+// l & 31) and 16 rows per slab (the C/D map of the 32x32 shapes: row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)), i.e. the
+// same "one query per lane, running best in registers" structure as the kernels above; the two lane halves hold
+// different rows of the same queries and are merged at the end.  Rows whose estimate cannot be ruled out are
+// re-evaluated with the exact fp64 sequence, in ascending row order, so the result is bit-identical.
+// Error bound (u = 2^-24, M = coord_bound, M' = M (1 + u), x^, q^ = the float-rounded coordinates): the MFMA is a
+// k-ordered fmaf chain starting from C, so |c - (|x^|^2 - 2 x^.q^)| <= (Dp + 1) u (|x^|^2 + 2 sum|x^ q^|) plus the
+// (Dp + 1) u |x^|^2 of the float evaluation of |x^|^2 itself, <= 4 (Dp + 1) u Dp M'^2 =: E1 (doubled below); and
+// |sum (x^ - q^)^2 - s| <= 4 u M sqrt(Dp s) + 4 u^2 M^2 Dp.  A row is skipped only if
+//   c > T := roundup_f32( thr + 4 u M sqrt(Dp thr) + 4 u^2 M^2 Dp + 2 E1 - |q^|^2 ),  thr = best_thr (1 + 2^-20),
+// which implies s > best_thr: the row could not have changed (best_d, best_i).
+typedef float rkh_f16v __attribute__((ext_vector_type(16)));
+typedef float rkh_f4v __attribute__((ext_vector_type(4)));
+static constexpr int kMfmaQueries = 128;  // 4 waves x 32 queries
+
+template <int DP>
+__global__ __launch_bounds__(kThreads) void nn1_sweep_mfma_kernel(NnArgs single, const NnArgs* __restrict__ table, int D,
+                                                                   uint32_t Bpad, double coord_bound) {
+  constexpr int H = DP / 2;
+  constexpr int TS = kTileRows + 4;  // float stride of one coordinate's row of the transposed copy
+  __shared__ __attribute__((aligned(16))) double tile[kTileRows * DP];
+  __shared__ __attribute__((aligned(16))) float tileT[DP * TS];
+  __shared__ __attribute__((aligned(16))) float xn[kTileRows];
+
+  const NnArgs a = table ? table[blockIdx.z] : single;
+  const double* __restrict__ pos = a.pos;
+  const double* __restrict__ q = a.q;
+  const uint32_t* __restrict__ d_qoff = a.d_qoff;
+  double* __restrict__ part_dist = a.part_dist;
+  uint32_t* __restrict__ part_idx = a.part_idx;
+  const uint64_t n = a.d_n ? uint64_t(*a.d_n) : a.n;
+  const uint32_t B = a.d_B ? *a.d_B : a.B;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, hi = lane >> 5;
+  const uint32_t qi = blockIdx.y * kMfmaQueries + wave * 32 + col;
+  if (blockIdx.y * kMfmaQueries >= B) return;
+
+  double qv[DP];
+  float bop[H];       // B operand of step j: -2 q^[2 j + hi]
+  double qn_d = 0.0;  // |q^|^2 (products of floats are exact in double)
+  {
+    const uint64_t qsrc = uint64_t(qi < B ? qi : (B - 1)) + (d_qoff ? uint64_t(*d_qoff) : 0ull);
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      qv[d] = d < D ? q[qsrc * D + d] : 0.0;
+      const float qf = float(qv[d]);
+      qn_d += double(qf) * double(qf);
+    }
+#pragma unroll
+    for (int j = 0; j < H; ++j) bop[j] = -2.0f * (hi ? float(qv[2 * j + 1]) : float(qv[2 * j]));
+  }
+  const double u32 = 5.9604644775390625e-08;  // 2^-24
+  const double Mb = coord_bound * (1.0 + u32);
+  const double e_abs = 4.0 * u32 * u32 * coord_bound * coord_bound * double(DP) +
+                       2.0 * (4.0 * double(DP + 1) * u32 * double(DP) * Mb * Mb);
+  const double e_sqrt = 4.0 * u32 * coord_bound * sqrt(double(DP));
+  auto make_T = [&](double best_thr) -> float {
+    const double thr = best_thr * (1.0 + 9.5367431640625e-07);
+    return __double2float_ru((thr + e_sqrt * sqrt(thr) + e_abs) * (1.0 + 2.0 * DBL_EPSILON) - qn_d * (1.0 - 4.0 * DBL_EPSILON));
+  };
+
+  const uint64_t tiles_total = (n + kTileRows - 1) / kTileRows;
+  const uint64_t tiles_per_block = (tiles_total + gridDim.x - 1) / gridDim.x;
+  const uint64_t tile0 = uint64_t(blockIdx.x) * tiles_per_block;
+  uint64_t tile1 = tile0 + tiles_per_block;
+  if (tile1 > tiles_total) tile1 = tiles_total;
+
+  double best_d = INFINITY;
+  double best_thr = INFINITY;
+  float T = INFINITY;  // skip rows whose estimate c exceeds this
+  uint32_t best_i = 0xFFFFFFFFu;
+
+  constexpr int N2 = kTileRows * DP / 2;
+  constexpr int PF = N2 / kThreads;
+  static_assert(N2 % kThreads == 0, "tile must split evenly");
+  double2 pf[PF];
+  auto fetch = [&](uint64_t t) {
+    const uint64_t row_base = t * kTileRows;
+    const double2* src = reinterpret_cast<const double2*>(pos + row_base * DP);
+    const uint64_t valid2 = (n - row_base >= uint64_t(kTileRows)) ? uint64_t(N2) : (n - row_base) * DP / 2;
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int i = tid + j * kThreads;
+      pf[j] = (uint64_t(i) < valid2) ? src[i] : make_double2(INFINITY, INFINITY);
+    }
+  };
+  if (tile0 < tile1) fetch(tile0);
+  for (uint64_t t = tile0; t < tile1; ++t) {
+    const uint64_t row_base = t * kTileRows;
+    {
+      double2* dst = reinterpret_cast<double2*>(tile);
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        const int i = tid + j * kThreads;
+        dst[i] = pf[j];
+        const int row = i / H, dp = i - row * H;
+        // rows past the end of the tree: a large finite float (its estimate is ~1e36, always skipped); the double copy
+        // keeps +inf
+        const bool pad = !(pf[j].x < INFINITY);
+        tileT[(2 * dp) * TS + row] = pad ? 1e18f : float(pf[j].x);
+        tileT[(2 * dp + 1) * TS + row] = pad ? 1e18f : float(pf[j].y);
+      }
+    }
+    if (t + 1 < tile1) fetch(t + 1);
+    __syncthreads();
+    {  // |x^|^2 of row tid, a float fmaf chain over the coordinates
+      float acc = 0.0f;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        const float v = tileT[d * TS + tid];
+        acc = __builtin_fmaf(v, v, acc);
+      }
+      xn[tid] = acc;
+    }
+    __syncthreads();
+    T = fminf(T, __shfl_xor(T, 32, 64));  // the other half's threshold is as good as one's own (same query)
+#pragma unroll 1
+    for (int g = 0; g < kTileRows / 32; ++g) {
+      rkh_f16v c;
+      {
+        const rkh_f4v* x4 = reinterpret_cast<const rkh_f4v*>(xn + 32 * g + 4 * hi);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const rkh_f4v v = x4[2 * k];  // rows 32 g + 8 k + 4 hi .. +3
+          c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const float aop = tileT[(2 * j + hi) * TS + 32 * g + col];
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bop[j], c, 0, 0, 0);
+      }
+      float m = fminf(fminf(c[0], c[1]), fminf(c[2], c[3]));
+#pragma unroll
+      for (int k = 1; k < 4; ++k) m = fminf(m, fminf(fminf(c[4 * k], c[4 * k + 1]), fminf(c[4 * k + 2], c[4 * k + 3])));
+      if (!(m > T)) {  // some row of this slab may matter: exact fp64 sequence of nn1_sweep_kernel, ascending rows
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (!(c[i] > T)) {
+            const int row = 32 * g + 8 * (i >> 2) + 4 * hi + (i & 3);
+            const double* p = tile + row * DP;
+            double s;
+            {
+              double df = qv[0] - p[0];
+              s = df * df;
+            }
+#pragma unroll
+            for (int d = 1; d < DP; ++d) {
+              double df = qv[d] - p[d];
+              s = s + df * df;
+            }
+            if (s <= best_thr) {
+              const double dd = sqrt(s);
+              if (dd < best_d) {
+                best_d = dd;
+                best_i = uint32_t(row_base + row);
+                best_thr = s * (1.0 + 4.0 * DBL_EPSILON);
+                T = make_T(best_thr);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  {  // the two halves of the wave hold different rows of the same 32 queries
+    const double od = __shfl_xor(best_d, 32, 64);
+    const uint32_t oi = __shfl_xor(best_i, 32, 64);
+    if (lex_less(od, oi, best_d, best_i)) {
+      best_d = od;
+      best_i = oi;
+    }
+  }
+  if (hi == 0 && qi < B) {
+    part_dist[uint64_t(blockIdx.x) * Bpad + qi] = best_d;
+    part_idx[uint64_t(blockIdx.x) * Bpad + qi] = best_i;
+  }
+}
+
 // one wave per query: lanes stride over the per-block partials, then a shuffle reduction
 __global__ __launch_bounds__(256) void nn1_reduce_kernel(NnArgs single, const NnArgs* __restrict__ table,
                                                           uint32_t nblocks, uint32_t Bpad) {
@@ -341,6 +527,15 @@ static int padded_dims(int D) {
 }
 int nn_padded_dims(int D) { return padded_dims(D); }
 
+// matrix-core pre-filter for batches of more than 64 queries (RKH_NN_MFMA=0 keeps the packed-fp32 VALU pre-filter)
+static bool mfma_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("RKH_NN_MFMA");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 static uint32_t pick_qb(uint32_t B) {
   // queries per block: the smallest padded query count wins (a block computes all its QB slots); ties go to the larger
   // block (fewer re-reads of the tiles)
@@ -348,6 +543,7 @@ static uint32_t pick_qb(uint32_t B) {
   if (B <= 16) return 16;
   if (B <= 32) return 32;
   if (B <= 64) return 64;
+  if (mfma_enabled()) return kMfmaQueries;
   const uint32_t pad128 = (B + 127) / 128 * 128, pad256 = (B + 255) / 256 * 256;
   return pad128 < pad256 ? 128 : 256;
 }
@@ -384,7 +580,12 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
   hipLaunchKernelGGL((nn1_sweep_f32_kernel<DP, QB>), grid, block, 0, s, single, d_table, D, Bpad, coord_bound)
   if (ev0) (void)hipEventRecord(ev0, s);
   const bool f32 = coord_bound > 0.0 && qb >= 32;  // compute-bound regime with known coordinate bounds
-  g_last_kernel = f32 ? "nn1_sweep_f32_kernel" : "nn1_sweep_kernel";
+  const bool mfma = f32 && qb == kMfmaQueries && mfma_enabled() && DP <= 16;
+  g_last_kernel = mfma ? "nn1_sweep_mfma_kernel" : (f32 ? "nn1_sweep_f32_kernel" : "nn1_sweep_kernel");
+  if (mfma) {
+    if constexpr (DP <= 16)
+      hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP>), grid, block, 0, s, single, d_table, D, Bpad, coord_bound);
+  } else
   switch (qb) {
     case 8: RKH_NN1_LAUNCH(8); break;
     case 16: RKH_NN1_LAUNCH(16); break;

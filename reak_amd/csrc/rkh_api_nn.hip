@@ -145,6 +145,12 @@ static rkh_status ensure_scratch(rkh_nn* nn, uint64_t q_elems, uint64_t res_elem
   return RKH_OK;
 }
 
+rkh_status rkh_nn_set_coord_bound(rkh_nn* nn, double bound) {
+  if (!nn || !(bound >= 0.0)) return RKH_ERR_BAD_ARG;
+  nn->coord_bound = bound;
+  return RKH_OK;
+}
+
 rkh_status rkh_nn_query1_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32_t* d_idx, double* d_dist) {
   if (!nn || !d_q || !d_idx || !d_dist) return RKH_ERR_BAD_ARG;
   if (B == 0) return RKH_OK;
@@ -161,7 +167,7 @@ rkh_status rkh_nn_query1_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32
   a.dist = d_dist;
   hipEvent_t e0 = nn->ev0, e1 = nn->ev1;
   nn->ev0 = nn->ev1 = nullptr;
-  return launch_nn1(nn->ctx->stream, nn->st.D, a, nullptr, 1, nn->n, B, nn->part_blocks, e0, e1);
+  return launch_nn1(nn->ctx->stream, nn->st.D, a, nullptr, 1, nn->n, B, nn->part_blocks, e0, e1, nn->coord_bound);
 }
 
 rkh_status rkh_nn_query1(rkh_nn* nn, const double* q, uint32_t B, uint32_t* idx, double* dist) {

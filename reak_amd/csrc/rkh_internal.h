@@ -162,6 +162,7 @@ struct rkh_nn {
   uint32_t part_blocks = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // one-shot: bracket the next sweep kernel
   void* d_knn_ws = nullptr;  // k-NN workspace
+  double coord_bound = 0.0;  // rkh_nn_set_coord_bound: |coordinate| bound enabling the single-precision pre-filters
   size_t knn_ws_bytes = 0;
 };
 

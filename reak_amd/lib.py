@@ -68,6 +68,7 @@ EXPORTS = [
     "rkh_last_error", "rkh_version", "rkh_ctx_create", "rkh_ctx_destroy", "rkh_ctx_synchronize", "rkh_ctx_stream",
     "rkh_nn_create", "rkh_nn_destroy", "rkh_nn_clear", "rkh_nn_size", "rkh_nn_append", "rkh_nn_query1",
     "rkh_nn_queryk", "rkh_nn_query1_async", "rkh_nn_queryk_async", "rkh_nn_fill_uniform", "rkh_nn_kernel_name",
+    "rkh_nn_set_coord_bound",
     "rkh_scene_create", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
@@ -113,6 +114,7 @@ def load():
     lib.rkh_nn_query1_async.argtypes = [vp, vp, u32, vp, vp]
     lib.rkh_nn_queryk_async.argtypes = [vp, vp, u32, u32, d, vp, vp, vp]
     lib.rkh_nn_fill_uniform.argtypes = [vp, u64, u64]
+    lib.rkh_nn_set_coord_bound.argtypes = [vp, C.c_double]
     lib.rkh_nn_set_events.argtypes = [vp, vp, vp]
     lib.rkh_nn_kernel_name.restype = C.c_char_p
     lib.rkh_scene_create.argtypes = [vp, C.POINTER(T.KteOp), C.c_int, C.POINTER(T.ChainBase), C.POINTER(T.Shape), C.c_int,
@@ -209,6 +211,12 @@ class HipNeighborSearch:
 
     def clear(self):
         _check(self.lib.rkh_nn_clear(self.h))
+
+    def set_coord_bound(self, bound):
+        _check(self.lib.rkh_nn_set_coord_bound(self.h, float(bound)))
+
+    def kernel_name(self):
+        return self.lib.rkh_nn_kernel_name().decode()
 
     def fill_uniform(self, n, seed=1):
         _check(self.lib.rkh_nn_fill_uniform(self.h, n, seed))

@@ -45,6 +45,33 @@ def test_nn1_bit_exact(L, ctx, oracle, D, n, B):
     assert np.array_equal(dist, rdist)  # bit-exact incl. the correctly rounded sqrt
 
 
+@pytest.mark.parametrize("D,n,B,expect", [(12, 30000, 300, "nn1_sweep_mfma_kernel"), (12, 777, 129, "nn1_sweep_mfma_kernel"),
+                                           (6, 20000, 200, "nn1_sweep_mfma_kernel"), (3, 5000, 1000, "nn1_sweep_mfma_kernel"),
+                                           (16, 9000, 130, "nn1_sweep_mfma_kernel"), (12, 30000, 48, "nn1_sweep_f32_kernel"),
+                                           (24, 4000, 200, "nn1_sweep_f32_kernel")])
+def test_nn1_single_precision_prefilters_are_bit_exact(L, ctx, oracle, D, n, B, expect):
+    """Sweeps with a coordinate bound run a float pre-filter (fp32 matrix cores above 64 queries, packed fp32 VALU below)
+    in front of the exact fp64 test: indices and distances must not change.  The cloud contains exact duplicates (ties
+    resolve to the lower index), near-duplicates one ulp apart and queries sitting on vertices (distance 0)."""
+    rng = np.random.default_rng(7 * D + n + B)
+    pts = rng.uniform(-np.pi, np.pi, size=(n, D))
+    dup = rng.integers(0, n // 2, size=n // 50)
+    pts[n // 2 + np.arange(len(dup))] = pts[dup]                       # exact duplicates at higher indices
+    near = rng.integers(0, n // 2, size=n // 50)
+    pts[n - 1 - np.arange(len(near))] = np.nextafter(pts[near], np.inf)  # one ulp away
+    q = rng.uniform(-np.pi, np.pi, size=(B, D))
+    q[::7] = pts[rng.integers(0, n, size=len(q[::7]))]                 # queries on vertices
+    q[1::7] = pts[dup[rng.integers(0, len(dup), size=len(q[1::7]))]] + rng.normal(0, 1e-9, size=(len(q[1::7]), D))
+    nn = L.HipNeighborSearch(ctx, D, n + 10)
+    nn.added_vertices(pts)
+    nn.set_coord_bound(np.pi + 1e-6)
+    idx, dist = nn.nearest(q)
+    assert nn.kernel_name() == expect
+    ridx, rdist = oracle.nn1(q, pts)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(dist, rdist)
+
+
 def test_nn1_ties_first_minimum_wins(L, ctx, oracle):
     rng = np.random.default_rng(7)
     base = rng.uniform(-1, 1, size=(500, 12))
