@@ -186,17 +186,18 @@ def main():
         rounds = max(int(st.rounds) for st in pl.all_stats)
         best = min(float(st.best_cost) for st in pl.all_stats)
         prof = [pl.nn_profile()]
+        nn_pairs = pl.nn_pairs()
         steer_ms, steer_launches = pl.steer_profile()
         nn_kernel[0] = lib.load().rkh_nn_kernel_name().decode()
         pl.close()
         return {"seconds": t1 - t0, "nodes": nodes, "edges": edges, "spec": spec, "rounds": rounds, "best": best,
                 "nn_ms": sum(p[0] for p in prof), "nn_bytes": sum(p[1] for p in prof), "nn_launches": sum(p[2] for p in prof),
-                "steer_ms": steer_ms, "steer_launches": steer_launches}
+                "nn_pairs": nn_pairs, "steer_ms": steer_ms, "steer_launches": steer_launches}
 
     for w in range(args.warmup):
         run_step(1000 + w, False)
     tot = {"seconds": 0.0, "nodes": 0, "edges": 0, "spec": 0, "rounds": 0, "nn_ms": 0.0, "nn_bytes": 0, "nn_launches": 0,
-           "steer_ms": 0.0, "steer_launches": 0}
+           "nn_pairs": 0, "steer_ms": 0.0, "steer_launches": 0}
     best = float("inf")
     if dist is not None:
         dist.barrier()
@@ -218,6 +219,7 @@ def main():
 
     if rank == 0:
         nn_gbps = (tot["nn_bytes"] / (tot["nn_ms"] * 1e-3) / 1e9) if tot["nn_ms"] > 0 else 0.0
+        nn_tflops = (tot["nn_pairs"] * 24.0 / (tot["nn_ms"] * 1e-3) / 1e12) if tot["nn_ms"] > 0 else 0.0
         out = {
             "metric": "valid RRT node-expansions/sec (+ edges-collision-checked/sec)",
             "value": nodes_all / elapsed,
@@ -240,12 +242,18 @@ def main():
             "rounds": tot["rounds"],
             "speculation_efficiency": (tot["edges"] / tot["spec"]) if tot["spec"] else None,
             "best_solution_cost": None if best == float("inf") else best,
-            "roofline": {"kernel": nn_kernel[0], "bound": "hbm", "achieved": nn_gbps, "peak": 8000.0, "unit": "GB/s",
-                         "frac": nn_gbps / 8000.0, "traffic": None, "launches": tot["nn_launches"],
+            # NN sweep of the timed region (rank 0).  In the planner every launch sweeps the trees of all problems for a
+            # whole speculative batch of queries each (a few hundred per tree), so it is bound by the arithmetic of the
+            # (vertex, query) pairs, not by HBM: the pre-filter evaluates each pair as a rank-Dp product on the fp32 matrix
+            # cores (v_mfma_f32_32x32x2_f32, 2 * Dp flops per pair, Dp = 12); peak = dense fp32 MFMA (MI355X_MICROARCH.md).
+            "roofline": {"kernel": nn_kernel[0], "bound": "mfma", "achieved": nn_tflops, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": nn_tflops / 157.3, "traffic": None, "launches": tot["nn_launches"],
                          "avg_launch_us": (tot["nn_ms"] * 1e3 / tot["nn_launches"]) if tot["nn_launches"] else None,
-                         "note": "rank-0 sweeps of the timed region; each launch sweeps the trees of all problems for a whole "
-                                 "speculative batch of queries each, so it is VALU-bound by design (packed-fp32 pre-filter + "
-                                 "exact fp64 recheck); see nn_sweep_hbm for the same sweep in its HBM-bound regime"},
+                         "pairs_per_launch": (tot["nn_pairs"] / tot["nn_launches"]) if tot["nn_launches"] else None,
+                         "algorithmic_GBps": nn_gbps,
+                         "note": "algorithmic flops = 24 per (vertex, query) pair of the profiled sweeps / HIP-event kernel "
+                                 "time on the planner stream; the survivors' exact fp64 recheck is not counted; "
+                                 "nn_sweep_hbm = the same sweep in its HBM-bound regime (few queries)"},
         }
         # the dominant kernels of the timed region (rank 0): the two steer mappings, fp64-VALU / latency bound.
         # Algorithmic work per propagated edge: 20 RK4 steps x 4 f-evals x ~7.5 k fp64 operations (6 joints)

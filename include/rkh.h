@@ -250,6 +250,8 @@ rkh_status rkh_birrt_get_solution(rkh_birrt* p, uint32_t problem, uint32_t* path
 /* With RKH_PROFILE_NN=1 in the environment at rkh_planner_create, every round brackets its NN sweep kernel with
  * HIP events on the planner stream: total kernel time, algorithmic bytes (n*D*8 per sweep) and launch count. */
 rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* total_bytes, uint64_t* launches);
+/* Same profile: (vertex, query) pairs the profiled sweeps evaluated = sum over rounds and problems of n * B. */
+rkh_status rkh_planner_nn_pairs(rkh_planner* p, uint64_t* pairs);
 /* Same switch: HIP events around the steer launches (both kernel mappings) of every round: total time, rounds. */
 rkh_status rkh_planner_steer_profile(rkh_planner* p, double* total_ms, uint64_t* launches);
 

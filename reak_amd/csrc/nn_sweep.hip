@@ -297,33 +297,41 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_f32_kernel(NnArgs single, 
   }
 }
 
-// The pre-filter on the matrix cores, for large query batches (>= 128 queries per sweep and tree).  The squared distance
-// is expanded, s = |x|^2 - 2 x.q + |q|^2, so that the (rows x queries) block of estimates is a rank-Dp product:
+// The pre-filter on the matrix cores, for large query batches (more than 64 queries per sweep and tree).  The squared
+// distance is expanded, s = |x|^2 - 2 x.q + |q|^2, so that the (rows x queries) block of estimates is a rank-Dp product:
 // v_mfma_f32_32x32x2_f32 with A = a 32-row slab of the float tile, B = -2 q for the wave's 32 queries and C = |x|^2 gives
 // c = |x|^2 - 2 x.q for 32 x 32 (row, query) pairs in Dp/2 instructions, at the packed-fp32 VALU rate but on the matrix
 // pipe, which leaves the VALU with one min-tree and one compare per 16 estimates.  A lane holds ONE query (column
-// l & 31) and 16 rows per slab (the C/D map of the 32x32 shapes: row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)), i.e. the
-// same "one query per lane, running best in registers" structure as the kernels above; the two lane halves hold
-// different rows of the same queries and are merged at the end.  Rows whose estimate cannot be ruled out are
-// re-evaluated with the exact fp64 sequence, in ascending row order, so the result is bit-identical.
+// l & 31) and 16 rows per slab (the C/D map of the 32x32 shapes: row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)); the two
+// lane halves hold different rows of the same queries and are merged at the end.
+// No exact arithmetic inside the sweep: with E >= |c_r - (s_r - |q^|^2)| for every row r, the true nearest row r*
+// satisfies c_{r*} <= c_min + 2 E, and the running minimum is never below the final one, so the rows with
+//   c_r <= (running min of c, including r's slab) + 2 E
+// are a superset of the candidates; they are appended, (row, c), to a short per-lane list in LDS, a handful per sweep.
+// After the sweep the list is cut down with the final minimum (typically to one or two rows) and those rows are
+// evaluated with the exact fp64 sequence of nn1_sweep_kernel straight from HBM; the lexicographic minimum of
+// (distance, index) over them is the reference's "first minimum wins".  Bit-identical results.
+// (Keeping whole slabs as candidates -- one compare per slab -- was measured: resolving a slab's 16 rows from HBM at
+// the end costs far more than the per-row checks it saves.)
 // Error bound (u = 2^-24, M = coord_bound, M' = M (1 + u), x^, q^ = the float-rounded coordinates): the MFMA is a
 // k-ordered fmaf chain starting from C, so |c - (|x^|^2 - 2 x^.q^)| <= (Dp + 1) u (|x^|^2 + 2 sum|x^ q^|) plus the
-// (Dp + 1) u |x^|^2 of the float evaluation of |x^|^2 itself, <= 4 (Dp + 1) u Dp M'^2 =: E1 (doubled below); and
-// |sum (x^ - q^)^2 - s| <= 4 u M sqrt(Dp s) + 4 u^2 M^2 Dp.  A row is skipped only if
-//   c > T := roundup_f32( thr + 4 u M sqrt(Dp thr) + 4 u^2 M^2 Dp + 2 E1 - |q^|^2 ),  thr = best_thr (1 + 2^-20),
-// which implies s > best_thr: the row could not have changed (best_d, best_i).
+// (Dp + 1) u |x^|^2 of the float evaluation of |x^|^2 itself, <= 4 (Dp + 1) u Dp M'^2; and |sum (x^ - q^)^2 - s| <=
+// 4 u M sqrt(Dp s) + 4 u^2 M^2 Dp <= 8 u Dp M^2 + 4 u^2 M^2 Dp (s <= 4 Dp M^2).  E is their sum with a factor 2.
 typedef float rkh_f16v __attribute__((ext_vector_type(16)));
 typedef float rkh_f4v __attribute__((ext_vector_type(4)));
-static constexpr int kMfmaQueries = 128;  // 4 waves x 32 queries
+static constexpr int kMfmaThreads = 256;
+static constexpr int kMfmaQueries = 128;  // 4 waves x 32 queries (8 waves x 32 per block measured 25 % slower)
+static constexpr int kCandCap = 8;        // per-lane candidate list (compacted, then resolved exactly, when it fills)
 
 template <int DP>
-__global__ __launch_bounds__(kThreads) void nn1_sweep_mfma_kernel(NnArgs single, const NnArgs* __restrict__ table, int D,
-                                                                   uint32_t Bpad, double coord_bound) {
+__global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs single, const NnArgs* __restrict__ table,
+                                                                      int D, uint32_t Bpad, double coord_bound) {
   constexpr int H = DP / 2;
   constexpr int TS = kTileRows + 4;  // float stride of one coordinate's row of the transposed copy
-  __shared__ __attribute__((aligned(16))) double tile[kTileRows * DP];
   __shared__ __attribute__((aligned(16))) float tileT[DP * TS];
   __shared__ __attribute__((aligned(16))) float xn[kTileRows];
+  __shared__ uint32_t cand_row[kCandCap][kMfmaThreads];
+  __shared__ float cand_c[kCandCap][kMfmaThreads];
 
   const NnArgs a = table ? table[blockIdx.z] : single;
   const double* __restrict__ pos = a.pos;
@@ -338,30 +346,20 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_mfma_kernel(NnArgs single,
   const int col = lane & 31, hi = lane >> 5;
   const uint32_t qi = blockIdx.y * kMfmaQueries + wave * 32 + col;
   if (blockIdx.y * kMfmaQueries >= B) return;
+  const uint64_t qsrc = uint64_t(qi < B ? qi : (B - 1)) + (d_qoff ? uint64_t(*d_qoff) : 0ull);
 
-  double qv[DP];
-  float bop[H];       // B operand of step j: -2 q^[2 j + hi]
-  double qn_d = 0.0;  // |q^|^2 (products of floats are exact in double)
-  {
-    const uint64_t qsrc = uint64_t(qi < B ? qi : (B - 1)) + (d_qoff ? uint64_t(*d_qoff) : 0ull);
+  float bop[H];  // B operand of step j: -2 q^[2 j + hi]
 #pragma unroll
-    for (int d = 0; d < DP; ++d) {
-      qv[d] = d < D ? q[qsrc * D + d] : 0.0;
-      const float qf = float(qv[d]);
-      qn_d += double(qf) * double(qf);
-    }
-#pragma unroll
-    for (int j = 0; j < H; ++j) bop[j] = -2.0f * (hi ? float(qv[2 * j + 1]) : float(qv[2 * j]));
+  for (int j = 0; j < H; ++j) {
+    const int d = 2 * j + hi;
+    bop[j] = -2.0f * float(d < D ? q[qsrc * D + d] : 0.0);
   }
   const double u32 = 5.9604644775390625e-08;  // 2^-24
   const double Mb = coord_bound * (1.0 + u32);
-  const double e_abs = 4.0 * u32 * u32 * coord_bound * coord_bound * double(DP) +
-                       2.0 * (4.0 * double(DP + 1) * u32 * double(DP) * Mb * Mb);
-  const double e_sqrt = 4.0 * u32 * coord_bound * sqrt(double(DP));
-  auto make_T = [&](double best_thr) -> float {
-    const double thr = best_thr * (1.0 + 9.5367431640625e-07);
-    return __double2float_ru((thr + e_sqrt * sqrt(thr) + e_abs) * (1.0 + 2.0 * DBL_EPSILON) - qn_d * (1.0 - 4.0 * DBL_EPSILON));
-  };
+  const double e_one = 2.0 * (4.0 * double(DP + 1) * u32 * double(DP) * Mb * Mb + 8.0 * u32 * double(DP) * Mb * Mb +
+                              4.0 * u32 * u32 * Mb * Mb * double(DP));
+  // 2 E, plus the rounding of the float sum (running min + band) at the magnitude of the estimates (<= 3 Dp M'^2)
+  const float band = __double2float_ru(2.0 * e_one + 8.0 * u32 * 3.0 * double(DP) * Mb * Mb);
 
   const uint64_t tiles_total = (n + kTileRows - 1) / kTileRows;
   const uint64_t tiles_per_block = (tiles_total + gridDim.x - 1) / gridDim.x;
@@ -369,14 +367,56 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_mfma_kernel(NnArgs single,
   uint64_t tile1 = tile0 + tiles_per_block;
   if (tile1 > tiles_total) tile1 = tiles_total;
 
-  double best_d = INFINITY;
-  double best_thr = INFINITY;
-  float T = INFINITY;  // skip rows whose estimate c exceeds this
+  double best_d = INFINITY;         // champion of the candidates resolved so far (list overflow only)
   uint32_t best_i = 0xFFFFFFFFu;
+  float cmin = INFINITY;            // running minimum of the estimates of this lane's query
+  int cnt = 0;                      // candidates in the list
+
+  // exact fp64 distance of vertex `row` (global index): the operation sequence of nn1_sweep_kernel
+  auto resolve = [&](uint32_t row) {
+    if (uint64_t(row) >= n) return;  // padding rows of the last tile (a half-wave that has seen nothing else)
+    const double* p = pos + uint64_t(row) * DP;
+    const double* qq = q + qsrc * D;
+    double s;
+    {
+      const double df = qq[0] - p[0];
+      s = df * df;
+    }
+#pragma unroll 1
+    for (int d = 1; d < DP; ++d) {
+      const double df = (d < D ? qq[d] : 0.0) - p[d];
+      s = s + df * df;
+    }
+    const double dd = sqrt(s);
+    if (lex_less(dd, row, best_d, best_i)) {
+      best_d = dd;
+      best_i = row;
+    }
+  };
+  // drop the candidates the current minimum rules out; if the list is still full, resolve it
+  auto compact = [&]() {
+    const float lim = cmin + band;
+    int w = 0;
+#pragma unroll 1
+    for (int k = 0; k < cnt; ++k) {
+      const float cc = cand_c[k][tid];
+      const uint32_t rr = cand_row[k][tid];
+      if (cc <= lim) {
+        cand_c[w][tid] = cc;
+        cand_row[w][tid] = rr;
+        ++w;
+      }
+    }
+    cnt = w;
+    if (cnt == kCandCap) {
+#pragma unroll 1
+      for (int k = 0; k < cnt; ++k) resolve(cand_row[k][tid]);
+      cnt = 0;
+    }
+  };
 
   constexpr int N2 = kTileRows * DP / 2;
-  constexpr int PF = N2 / kThreads;
-  static_assert(N2 % kThreads == 0, "tile must split evenly");
+  constexpr int PF = (N2 + kMfmaThreads - 1) / kMfmaThreads;
   double2 pf[PF];
   auto fetch = [&](uint64_t t) {
     const uint64_t row_base = t * kTileRows;
@@ -384,22 +424,20 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_mfma_kernel(NnArgs single,
     const uint64_t valid2 = (n - row_base >= uint64_t(kTileRows)) ? uint64_t(N2) : (n - row_base) * DP / 2;
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
-      const int i = tid + j * kThreads;
-      pf[j] = (uint64_t(i) < valid2) ? src[i] : make_double2(INFINITY, INFINITY);
+      const int i = tid + j * kMfmaThreads;
+      pf[j] = (uint64_t(i) < valid2 && i < N2) ? src[i] : make_double2(INFINITY, INFINITY);
     }
   };
   if (tile0 < tile1) fetch(tile0);
   for (uint64_t t = tile0; t < tile1; ++t) {
-    const uint64_t row_base = t * kTileRows;
+    const uint32_t row_base = uint32_t(t * kTileRows);
     {
-      double2* dst = reinterpret_cast<double2*>(tile);
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
-        const int i = tid + j * kThreads;
-        dst[i] = pf[j];
+        const int i = tid + j * kMfmaThreads;
+        if (i >= N2) continue;
         const int row = i / H, dp = i - row * H;
-        // rows past the end of the tree: a large finite float (its estimate is ~1e36, always skipped); the double copy
-        // keeps +inf
+        // rows past the end of the tree: a large finite float (estimate ~1e36: never a candidate)
         const bool pad = !(pf[j].x < INFINITY);
         tileT[(2 * dp) * TS + row] = pad ? 1e18f : float(pf[j].x);
         tileT[(2 * dp + 1) * TS + row] = pad ? 1e18f : float(pf[j].y);
@@ -407,7 +445,7 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_mfma_kernel(NnArgs single,
     }
     if (t + 1 < tile1) fetch(t + 1);
     __syncthreads();
-    {  // |x^|^2 of row tid, a float fmaf chain over the coordinates
+    if (tid < kTileRows) {  // |x^|^2 of row tid, a float fmaf chain over the coordinates
       float acc = 0.0f;
 #pragma unroll
       for (int d = 0; d < DP; ++d) {
@@ -417,9 +455,11 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_mfma_kernel(NnArgs single,
       xn[tid] = acc;
     }
     __syncthreads();
-    T = fminf(T, __shfl_xor(T, 32, 64));  // the other half's threshold is as good as one's own (same query)
-#pragma unroll 1
-    for (int g = 0; g < kTileRows / 32; ++g) {
+    cmin = fminf(cmin, __shfl_xor(cmin, 32, 64));  // the other half's minimum bounds the final one just as well
+    // a wave whose 32 query slots all lie past the batch only helps staging the tiles
+    const int n_slabs = (blockIdx.y * kMfmaQueries + wave * 32 < B) ? kTileRows / 32 : 0;
+#pragma unroll 2
+    for (int g = 0; g < n_slabs; ++g) {
       rkh_f16v c;
       {
         const rkh_f4v* x4 = reinterpret_cast<const rkh_f4v*>(xn + 32 * g + 4 * hi);
@@ -437,36 +477,39 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_mfma_kernel(NnArgs single,
       float m = fminf(fminf(c[0], c[1]), fminf(c[2], c[3]));
 #pragma unroll
       for (int k = 1; k < 4; ++k) m = fminf(m, fminf(fminf(c[4 * k], c[4 * k + 1]), fminf(c[4 * k + 2], c[4 * k + 3])));
-      if (!(m > T)) {  // some row of this slab may matter: exact fp64 sequence of nn1_sweep_kernel, ascending rows
+      cmin = fminf(cmin, m);
+      const float lim = cmin + band;
+      if (m <= lim) {  // a new minimum, or a row within the band of the old one
+        if (cnt > kCandCap - 3) compact();
+        bool overflow = false;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          if (!(c[i] > T)) {
-            const int row = 32 * g + 8 * (i >> 2) + 4 * hi + (i & 3);
-            const double* p = tile + row * DP;
-            double s;
-            {
-              double df = qv[0] - p[0];
-              s = df * df;
-            }
-#pragma unroll
-            for (int d = 1; d < DP; ++d) {
-              double df = qv[d] - p[d];
-              s = s + df * df;
-            }
-            if (s <= best_thr) {
-              const double dd = sqrt(s);
-              if (dd < best_d) {
-                best_d = dd;
-                best_i = uint32_t(row_base + row);
-                best_thr = s * (1.0 + 4.0 * DBL_EPSILON);
-                T = make_T(best_thr);
-              }
+          if (c[i] <= lim) {
+            if (cnt < kCandCap) {
+              cand_c[cnt][tid] = c[i];
+              cand_row[cnt][tid] = row_base + uint32_t(32 * g + 8 * (i >> 2) + 4 * hi + (i & 3));
+              ++cnt;
+            } else {
+              overflow = true;
             }
           }
+        }
+        // more candidates in one slab than the list takes (many coincident vertices): settle this slab exactly
+        if (overflow) {
+#pragma unroll 1
+          for (int i = 0; i < 16; ++i) resolve(row_base + uint32_t(32 * g + 8 * (i >> 2) + 4 * hi + (i & 3)));
         }
       }
     }
     __syncthreads();
+  }
+  // resolve what the final minimum (of both halves) leaves of the list
+  cmin = fminf(cmin, __shfl_xor(cmin, 32, 64));
+  {
+    const float lim = cmin + band;
+#pragma unroll 1
+    for (int k = 0; k < cnt; ++k)
+      if (cand_c[k][tid] <= lim) resolve(cand_row[k][tid]);
   }
   {  // the two halves of the wave hold different rows of the same 32 queries
     const double od = __shfl_xor(best_d, 32, 64);
@@ -551,8 +594,15 @@ static uint32_t pick_qb(uint32_t B) {
 static uint32_t pick_gx(uint64_t n_upper, uint32_t gy) {
   uint64_t tiles = (n_upper + kTileRows - 1) / kTileRows;
   if (tiles < 1) tiles = 1;
-  uint64_t want = 2048 / gy;  // ~8 blocks per CU over the whole grid
+  static const long forced = [] {  // diagnostic override of the row-slice count
+    const char* e = getenv("RKH_NN_BLOCKS");
+    return e ? atol(e) : 0L;
+  }();
+  uint64_t want = forced > 0 ? uint64_t(forced) : 4096 / gy;  // ~16 blocks per CU over the whole grid
   if (want < 1) want = 1;
+  // a block's fixed costs (query setup, resolving its candidates, one partial per query) are worth at least 4 tiles
+  const uint64_t most = tiles >= 4 ? tiles / 4 : 1;
+  if (want > most) want = most;
   return uint32_t(tiles < want ? tiles : want);
 }
 
@@ -584,7 +634,7 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
   g_last_kernel = mfma ? "nn1_sweep_mfma_kernel" : (f32 ? "nn1_sweep_f32_kernel" : "nn1_sweep_kernel");
   if (mfma) {
     if constexpr (DP <= 16)
-      hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP>), grid, block, 0, s, single, d_table, D, Bpad, coord_bound);
+      hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP>), grid, dim3(kMfmaThreads), 0, s, single, d_table, D, Bpad, coord_bound);
   } else
   switch (qb) {
     case 8: RKH_NN1_LAUNCH(8); break;

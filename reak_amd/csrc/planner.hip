@@ -70,6 +70,7 @@ struct ProblemDev {  // device pointers of one problem
 // sel: {edge counter of even rounds, of odd rounds}.  Every problem adds its candidates + pending goal probes to the
 // counter of this round's parity and block 0 clears the other one for the next round; the two steer kernels of the
 // round compare the sum with their threshold (see launch_edges).
+constexpr uint32_t kProfRounds = 8192;  // profiled rounds per planner (RKH_PROFILE_NN)
 __global__ void round_begin_kernel(const ProblemDev* __restrict__ probs, uint32_t round_slot, uint32_t* __restrict__ sel,
                                    uint32_t parity) {
   if (threadIdx.x != 0) return;
@@ -89,6 +90,7 @@ __global__ void round_begin_kernel(const ProblemDev* __restrict__ probs, uint32_
   }
   st->B = B;
   st->F = B;
+  if (pr.round_n) pr.round_n[kProfRounds + round_slot] = B;  // second half of the profile array: queries of the round
   if (B) {
     st->rounds += 1;
     st->edges_speculated += B;
@@ -284,7 +286,7 @@ struct rkh_planner {
   std::vector<hipEvent_t> ev;  // pairs
   std::vector<hipEvent_t> ev_steer;  // pairs around the steer launches of the same rounds
   uint32_t prof_rounds = 0;
-  static constexpr uint32_t kProfMax = 8192;
+  static constexpr uint32_t kProfMax = kProfRounds;
 };
 
 namespace {
@@ -601,7 +603,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     RKH_HIP(hipMalloc(&q.d_goal, D * sizeof(double)));
     RKH_HIP(hipMalloc(&q.d_part_dist, uint64_t(p->part_blocks) * p->b_max * sizeof(double)));
     RKH_HIP(hipMalloc(&q.d_part_idx, uint64_t(p->part_blocks) * p->b_max * sizeof(uint32_t)));
-    if (p->profile_nn) RKH_HIP(hipMalloc(&q.d_round_n, rkh_planner::kProfMax * sizeof(uint32_t)));
+    if (p->profile_nn) RKH_HIP(hipMalloc(&q.d_round_n, 2 * rkh_planner::kProfMax * sizeof(uint32_t)));
     // root vertex = query start (create_root, rrt_path_planner.tpp:131-133)
     std::vector<double> row(DP, 0.0);
     for (int d = 0; d < D; ++d) row[d] = prms[i].start[d];
@@ -753,6 +755,20 @@ rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* to
     *total_ms += ms;
     *total_bytes += rows[r] * p->DP * sizeof(double);  // algorithmic bytes of one launch: sum over problems of n * D * 8
     *launches += 1;
+  }
+  return RKH_OK;
+}
+
+rkh_status rkh_planner_nn_pairs(rkh_planner* p, uint64_t* pairs) {
+  if (!p || !pairs) return RKH_ERR_BAD_ARG;
+  *pairs = 0;
+  if (!p->profile_nn || p->prof_rounds == 0) return RKH_OK;
+  RKH_HIP(hipStreamSynchronize(p->stream));
+  std::vector<uint32_t> rn(p->prof_rounds), rb(p->prof_rounds);
+  for (Problem& q : p->prob) {
+    RKH_HIP(hipMemcpy(rn.data(), q.d_round_n, rn.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    RKH_HIP(hipMemcpy(rb.data(), q.d_round_n + rkh_planner::kProfMax, rb.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < p->prof_rounds; ++r) *pairs += uint64_t(rn[r]) * rb[r];
   }
   return RKH_OK;
 }

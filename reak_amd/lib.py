@@ -72,7 +72,7 @@ EXPORTS = [
     "rkh_scene_create", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
-    "rkh_planner_nn_profile", "rkh_planner_steer_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
+    "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
     "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph", "rkh_birrt_create_qs_batch", "rkh_birrt_destroy", "rkh_birrt_solve", "rkh_birrt_get_trees", "rkh_planner_get_solution", "rkh_rrtstar_get_solution", "rkh_birrt_get_solution",
 ]
 
@@ -155,6 +155,7 @@ def load():
     lib.rkh_planner_stream.restype = vp
     lib.rkh_planner_stream.argtypes = [vp]
     lib.rkh_planner_nn_profile.argtypes = [vp, dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.rkh_planner_nn_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.rkh_planner_steer_profile.argtypes = [vp, dp, C.POINTER(C.c_uint64)]
     _lib = lib
     return lib
@@ -384,6 +385,11 @@ class RrtPlanner:
         ms, by, ln = C.c_double(), C.c_uint64(), C.c_uint64()
         _check(self.lib.rkh_planner_nn_profile(self.h, C.byref(ms), C.byref(by), C.byref(ln)))
         return ms.value, by.value, ln.value
+
+    def nn_pairs(self):
+        pairs = C.c_uint64()
+        _check(self.lib.rkh_planner_nn_pairs(self.h, C.byref(pairs)))
+        return pairs.value
 
     def solution(self, problem=0):
         n, cost = C.c_uint32(), C.c_double()

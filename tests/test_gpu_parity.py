@@ -62,6 +62,11 @@ def test_nn1_single_precision_prefilters_are_bit_exact(L, ctx, oracle, D, n, B, 
     q = rng.uniform(-np.pi, np.pi, size=(B, D))
     q[::7] = pts[rng.integers(0, n, size=len(q[::7]))]                 # queries on vertices
     q[1::7] = pts[dup[rng.integers(0, len(dup), size=len(q[1::7]))]] + rng.normal(0, 1e-9, size=(len(q[1::7]), D))
+    if n > 400:  # more coincident vertices than a lane's candidate list holds, inside one 32-row slab and across slabs
+        pts[100:124] = pts[100]
+        pts[300:400:7] = pts[100]
+        q[2] = pts[100] + 1e-9
+        q[3] = pts[100]
     nn = L.HipNeighborSearch(ctx, D, n + 10)
     nn.added_vertices(pts)
     nn.set_coord_bound(np.pi + 1e-6)
