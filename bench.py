@@ -18,6 +18,7 @@ Extra objects on the JSON line:
                 per sweep), measured outside the timed region
   steer_kernels the dominant kernels of the timed region (the two mappings of the steer kernel): share of the step time,
                 edges/s inside the kernel, achieved fp64 operation rate against the no-FMA VALU peak
+  cpu_baseline_all_cores  the same sample on every host core (one oracle process per core, independent seeds)
   cpu_baseline  the CPU oracle (restatement of the reference planner, -O3 -march=native) on a bounded sample of the
                 same workload, single thread like ReaK itself
 """
@@ -118,6 +119,26 @@ def cpu_baseline(scn, seconds_target=15.0):
             "sample": f"seed 1 of the same C2 world, first {nv2} vertices ({out.iterations} iterations, "
                       f"{out.seconds:.1f} s), oracle -O3 -march=native, 1 thread (ReaK is single-threaded)",
             "note": "ReaK planner, CPU restatement (reference binary unavailable: needs Boost + BGL-Extra)"}
+
+
+def cpu_baseline_all_cores(nv, max_workers=64):
+    """The same bounded sample on every host core the process may use: one oracle process per core, independent seeds
+    (the reference's own evaluation mode is independent Monte-Carlo runs, planner_exec_engines.hpp:139-206)."""
+    import subprocess
+
+    cores = min(len(os.sched_getaffinity(0)), max_workers)
+    worker = os.path.join(ROOT, "tests", "cpu_worker.py")
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, worker, str(1 + i), str(nv)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+             for i in range(cores)]
+    outs = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in procs]
+    wall = time.perf_counter() - t0
+    busy = max(o["seconds"] for o in outs)
+    nodes = sum(o["vertices"] - 1 for o in outs)
+    return {"value": nodes / busy, "unit": "valid node expansions/s", "cores": cores, "kind": "port",
+            "edges_checked_per_s": sum(o["edges"] for o in outs) / busy,
+            "sample": f"{cores} processes x seeds 1..{cores}, first {nv} vertices each ({busy:.1f} s planner time, "
+                      f"{wall:.1f} s wall incl. process start), oracle -O3 -march=native"}
 
 
 def main():
@@ -272,6 +293,8 @@ def main():
             out["nn_sweep_hbm"] = nn_sweep_microbench(lib, ctx, events, 4 * 1024 * 1024, 8, 20)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scn)
+            nv_used = int(out["cpu_baseline"]["sample"].split("first ")[1].split(" ")[0])
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(nv_used)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
