@@ -12,8 +12,10 @@ Multi-GPU: independent seeds shard across ranks ("scaling": "weak"), no data-pat
 region one all-reduce(min) of the best solution cost and all-reduce(sum) of the counters.
 
 Extra objects on the JSON line:
-  roofline      NN-sweep kernel of the timed region, HIP-event timed on the planner streams
-                (algorithmic bytes n*D*8 per launch); peak 8 TB/s HBM3E.
+  roofline      NN-sweep kernel of the timed region, HIP-event timed on the planner streams.  In the planner a sweep serves
+                hundreds of queries per tree, so it is bound by the (vertex, query) pair arithmetic on the fp32 matrix
+                cores: 24 flops per pair against the 157.3 TFLOP/s dense fp32 MFMA peak (algorithmic bytes n*D*8 per
+                launch, SURVEY.md 8(d), are reported beside it as algorithmic_GBps).
   nn_sweep_hbm  the same kernel in its HBM-bound regime (tree larger than the 256 MiB Infinity Cache, 8 queries
                 per sweep), measured outside the timed region
   steer_kernels the dominant kernels of the timed region (the two mappings of the steer kernel): share of the step time,
