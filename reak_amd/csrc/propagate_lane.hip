@@ -85,6 +85,7 @@ struct LdsLayout {
 template <int N>
 struct LaneLds {
   double v[LdsLayout<N>::SLOTS][kEdgesPerWave];
+  double axis[N][3];  // revolute_joint_3D::mAxis of every joint: the one chain constant that is indexed per lane
 };
 #define RKH_LD(slot) lds.v[(slot)][el]
 
@@ -192,8 +193,8 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
         const d3 f2pos = ipos + mulT(pos, Rc);
         const d4 f2q = qmul(iq, Q);
         const m33 Rf = rotmat(f2q);
-        // joints[c].axis: per-lane index (the edge's two lanes work on different columns)
-        const d3 ax_c = mk3(sc->joints[c].axis[0], sc->joints[c].axis[1], sc->joints[c].axis[2]);
+        // joints[c].axis: per-lane index (the edge's two lanes work on different columns), from the wave's LDS copy
+        const d3 ax_c = mk3(lds.axis[c][0], lds.axis[c][1], lds.axis[c][2]);
         const d3 wt = mulT(ax_c, Rf);
         const d3 vt = mulT(cross(ax_c, f2pos), Rf);
         if (cr >= 0) {
@@ -494,6 +495,8 @@ __global__ __launch_bounds__(64, 1) void propagate_lane_kernel(const SceneDev* _
     const uint32_t c = *gate.count;
     if (c < gate.lo || c >= gate.hi) return;
   }
+  if (threadIdx.x < 3 * N) lds.axis[threadIdx.x / 3][threadIdx.x % 3] = sc->joints[threadIdx.x / 3].axis[threadIdx.x % 3];
+  __syncthreads();
   constexpr int D = 2 * N;
   const bool group_b = blockIdx.x >= grid_a;
   const EdgeIO io = tab_a ? (group_b ? tab_b[blockIdx.y] : tab_a[blockIdx.y]) : (group_b ? io_b : io_a);
@@ -653,6 +656,8 @@ __global__ __launch_bounds__(64, 1) void lane_cycles_kernel(const SceneDev* __re
                                                              unsigned long long* __restrict__ out,
                                                              double* __restrict__ sink_out) {
   __shared__ LaneLds<N> lds;
+  if (threadIdx.x < 3 * N) lds.axis[threadIdx.x / 3][threadIdx.x % 3] = sc->joints[threadIdx.x / 3].axis[threadIdx.x % 3];
+  __syncthreads();
   typedef LdsLayout<N> L_;
   const int lane = threadIdx.x, h = lane >> 5, el_raw = lane & 31;
   const int el = el_raw < kEdgesPerWave ? el_raw : 0;
