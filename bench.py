@@ -105,6 +105,32 @@ def nn_sweep_microbench(lib, ctx, events, n_rows, B, reps):
             "algorithmic_bytes": bytes_per_sweep, "traffic": traffic}
 
 
+def nn_mfma_microbench(lib, ctx, events, n_rows=1 << 20, B=1024, reps=10):
+    """The matrix-core pre-filter sweep alone on one large tree (exclusive use of the GPU, outside the timed region)."""
+    import torch
+
+    D = 12
+    nn = lib.HipNeighborSearch(ctx, D, n_rows)
+    nn.fill_uniform(n_rows, seed=7)
+    nn.set_coord_bound(1.0)
+    q = torch.rand(B, D, dtype=torch.float64, device="cuda")
+    idx = torch.zeros(B, dtype=torch.int32, device="cuda")
+    dist = torch.zeros(B, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        nn.nearest_async(q.data_ptr(), B, idx.data_ptr(), dist.data_ptr())
+    ctx.synchronize()
+    pairs = [(events.create(), events.create()) for _ in range(reps)]
+    for a, b in pairs:
+        nn.nearest_async(q.data_ptr(), B, idx.data_ptr(), dist.data_ptr(), events=(a, b))
+    ctx.synchronize()
+    ms = sum(events.elapsed_ms(a, b) for a, b in pairs) / reps
+    name = nn.kernel_name()
+    nn.close()
+    tf = n_rows * B * 24.0 / (ms * 1e-3) / 1e12
+    return {"kernel": name, "bound": "mfma", "n": n_rows, "dims": D, "queries_per_sweep": B, "ms_per_sweep": ms,
+            "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}
+
+
 def cpu_baseline(scn, seconds_target=15.0):
     """Oracle (kind 'port': the reference cannot be built here) on a bounded sample."""
     import oracle_lib
@@ -123,7 +149,7 @@ def cpu_baseline(scn, seconds_target=15.0):
             "note": "ReaK planner, CPU restatement (reference binary unavailable: needs Boost + BGL-Extra)"}
 
 
-def cpu_baseline_all_cores(nv, max_workers=64):
+def cpu_baseline_all_cores(nv, max_workers=16):
     """The same bounded sample on every host core the process may use: one oracle process per core, independent seeds
     (the reference's own evaluation mode is independent Monte-Carlo runs, planner_exec_engines.hpp:139-206)."""
     import subprocess
@@ -150,6 +176,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--problems", type=int, default=int(os.environ.get("RKH_BENCH_PROBLEMS", "256")))
     ap.add_argument("--max-vertices", type=int, default=100000)
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("RKH_BENCH_GROUPS", "1")),
+                    help="planner handles (HIP streams) the problems of a GPU are split over; 2 overlaps one group's "
+                         "steer tail with the other's NN sweep (+5 %% at 100 k vertices, +14 %% at 30 k) but the "
+                         "per-kernel HIP-event times then include the contention, so the default keeps one group")
     ap.add_argument("--rounds-per-sync", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
@@ -189,7 +219,8 @@ def main():
 
     def run_step(step_index, timed):
         seeds = dist_utils.seeds_for_rank(step_index, rank, world, P)
-        pl = lib.RrtPlanner(scene, [scn.rrt_params(seed=s, max_vertices=args.max_vertices) for s in seeds])
+        pl = lib.RrtPlannerPool(scene, [scn.rrt_params(seed=s, max_vertices=args.max_vertices) for s in seeds],
+                                groups=args.groups)
         pl.enqueue(0)  # sample chunks resident before the clock starts
         torch.cuda.synchronize()
         if dist is not None:
@@ -261,7 +292,8 @@ def main():
             "config": {"workload": "C2: 6-DOF revolute KTE chain, RRT + RK4 dynamics (dt=1e-3, 20 steps/edge), 50 convex "
                                    "obstacles, goal probe per vertex, LINEAR_SEARCH_KNN semantics",
                        "max_vertices": args.max_vertices, "problems_per_gpu": P, "seeds": "independent per problem",
-                       "parallelism": f"{world} x {P} independent planners"},
+                       "parallelism": f"{world} x {P} independent planners",
+                       "planner_groups_per_gpu": args.groups},
             "rounds": tot["rounds"],
             "speculation_efficiency": (tot["edges"] / tot["spec"]) if tot["spec"] else None,
             "best_solution_cost": None if best == float("inf") else best,
@@ -275,8 +307,10 @@ def main():
                          "pairs_per_launch": (tot["nn_pairs"] / tot["nn_launches"]) if tot["nn_launches"] else None,
                          "algorithmic_GBps": nn_gbps,
                          "note": "algorithmic flops = 24 per (vertex, query) pair of the profiled sweeps / HIP-event kernel "
-                                 "time on the planner stream; the survivors' exact fp64 recheck is not counted; "
-                                 "nn_sweep_hbm = the same sweep in its HBM-bound regime (few queries)"},
+                                 "time on the planner streams; the survivors' exact fp64 recheck is not counted "
+                                 "(with --groups 2 a sweep runs beside the other group's steer kernel and its elapsed "
+                                 "time includes the share of the machine it did not have); nn_sweep_mfma = the same "
+                                 "kernel alone on one large tree, nn_sweep_hbm = the fp64 sweep in its HBM-bound regime"},
         }
         # the dominant kernels of the timed region (rank 0): the two steer mappings, fp64-VALU / latency bound.
         # Algorithmic work per propagated edge: 20 RK4 steps x 4 f-evals x ~7.5 k fp64 operations (6 joints)
@@ -293,6 +327,7 @@ def main():
                                     "note": "f-eval operations only (proximity excluded); rank-0 launches of the timed region"}
         if not args.no_microbench:
             out["nn_sweep_hbm"] = nn_sweep_microbench(lib, ctx, events, 4 * 1024 * 1024, 8, 20)
+            out["nn_sweep_mfma"] = nn_mfma_microbench(lib, ctx, events)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scn)
             nv_used = int(out["cpu_baseline"]["sample"].split("first ")[1].split(" ")[0])
