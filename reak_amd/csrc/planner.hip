@@ -71,31 +71,87 @@ struct ProblemDev {  // device pointers of one problem
 // counter of this round's parity and block 0 clears the other one for the next round; the two steer kernels of the
 // round compare the sum with their threshold (see launch_edges).
 constexpr uint32_t kProfRounds = 8192;  // profiled rounds per planner (RKH_PROFILE_NN)
-__global__ void round_begin_kernel(const ProblemDev* __restrict__ probs, uint32_t round_slot, uint32_t* __restrict__ sel,
-                                   uint32_t parity) {
-  if (threadIdx.x != 0) return;
-  const ProblemDev pr = probs[blockIdx.x];
-  PlannerState* st = pr.st;
-  if (blockIdx.x == 0) sel[parity ^ 1u] = 0u;
-  if (pr.round_n) pr.round_n[round_slot] = st->done ? 0u : st->n;
-  uint32_t B = 0;
-  if (!st->done) {
-    const float want = st->batch_factor * sqrtf(float(st->n));
-    B = uint32_t(want);
+// One block for all problems.  Batch sizes: B = scale * batch_factor * sqrt(n) (results do not depend on them).  With
+// fit_fill > 0 the scale of the round is chosen here, from the exact counts: the two-lanes steer kernel runs one wave of
+// 28 edges per SIMD (`slots` waves at a time), so the steer time of a round is its number of waves divided by `slots`,
+// rounded UP; the scale (0.75 .. 1.4) is bisected so that the round's waves -- candidates plus the pending goal probes
+// of every problem -- fill fit_fill of a whole number of such passes.
+__global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __restrict__ probs, uint32_t P,
+                                                           uint32_t round_slot, uint32_t* __restrict__ sel, uint32_t parity,
+                                                           float fit_fill, uint32_t slots, uint32_t* __restrict__ wave_base) {
+  __shared__ unsigned int s_waves;
+  const uint32_t tid = threadIdx.x;
+  auto batch_of = [&](const PlannerState* st, float sc) -> uint32_t {
+    if (st->done) return 0u;
+    const float want = sc * st->batch_factor * sqrtf(float(st->n));
+    uint32_t B = uint32_t(want);
     if (B < st->b_min) B = st->b_min;
     if (B > st->b_max) B = st->b_max;
     const uint32_t avail = st->samples_ready - st->s0;
     if (B > avail) B = avail;
-    if (B == 0) st->done = 2;  // sample stream exhausted: host must upload more
+    return B;
+  };
+  auto waves_at = [&](float sc) -> uint32_t {  // block-wide sum, same value in every thread
+    uint32_t w = 0;
+    for (uint32_t i = tid; i < P; i += blockDim.x) {
+      const PlannerState* st = probs[i].st;
+      w += (batch_of(st, sc) + 27u) / 28u + (st->n_new + 27u) / 28u;
+    }
+    __syncthreads();
+    if (tid == 0) s_waves = 0u;
+    __syncthreads();
+    if (w) atomicAdd(&s_waves, w);
+    __syncthreads();
+    return s_waves;
+  };
+  float scale = 1.0f;
+  if (fit_fill > 0.0f) {
+    const float w1 = float(waves_at(1.0f));
+    if (w1 > 0.75f * float(slots)) {
+      const float passes = ceilf(w1 / float(slots) - 0.15f);
+      const float target = passes * float(slots) * fit_fill;
+      float lo = 0.75f, hi = 1.4f;
+      for (int it = 0; it < 10; ++it) {
+        const float mid = 0.5f * (lo + hi);
+        if (float(waves_at(mid)) > target) hi = mid;
+        else lo = mid;
+      }
+      scale = lo;
+    }
   }
-  st->B = B;
-  st->F = B;
-  if (pr.round_n) pr.round_n[kProfRounds + round_slot] = B;  // second half of the profile array: queries of the round
-  if (B) {
-    st->rounds += 1;
-    st->edges_speculated += B;
+  if (tid == 0) sel[parity ^ 1u] = 0u;
+  uint32_t edges = 0;
+  for (uint32_t i = tid; i < P; i += blockDim.x) {
+    const ProblemDev pr = probs[i];
+    PlannerState* st = pr.st;
+    if (pr.round_n) pr.round_n[round_slot] = st->done ? 0u : st->n;
+    const uint32_t B = batch_of(st, scale);
+    if (!st->done && B == 0) st->done = 2;  // sample stream exhausted: host must upload more
+    st->B = B;
+    st->F = B;
+    if (pr.round_n) pr.round_n[kProfRounds + round_slot] = B;  // second half of the profile array: queries of the round
+    if (B) {
+      st->rounds += 1;
+      st->edges_speculated += B;
+    }
+    edges += B + st->n_new;
+    if (wave_base) {  // working waves of the two segments of this problem (two-lanes steer kernel); scanned below
+      wave_base[2 * i + 1] = (B + 27u) / 28u;
+      wave_base[2 * i + 2] = (st->n_new + 27u) / 28u;
+    }
   }
-  atomicAdd(&sel[parity], B + st->n_new);
+  if (edges) atomicAdd(&sel[parity], edges);
+  if (wave_base) {
+    __syncthreads();
+    if (tid == 0) {  // exclusive prefix in place: wave_base[s] = waves before segment s, wave_base[2 P] = total
+      uint32_t acc = 0;
+      wave_base[0] = 0;
+      for (uint32_t k = 1; k <= 2 * P; ++k) {
+        acc += wave_base[k];
+        wave_base[k] = acc;
+      }
+    }
+  }
 }
 
 // One wave per candidate b: smallest squared distance from sample b to the end states of accepted
@@ -258,11 +314,15 @@ struct rkh_planner {
   double* d_lane_ws = nullptr;  // workspace of the two-lanes-per-edge kernel
   double coord_bound = 0.0;     // max |coordinate| of vertices and samples (hyperbox bounds), 0 = unknown
   uint32_t* d_sel = nullptr;    // [2] edges of the current round (by round parity), see round_begin_kernel
+  uint32_t* d_wave_base = nullptr;  // [2 P + 1] prefix of the working waves per (problem, candidates | probes) segment
   uint32_t round_parity = 0;
   // host-side upper bounds that size the launches of a round (the exact counts live on the device): n_ub[i] >= vertex
   // count of problem i (exact after every sync, + the round's batch bound per enqueued round)
   std::vector<uint64_t> n_ub;
   uint32_t prev_batch_ub = 0;  // batch bound of the previous round = bound on this round's goal probes
+  int wave_fit = 1;          // per-round batch scale chosen on the device (round_begin_kernel); RKH_WAVE_FIT=0: off
+  double wave_fill = 0.99;   // target fill of the last pass of steer waves (RKH_WAVE_FILL)
+  uint32_t wave_slots = 1024;    // SIMDs of the device = concurrent waves of the two-lanes steer kernel
   uint32_t lane_threshold = 4500;  // rounds with at least this many edges go to the two-lanes-per-edge kernel
   uint32_t part_blocks = 0;
   uint64_t max_capacity = 0;
@@ -356,8 +416,8 @@ void launch_fixup(rkh_planner* p, uint32_t batch_ub) {
 
 // upper bound of the batch size round_begin_kernel will choose for a problem with at most n_ub vertices (same float
 // formula, monotone in n)
-uint32_t batch_upper_bound(const PlannerState& st, uint64_t n_ub) {
-  const float want = st.batch_factor * sqrtf(float(n_ub));
+uint32_t batch_upper_bound(const PlannerState& st, uint64_t n_ub, float batch_scale = 1.0f) {
+  const float want = batch_scale * st.batch_factor * sqrtf(float(n_ub));
   uint32_t B = uint32_t(want);
   if (B < st.b_min) B = st.b_min;
   if (B > st.b_max) B = st.b_max;
@@ -365,7 +425,8 @@ uint32_t batch_upper_bound(const PlannerState& st, uint64_t n_ub) {
 }
 
 // steer / probe edges of all problems: RK4 propagation (dynamic space) or the min_interval walk (quasi-static space)
-rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const EdgeIO* tab_a, const EdgeIO* tab_b) {
+rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const EdgeIO* tab_a, const EdgeIO* tab_b,
+                        bool compact = false) {
   if (p->quasi_static)
     return launch_edge_check(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
                              p->scene->n_pairs, p->qs, EdgeIO(), grid_a, nullptr, grid_b, tab_a, tab_b, p->P);
@@ -377,6 +438,10 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
   // the one that is not chosen exits at once.  Small rounds -> one wave per edge (latency), large -> 28 edges per wave.
   KernelGate gate_wave{p->d_sel + p->round_parity, 0u, p->lane_threshold};
   KernelGate gate_lane{p->d_sel + p->round_parity, p->lane_threshold, 0xFFFFFFFFu};
+  if (compact && p->d_wave_base) {  // a regular round: (candidates, probes) segments as round_begin_kernel counted them
+    gate_lane.wave_base = p->d_wave_base;
+    gate_lane.n_segments = 2 * p->P;
+  }
   rkh_status st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
                                    p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, 64, tab_a, tab_b, p->P,
                                    nullptr, gate_wave);
@@ -418,25 +483,29 @@ rkh_status enqueue_round(rkh_planner* p) {
       p->ev_steer.push_back(b);
     }
   }
+  // the round's batch scale is chosen on the device (round_begin_kernel); the launches are sized for its upper end
+  const bool fit = p->wave_fit && !p->quasi_static && p->lanes_per_edge == 0;
+  const float scale = fit ? 1.4f : 1.0f;
   // launch sizes of this round from the host-side bounds
   uint32_t batch_ub = 1;
   for (uint32_t i = 0; i < p->P; ++i) {
     const PlannerState& hs = p->prob[i].h_state;
-    const uint32_t b = batch_upper_bound(hs, p->n_ub[i]);
+    const uint32_t b = batch_upper_bound(hs, p->n_ub[i], scale);
     batch_ub = std::max(batch_ub, b);
     p->n_ub[i] = std::min<uint64_t>(p->n_ub[i] + b, uint64_t(hs.max_total));
   }
   const uint32_t probe_ub = p->prev_batch_ub ? p->prev_batch_ub : p->b_max;
   p->prev_batch_ub = batch_ub;
   p->round_parity ^= 1u;
-  hipLaunchKernelGGL(round_begin_kernel, dim3(p->P), dim3(64), 0, s, p->d_probs, slot, p->d_sel, p->round_parity);
+  hipLaunchKernelGGL(round_begin_kernel, dim3(1), dim3(256), 0, s, p->d_probs, p->P, slot, p->d_sel, p->round_parity,
+                     fit ? float(p->wave_fill) : 0.0f, p->wave_slots, p->d_wave_base);
   // 1. NN sweep of every problem's samples over its snapshot
   rkh_status st = launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, batch_ub, p->part_blocks, ev0, ev1,
                              p->coord_bound);
   if (st != RKH_OK) return st;
   // 2. speculative steer of all candidates + the goal probes of the vertices the previous round committed
   if (ev0) (void)hipEventRecord(p->ev_steer[2 * slot], s);
-  st = launch_edges(p, batch_ub, probe_ub, p->d_io_steer, p->d_io_probe);
+  st = launch_edges(p, batch_ub, probe_ub, p->d_io_steer, p->d_io_probe, true);
   if (st != RKH_OK) return st;
   if (ev0) (void)hipEventRecord(p->ev_steer[2 * slot + 1], s);
   // 3. fix-up against the vertices this round itself would add
@@ -534,6 +603,13 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     }
   RKH_HIP(hipSetDevice(scene->ctx->device));
   RKH_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  if (const char* e = getenv("RKH_WAVE_FIT")) p->wave_fit = atoi(e);
+  if (const char* e = getenv("RKH_WAVE_FILL")) p->wave_fill = atof(e);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, scene->ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+      p->wave_slots = uint32_t(prop.multiProcessorCount) * 4u;
+  }
   if (const char* e = getenv("RKH_BATCH_MAX")) p->b_max = std::max(8, atoi(e));
   p->b_max = std::min<uint32_t>(p->b_max, 4096);
   if (const char* e = getenv("RKH_LANE_THRESHOLD")) p->lane_threshold = uint32_t(std::max(0, atoi(e)));
@@ -565,6 +641,10 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   RKH_HIP(hipMalloc(&p->d_io_probe, P * sizeof(EdgeIO)));
   if (!p->quasi_static && (p->lanes_per_edge == 1 || p->lanes_per_edge == 0))
     RKH_HIP(hipMalloc(&p->d_lane_ws, propagate_lanes_workspace_bytes(p->n_dof, p->b_max, p->b_max, P)));
+  if (p->d_lane_ws) {
+    RKH_HIP(hipMalloc(&p->d_wave_base, (2 * size_t(P) + 1) * sizeof(uint32_t)));
+    RKH_HIP(hipMemset(p->d_wave_base, 0, (2 * size_t(P) + 1) * sizeof(uint32_t)));
+  }
   RKH_HIP(hipMalloc(&p->d_sel, 2 * sizeof(uint32_t)));
   RKH_HIP(hipMemset(p->d_sel, 0, 2 * sizeof(uint32_t)));
   for (uint32_t i = 0; i < P; ++i) {
@@ -726,6 +806,7 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   }
   (void)hipFree(p->d_lane_ws);
   (void)hipFree(p->d_sel);
+  (void)hipFree(p->d_wave_base);
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->ev_steer) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(p->stream);

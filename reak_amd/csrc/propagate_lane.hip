@@ -495,14 +495,29 @@ __global__ __launch_bounds__(64, 1) void propagate_lane_kernel(const SceneDev* _
     const uint32_t c = *gate.count;
     if (c < gate.lo || c >= gate.hi) return;
   }
+  constexpr int D = 2 * N;
+  bool group_b = blockIdx.x >= grid_a;
+  uint32_t problem = blockIdx.y;
+  uint32_t wave = group_b ? blockIdx.x - grid_a : blockIdx.x;
+  if (gate.wave_base) {  // compact mapping: block L of the grid (dispatch order) takes working wave L
+    const uint32_t L = blockIdx.y * gridDim.x + blockIdx.x;
+    if (L >= gate.wave_base[gate.n_segments]) return;
+    uint32_t lo = 0, hi = gate.n_segments;  // wave_base[lo] <= L < wave_base[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (gate.wave_base[mid] <= L) lo = mid;
+      else hi = mid;
+    }
+    problem = lo >> 1;
+    group_b = (lo & 1u) != 0u;
+    wave = L - gate.wave_base[lo];
+  }
   if (threadIdx.x < 3 * N) lds.axis[threadIdx.x / 3][threadIdx.x % 3] = sc->joints[threadIdx.x / 3].axis[threadIdx.x % 3];
   __syncthreads();
-  constexpr int D = 2 * N;
-  const bool group_b = blockIdx.x >= grid_a;
-  const EdgeIO io = tab_a ? (group_b ? tab_b[blockIdx.y] : tab_a[blockIdx.y]) : (group_b ? io_b : io_a);
+  const EdgeIO io = tab_a ? (group_b ? tab_b[problem] : tab_a[problem]) : (group_b ? io_b : io_a);
   const uint32_t B = io.d_B ? *io.d_B : io.B;
   const int lane = threadIdx.x;
-  const uint32_t e0 = (group_b ? blockIdx.x - grid_a : blockIdx.x) * uint32_t(kEdgesPerWave);
+  const uint32_t e0 = wave * uint32_t(kEdgesPerWave);
   if (e0 >= B) return;
   const int h = lane >> 5;
   const int el_raw = lane & 31;

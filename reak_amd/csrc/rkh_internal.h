@@ -234,6 +234,12 @@ struct EdgeIO {  // inputs / outputs of one propagate launch (all device pointer
 struct KernelGate {
   const uint32_t* count = nullptr;
   uint32_t lo = 0, hi = 0xFFFFFFFFu;
+  // two-lanes kernel, table launches: exclusive prefix of the working waves per segment (segment 2p = candidates of
+  // problem p, 2p+1 = its goal probes; wave_base[n_segments] = total).  The blocks of the grid, in dispatch order, then
+  // take the working waves one after the other, so the round-robin of blocks over the 8 XCDs spreads the work evenly
+  // whatever the per-problem counts are (a (wave, problem) grid leaves holes that land unevenly on the XCDs).
+  const uint32_t* wave_base = nullptr;
+  uint32_t n_segments = 0;
 };
 rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                             int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges,
