@@ -178,8 +178,8 @@ def main():
     ap.add_argument("--max-vertices", type=int, default=100000)
     ap.add_argument("--groups", type=int, default=int(os.environ.get("RKH_BENCH_GROUPS", "1")),
                     help="planner handles (HIP streams) the problems of a GPU are split over; 2 overlaps one group's "
-                         "steer tail with the other's NN sweep (+5 %% at 100 k vertices, +14 %% at 30 k) but the "
-                         "per-kernel HIP-event times then include the contention, so the default keeps one group")
+                         "steer tail with the other's NN sweep, which paid before the steer waves were packed and the "
+                         "batches fitted to whole passes of the machine; now one group is faster (DESIGN.md section 5)")
     ap.add_argument("--rounds-per-sync", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
