@@ -828,3 +828,26 @@ def test_planar_scene_refuses_dynamics(L, ctx):
     sc = L.Scene(ctx, c1)
     with pytest.raises(L.RkhError):
         sc.state_derivative(np.zeros((1, 6)), np.zeros((1, 3)))
+
+
+def test_batch_scale_fit_and_wave_packing_do_not_change_results(L, ctx, oracle, c2, monkeypatch):
+    """The per-round batch scale (fitted on the device to whole passes of steer waves) and the packed wave mapping only
+    move work around: the trees of a batch are the same with the fit switched off, and equal to the oracle's."""
+    prms = [c2.rrt_params(seed=70 + i, max_vertices=2500) for i in range(40)]
+    trees = {}
+    for fit in ("1", "0"):
+        monkeypatch.setenv("RKH_WAVE_FIT", fit)
+        pl = L.RrtPlanner(L.Scene(ctx, c2), prms)
+        pl.solve_planning_query()
+        trees[fit] = [(int(pl.all_stats[i].num_vertices), int(pl.all_stats[i].iterations), pl.tree(i)) for i in (0, 17, 39)]
+        pl.close()
+    osc = oracle.OracleScene(c2, fast=True)
+    for k, i in enumerate((0, 17, 39)):
+        a, b = trees["1"][k], trees["0"][k]
+        assert a[:2] == b[:2]
+        for key in ("parent", "nn_seq", "accept", "pos"):
+            assert np.array_equal(a[2][key], b[2][key]), key
+    rc, ro, rt = osc.rrt_dyn(prms[17])
+    t = trees["1"][1]
+    assert (t[0], t[1]) == (ro.num_vertices, ro.iterations)
+    assert np.array_equal(t[2]["parent"], rt["parent"]) and np.array_equal(t[2]["accept"], rt["accept"])
