@@ -21,6 +21,18 @@ it = sum(int(s.loop_iterations) for s in pl.all_stats); ed = sum(int(s.edges_che
 print(f"C3 RRT* GPU P={P} mv={mv}: {dt:.1f}s  {it/dt:.0f} iterations/s  {ed/dt:.0f} edges/s  rewires {pl.stats.rewires} "
       f"solutions {pl.stats.num_solutions} best {pl.stats.best_cost:.4f}", flush=True)
 g = pl.graph(0)
+if mv > 60000:  # the oracle's linear k-NN makes it impractical here: check the cost invariants of the result instead
+    pred, dist, pos = g["pred"].astype(np.int64), g["dist"], g["pos"]
+    v = np.arange(1, len(pred))
+    ok = pred[v] != 0xFFFFFFFF
+    w = np.sqrt(((pos[v[ok]] - pos[pred[v[ok]]]) ** 2).sum(axis=1))
+    # an edge's weight is the distance travelled along it, and can_be_connected (planning_visitors.hpp:385-395) accepts a
+    # walk that stops up to 5 % short of its target, so dist[v] - dist[pred] lies in [|edge| / 1.05, |edge|]
+    dw = dist[v[ok]] - dist[pred[v[ok]]]
+    print(f"vertices {len(pred)}, connected {ok.sum()}, edges with weight != length: {(np.abs(dw - w) > 1e-9).sum()}, "
+          f"all within [|e|/1.05, |e|]: {bool(((dw <= w + 1e-9) & (dw >= w / 1.05 - 1e-9)).all())}, "
+          f"costs increase along the tree: {bool((dw > 0).all())}", flush=True)
+    sys.exit(0)
 osc = O.OracleScene(scn, fast=False)
 rc, out, rg = osc.rrtstar_qs(lo, hi, mi, prms[0])
 print(f"C3 RRT* CPU oracle seed 1: {out.seconds:.1f}s {out.loop_iterations/out.seconds:.0f} iterations/s; "
