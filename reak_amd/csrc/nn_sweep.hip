@@ -325,7 +325,9 @@ static constexpr int kCandCap = 8;        // per-lane candidate list (compacted,
 
 template <int DP>
 __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs single, const NnArgs* __restrict__ table,
-                                                                      int D, uint32_t Bpad, double coord_bound) {
+                                                                      int D, uint32_t Bpad, double coord_bound,
+                                                                      const uint32_t* __restrict__ yblock_base,
+                                                                      uint32_t n_problems) {
   constexpr int H = DP / 2;
   constexpr int TS = kTileRows + 4;  // float stride of one coordinate's row of the transposed copy
   __shared__ __attribute__((aligned(16))) float tileT[DP * TS];
@@ -333,7 +335,26 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
   __shared__ uint32_t cand_row[kCandCap][kMfmaThreads];
   __shared__ float cand_c[kCandCap][kMfmaThreads];
 
-  const NnArgs a = table ? table[blockIdx.z] : single;
+  // (row slice, query block, problem) of this block.  With a prefix of the query blocks per problem (yblock_base, written
+  // by the planner's round_begin_kernel) the grid's blocks, in dispatch order, take the working (slice, query block)
+  // pairs one after the other: no holes for problems with fewer queries than the grid was sized for, and an even spread
+  // over the XCDs.
+  uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (yblock_base) {
+    const uint32_t L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const uint32_t yy = L / gridDim.x;
+    if (yy >= yblock_base[n_problems]) return;
+    uint32_t lo = 0, hi = n_problems;  // yblock_base[lo] <= yy < yblock_base[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (yblock_base[mid] <= yy) lo = mid;
+      else hi = mid;
+    }
+    bx = L - yy * gridDim.x;
+    by = yy - yblock_base[lo];
+    bz = lo;
+  }
+  const NnArgs a = table ? table[bz] : single;
   const double* __restrict__ pos = a.pos;
   const double* __restrict__ q = a.q;
   const uint32_t* __restrict__ d_qoff = a.d_qoff;
@@ -344,8 +365,8 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, hi = lane >> 5;
-  const uint32_t qi = blockIdx.y * kMfmaQueries + wave * 32 + col;
-  if (blockIdx.y * kMfmaQueries >= B) return;
+  const uint32_t qi = by * kMfmaQueries + wave * 32 + col;
+  if (by * kMfmaQueries >= B) return;
   const uint64_t qsrc = uint64_t(qi < B ? qi : (B - 1)) + (d_qoff ? uint64_t(*d_qoff) : 0ull);
 
   float bop[H];  // B operand of step j: -2 q^[2 j + hi]
@@ -363,7 +384,7 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
 
   const uint64_t tiles_total = (n + kTileRows - 1) / kTileRows;
   const uint64_t tiles_per_block = (tiles_total + gridDim.x - 1) / gridDim.x;
-  const uint64_t tile0 = uint64_t(blockIdx.x) * tiles_per_block;
+  const uint64_t tile0 = uint64_t(bx) * tiles_per_block;
   uint64_t tile1 = tile0 + tiles_per_block;
   if (tile1 > tiles_total) tile1 = tiles_total;
 
@@ -457,7 +478,7 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
     __syncthreads();
     cmin = fminf(cmin, __shfl_xor(cmin, 32, 64));  // the other half's minimum bounds the final one just as well
     // a wave whose 32 query slots all lie past the batch only helps staging the tiles
-    const int n_slabs = (blockIdx.y * kMfmaQueries + wave * 32 < B) ? kTileRows / 32 : 0;
+    const int n_slabs = (by * kMfmaQueries + wave * 32 < B) ? kTileRows / 32 : 0;
 #pragma unroll 2
     for (int g = 0; g < n_slabs; ++g) {
       rkh_f16v c;
@@ -520,8 +541,8 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
     }
   }
   if (hi == 0 && qi < B) {
-    part_dist[uint64_t(blockIdx.x) * Bpad + qi] = best_d;
-    part_idx[uint64_t(blockIdx.x) * Bpad + qi] = best_i;
+    part_dist[uint64_t(bx) * Bpad + qi] = best_d;
+    part_idx[uint64_t(bx) * Bpad + qi] = best_i;
   }
 }
 
@@ -612,13 +633,15 @@ uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B, uint32_t n_problems) {
   return pick_gx(n_upper, gy * (n_problems ? n_problems : 1));
 }
 
+uint32_t nn1_mfma_queries() { return uint32_t(kMfmaQueries); }
+
 static const char* g_last_kernel = "";
 const char* nn_last_kernel_name() { return g_last_kernel; }
 
 template <int DP>
 static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
                                 uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0,
-                                hipEvent_t ev1, double coord_bound) {
+                                hipEvent_t ev1, double coord_bound, const uint32_t* d_yblock_base) {
   const uint32_t qb = pick_qb(B);
   const uint32_t gy = (B + qb - 1) / qb;
   uint32_t gx = pick_gx(n_upper, gy * n_problems);
@@ -634,7 +657,8 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
   g_last_kernel = mfma ? "nn1_sweep_mfma_kernel" : (f32 ? "nn1_sweep_f32_kernel" : "nn1_sweep_kernel");
   if (mfma) {
     if constexpr (DP <= 16)
-      hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP>), grid, dim3(kMfmaThreads), 0, s, single, d_table, D, Bpad, coord_bound);
+      hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP>), grid, dim3(kMfmaThreads), 0, s, single, d_table, D, Bpad, coord_bound,
+                         d_table ? d_yblock_base : nullptr, n_problems);
   } else
   switch (qb) {
     case 8: RKH_NN1_LAUNCH(8); break;
@@ -656,11 +680,12 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
 // n_upper (host bound on the vertex count) and B (host bound on the query count) only size the grid.
 rkh_status launch_nn1(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
                       uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0, hipEvent_t ev1,
-                      double coord_bound) {
+                      double coord_bound, const uint32_t* d_yblock_base) {
   if (B == 0 || n_problems == 0) return RKH_OK;
   switch (padded_dims(D)) {
 #define RKH_CASE(DP) \
-  case DP: return launch_nn1_dp<DP>(s, D, single, d_table, n_problems, n_upper, B, part_capacity_blocks, ev0, ev1, coord_bound)
+  case DP: return launch_nn1_dp<DP>(s, D, single, d_table, n_problems, n_upper, B, part_capacity_blocks, ev0, ev1, coord_bound, \
+                                    d_yblock_base)
     RKH_CASE(2);
     RKH_CASE(4);
     RKH_CASE(6);

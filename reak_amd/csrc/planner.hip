@@ -78,7 +78,8 @@ constexpr uint32_t kProfRounds = 8192;  // profiled rounds per planner (RKH_PROF
 // of every problem -- fill fit_fill of a whole number of such passes.
 __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __restrict__ probs, uint32_t P,
                                                            uint32_t round_slot, uint32_t* __restrict__ sel, uint32_t parity,
-                                                           float fit_fill, uint32_t slots, uint32_t* __restrict__ wave_base) {
+                                                           float fit_fill, uint32_t slots, uint32_t* __restrict__ wave_base,
+                                                           uint32_t* __restrict__ nn_base, uint32_t nn_queries) {
   __shared__ unsigned int s_waves;
   const uint32_t tid = threadIdx.x;
   auto batch_of = [&](const PlannerState* st, float sc) -> uint32_t {
@@ -139,17 +140,24 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
       wave_base[2 * i + 1] = (B + 27u) / 28u;
       wave_base[2 * i + 2] = (st->n_new + 27u) / 28u;
     }
+    if (nn_base) nn_base[i + 1] = (B + nn_queries - 1u) / nn_queries;  // query blocks of the NN sweep; scanned below
   }
   if (edges) atomicAdd(&sel[parity], edges);
-  if (wave_base) {
-    __syncthreads();
-    if (tid == 0) {  // exclusive prefix in place: wave_base[s] = waves before segment s, wave_base[2 P] = total
-      uint32_t acc = 0;
-      wave_base[0] = 0;
-      for (uint32_t k = 1; k <= 2 * P; ++k) {
-        acc += wave_base[k];
-        wave_base[k] = acc;
-      }
+  __syncthreads();
+  if (wave_base && tid == 0) {  // exclusive prefix in place: wave_base[s] = waves before segment s, wave_base[2 P] = total
+    uint32_t acc = 0;
+    wave_base[0] = 0;
+    for (uint32_t k = 1; k <= 2 * P; ++k) {
+      acc += wave_base[k];
+      wave_base[k] = acc;
+    }
+  }
+  if (nn_base && tid == 64) {
+    uint32_t acc = 0;
+    nn_base[0] = 0;
+    for (uint32_t k = 1; k <= P; ++k) {
+      acc += nn_base[k];
+      nn_base[k] = acc;
     }
   }
 }
@@ -314,6 +322,7 @@ struct rkh_planner {
   double* d_lane_ws = nullptr;  // workspace of the two-lanes-per-edge kernel
   double coord_bound = 0.0;     // max |coordinate| of vertices and samples (hyperbox bounds), 0 = unknown
   uint32_t* d_sel = nullptr;    // [2] edges of the current round (by round parity), see round_begin_kernel
+  uint32_t* d_nn_base = nullptr;    // [P + 1] prefix of the NN sweep's query blocks per problem (matrix-core kernel)
   uint32_t* d_wave_base = nullptr;  // [2 P + 1] prefix of the working waves per (problem, candidates | probes) segment
   uint32_t round_parity = 0;
   // host-side upper bounds that size the launches of a round (the exact counts live on the device): n_ub[i] >= vertex
@@ -498,10 +507,10 @@ rkh_status enqueue_round(rkh_planner* p) {
   p->prev_batch_ub = batch_ub;
   p->round_parity ^= 1u;
   hipLaunchKernelGGL(round_begin_kernel, dim3(1), dim3(256), 0, s, p->d_probs, p->P, slot, p->d_sel, p->round_parity,
-                     fit ? float(p->wave_fill) : 0.0f, p->wave_slots, p->d_wave_base);
+                     fit ? float(p->wave_fill) : 0.0f, p->wave_slots, p->d_wave_base, p->d_nn_base, nn1_mfma_queries());
   // 1. NN sweep of every problem's samples over its snapshot
   rkh_status st = launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, batch_ub, p->part_blocks, ev0, ev1,
-                             p->coord_bound);
+                             p->coord_bound, p->d_nn_base);
   if (st != RKH_OK) return st;
   // 2. speculative steer of all candidates + the goal probes of the vertices the previous round committed
   if (ev0) (void)hipEventRecord(p->ev_steer[2 * slot], s);
@@ -645,6 +654,8 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     RKH_HIP(hipMalloc(&p->d_wave_base, (2 * size_t(P) + 1) * sizeof(uint32_t)));
     RKH_HIP(hipMemset(p->d_wave_base, 0, (2 * size_t(P) + 1) * sizeof(uint32_t)));
   }
+  RKH_HIP(hipMalloc(&p->d_nn_base, (size_t(P) + 1) * sizeof(uint32_t)));
+  RKH_HIP(hipMemset(p->d_nn_base, 0, (size_t(P) + 1) * sizeof(uint32_t)));
   RKH_HIP(hipMalloc(&p->d_sel, 2 * sizeof(uint32_t)));
   RKH_HIP(hipMemset(p->d_sel, 0, 2 * sizeof(uint32_t)));
   for (uint32_t i = 0; i < P; ++i) {
@@ -807,6 +818,7 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   (void)hipFree(p->d_lane_ws);
   (void)hipFree(p->d_sel);
   (void)hipFree(p->d_wave_base);
+  (void)hipFree(p->d_nn_base);
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->ev_steer) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(p->stream);

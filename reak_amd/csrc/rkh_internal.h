@@ -50,7 +50,10 @@ struct NnArgs {  // one 1-NN problem: tree rows, queries, outputs (device pointe
 };
 rkh_status launch_nn1(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
                       uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0 = nullptr,
-                      hipEvent_t ev1 = nullptr, double coord_bound = 0.0);
+                      hipEvent_t ev1 = nullptr, double coord_bound = 0.0, const uint32_t* d_yblock_base = nullptr);
+// d_yblock_base (table launches, matrix-core kernel): [n_problems + 1] exclusive prefix of ceil(B_p / nn1_mfma_queries())
+// over the problems; the grid's blocks then take the working (row slice, query block) pairs in dispatch order.
+uint32_t nn1_mfma_queries();
 // coord_bound > 0: every |coordinate| of rows and queries is <= coord_bound; sweeps with >= 32 queries then run the
 // single-precision pre-filter variant (identical results).
 uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B, uint32_t n_problems = 1);
