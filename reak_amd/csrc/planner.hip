@@ -79,7 +79,8 @@ constexpr uint32_t kProfRounds = 8192;  // profiled rounds per planner (RKH_PROF
 __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __restrict__ probs, uint32_t P,
                                                            uint32_t round_slot, uint32_t* __restrict__ sel, uint32_t parity,
                                                            float fit_fill, uint32_t slots, uint32_t* __restrict__ wave_base,
-                                                           uint32_t* __restrict__ nn_base, uint32_t nn_queries) {
+                                                           uint32_t* __restrict__ nn_base, uint32_t nn_queries,
+                                                           uint32_t* __restrict__ edge_base) {
   __shared__ unsigned int s_waves;
   const uint32_t tid = threadIdx.x;
   auto batch_of = [&](const PlannerState* st, float sc) -> uint32_t {
@@ -141,6 +142,10 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
       wave_base[2 * i + 2] = (st->n_new + 27u) / 28u;
     }
     if (nn_base) nn_base[i + 1] = (B + nn_queries - 1u) / nn_queries;  // query blocks of the NN sweep; scanned below
+    if (edge_base) {  // edges per segment (one-wave-per-edge steer kernel of the small rounds); scanned below
+      edge_base[2 * i + 1] = B;
+      edge_base[2 * i + 2] = st->n_new;
+    }
   }
   if (edges) atomicAdd(&sel[parity], edges);
   __syncthreads();
@@ -150,6 +155,14 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
     for (uint32_t k = 1; k <= 2 * P; ++k) {
       acc += wave_base[k];
       wave_base[k] = acc;
+    }
+  }
+  if (edge_base && tid == 128) {
+    uint32_t acc = 0;
+    edge_base[0] = 0;
+    for (uint32_t k = 1; k <= 2 * P; ++k) {
+      acc += edge_base[k];
+      edge_base[k] = acc;
     }
   }
   if (nn_base && tid == 64) {
@@ -450,6 +463,8 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
   if (compact && p->d_wave_base) {  // a regular round: (candidates, probes) segments as round_begin_kernel counted them
     gate_lane.wave_base = p->d_wave_base;
     gate_lane.n_segments = 2 * p->P;
+    gate_wave.wave_base = p->d_wave_base + (2 * p->P + 1);
+    gate_wave.n_segments = 2 * p->P;
   }
   rkh_status st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
                                    p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, 64, tab_a, tab_b, p->P,
@@ -507,7 +522,8 @@ rkh_status enqueue_round(rkh_planner* p) {
   p->prev_batch_ub = batch_ub;
   p->round_parity ^= 1u;
   hipLaunchKernelGGL(round_begin_kernel, dim3(1), dim3(256), 0, s, p->d_probs, p->P, slot, p->d_sel, p->round_parity,
-                     fit ? float(p->wave_fill) : 0.0f, p->wave_slots, p->d_wave_base, p->d_nn_base, nn1_mfma_queries());
+                     fit ? float(p->wave_fill) : 0.0f, p->wave_slots, p->d_wave_base, p->d_nn_base, nn1_mfma_queries(),
+                     p->d_wave_base ? p->d_wave_base + (2 * p->P + 1) : nullptr);
   // 1. NN sweep of every problem's samples over its snapshot
   rkh_status st = launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, batch_ub, p->part_blocks, ev0, ev1,
                              p->coord_bound, p->d_nn_base);
@@ -651,8 +667,9 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   if (!p->quasi_static && (p->lanes_per_edge == 1 || p->lanes_per_edge == 0))
     RKH_HIP(hipMalloc(&p->d_lane_ws, propagate_lanes_workspace_bytes(p->n_dof, p->b_max, p->b_max, P)));
   if (p->d_lane_ws) {
-    RKH_HIP(hipMalloc(&p->d_wave_base, (2 * size_t(P) + 1) * sizeof(uint32_t)));
-    RKH_HIP(hipMemset(p->d_wave_base, 0, (2 * size_t(P) + 1) * sizeof(uint32_t)));
+    // two prefix arrays of 2 P + 1 entries: 28-edge waves (two-lanes kernel), then single edges (one-wave-per-edge kernel)
+    RKH_HIP(hipMalloc(&p->d_wave_base, 2 * (2 * size_t(P) + 1) * sizeof(uint32_t)));
+    RKH_HIP(hipMemset(p->d_wave_base, 0, 2 * (2 * size_t(P) + 1) * sizeof(uint32_t)));
   }
   RKH_HIP(hipMalloc(&p->d_nn_base, (size_t(P) + 1) * sizeof(uint32_t)));
   RKH_HIP(hipMemset(p->d_nn_base, 0, (size_t(P) + 1) * sizeof(uint32_t)));

@@ -26,6 +26,7 @@
 // sin/cos (OCML vs glibc) differ by ulps (stated tolerance: 1e-10 relative on propagated states).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -661,12 +662,27 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
   BlockLds<N, GL>& lds = *reinterpret_cast<BlockLds<N, GL>*>(smem_raw);
   ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayout<N, GL>::block_bytes);
   // blockIdx.y selects the planning problem when per-problem EdgeIO tables are given
-  const bool group_b = blockIdx.x >= grid_a;
-  const EdgeIO io = tab_a ? (group_b ? tab_b[blockIdx.y] : tab_a[blockIdx.y]) : (group_b ? io_b : io_a);
+  bool group_b = blockIdx.x >= grid_a;
+  uint32_t problem = blockIdx.y;
+  uint32_t blk = group_b ? blockIdx.x - grid_a : blockIdx.x;
+  if (gate.wave_base) {  // compact mapping (one edge per wave): block L of a 1-D grid takes working edge L
+    const uint32_t L = blockIdx.x;
+    if (L >= gate.wave_base[gate.n_segments]) return;
+    uint32_t lo = 0, hi = gate.n_segments;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (gate.wave_base[mid] <= L) lo = mid;
+      else hi = mid;
+    }
+    problem = lo >> 1;
+    group_b = (lo & 1u) != 0u;
+    blk = L - gate.wave_base[lo];
+  }
+  const EdgeIO io = tab_a ? (group_b ? tab_b[problem] : tab_a[problem]) : (group_b ? io_b : io_a);
   const uint32_t B = io.d_B ? *io.d_B : io.B;
   const int lane = threadIdx.x;
   const int g = lane / GL, gl = lane % GL, gb = g * GL;
-  const uint32_t e0 = (group_b ? blockIdx.x - grid_a : blockIdx.x) * G;
+  const uint32_t e0 = blk * G;
   if (e0 >= B) return;
   const uint32_t e = e0 + g;
   const bool edge_valid = e < B;
@@ -1070,7 +1086,14 @@ static void launch_propagate_t(hipStream_t s, int n_env, const SceneDev* d_scene
                                KernelGate gate) {
   constexpr uint32_t G = 64 / GL;
   const uint32_t ga = (edges_a + G - 1) / G, gbk = (edges_b + G - 1) / G;
-  hipLaunchKernelGGL((propagate_kernel<N, GL>), dim3(ga + gbk, n_problems), dim3(64), (SmemLayout<N, GL>::bytes(n_env)),
+  dim3 grid(ga + gbk, n_problems);
+  if (gate.wave_base) {
+    // compact mapping (G = 1): the kernel only runs while the round has fewer than gate.hi edges in total, so that many
+    // blocks are enough -- instead of (bound per problem) x problems blocks that find nothing when the gate is closed
+    const uint64_t all = uint64_t(ga + gbk) * n_problems;
+    grid = dim3(uint32_t(std::min<uint64_t>(all, gate.hi)), 1);
+  }
+  hipLaunchKernelGGL((propagate_kernel<N, GL>), grid, dim3(64), (SmemLayout<N, GL>::bytes(n_env)),
                      s, d_scene, d_pairs, n_pairs, dyn, io, io_b, tab_a, tab_b, ga, gate);
 }
 
