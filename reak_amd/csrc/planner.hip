@@ -323,6 +323,7 @@ struct Problem {  // host view of one planning problem
 struct rkh_planner {
   rkh_scene* scene = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // sample-stream uploads (beside the rounds enqueued on `stream`)
   bool quasi_static = false;  // false: steerable dynamic space (propagate kernel); true: manip_quasi_static_env (edge_check)
   double lower[RKH_MAX_STATE], upper[RKH_MAX_STATE];  // hyperbox the samples are drawn from
   DynDev dyn;
@@ -376,8 +377,8 @@ namespace {
 // Extend every problem's device-resident sample stream by `ahead` samples beyond its (last known) cursor.
 // hyperbox_topology::random_point (hyperbox_topology.hpp:97-103): D draws of uniform_01 per sample,
 // uniform_01<mt19937&,double> = eng() * 2^-32 (Boost.Random; one 32-bit draw per coordinate).
-// All copies are asynchronous on the planner stream out of one pinned staging buffer; the buffer's previous use is
-// awaited through its event, so no stream synchronisation happens here.
+// All copies are asynchronous on the planner's copy stream out of one pinned staging buffer; the buffer's previous use
+// is awaited through its event, so no stream synchronisation happens here.
 rkh_status upload_samples_all(rkh_planner* p, uint64_t ahead, int which) {
   rkh_planner::Staging& sg = p->staging[which];
   const int D = p->D;
@@ -420,13 +421,18 @@ rkh_status upload_samples_all(rkh_planner* p, uint64_t ahead, int which) {
         dst[k * D + d] = p->lower[d] + u * (p->upper[d] - p->lower[d]);
       }
     RKH_HIP(hipMemcpyAsync(q.d_samples + q.samples_ready * D, dst, cnt * D * sizeof(double), hipMemcpyHostToDevice,
-                           p->stream));
+                           p->copy_stream));
     q.samples_ready = upto[i];
     sg.h_sr[i] = uint32_t(upto[i]);
-    RKH_HIP(hipMemcpyAsync(&p->d_states[i].samples_ready, &sg.h_sr[i], sizeof(uint32_t), hipMemcpyHostToDevice, p->stream));
+    RKH_HIP(hipMemcpyAsync(&p->d_states[i].samples_ready, &sg.h_sr[i], sizeof(uint32_t), hipMemcpyHostToDevice,
+                           p->copy_stream));
     off += size_t(cnt) * D;
   }
-  RKH_HIP(hipEventRecord(sg.done, p->stream));
+  // The copies run on their own stream, beside the rounds already enqueued on the planner stream: they write beyond every
+  // problem's samples_ready (no round reads there) and then raise samples_ready (a round that sees the old value just
+  // takes a smaller batch).  Work enqueued on the planner stream from here on waits for them.
+  RKH_HIP(hipEventRecord(sg.done, p->copy_stream));
+  RKH_HIP(hipStreamWaitEvent(p->stream, sg.done, 0));
   sg.pending = true;
   return RKH_OK;
 }
@@ -628,6 +634,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     }
   RKH_HIP(hipSetDevice(scene->ctx->device));
   RKH_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  RKH_HIP(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
   if (const char* e = getenv("RKH_WAVE_FIT")) p->wave_fit = atoi(e);
   if (const char* e = getenv("RKH_WAVE_FILL")) p->wave_fill = atof(e);
   {
@@ -838,6 +845,8 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   (void)hipFree(p->d_nn_base);
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : p->ev_steer) (void)hipEventDestroy(e);
+  (void)hipStreamSynchronize(p->copy_stream);
+  (void)hipStreamDestroy(p->copy_stream);
   (void)hipStreamDestroy(p->stream);
   delete p;
   return RKH_OK;
