@@ -82,6 +82,13 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
                                                            uint32_t* __restrict__ nn_base, uint32_t nn_queries,
                                                            uint32_t* __restrict__ edge_base) {
   __shared__ unsigned int s_waves;
+  // per-problem inputs of the batch formula, cached once (the bisection below evaluates it ten times per problem) and the
+  // three count arrays, scanned in LDS; problems beyond the cache capacity fall back to global memory
+  constexpr uint32_t kCache = 1024;
+  __shared__ float s_bf[kCache], s_sq[kCache];
+  __shared__ uint32_t s_bmin[kCache], s_bcap[kCache], s_probe_waves[kCache];
+  __shared__ uint32_t s_scan[3][2 * kCache + 1];
+  const bool cached = P <= kCache;
   const uint32_t tid = threadIdx.x;
   auto batch_of = [&](const PlannerState* st, float sc) -> uint32_t {
     if (st->done) return 0u;
@@ -93,11 +100,35 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
     if (B > avail) B = avail;
     return B;
   };
+  if (cached) {
+    for (uint32_t i = tid; i < P; i += blockDim.x) {
+      const PlannerState* st = probs[i].st;
+      const bool done = st->done != 0u;
+      const uint32_t avail = st->samples_ready - st->s0;
+      s_bf[i] = st->batch_factor;
+      s_sq[i] = sqrtf(float(st->n));
+      s_bmin[i] = done ? 0u : st->b_min;
+      s_bcap[i] = done ? 0u : (st->b_max < avail ? st->b_max : avail);  // min(b_max, avail): the two upper clamps
+      s_probe_waves[i] = (st->n_new + 27u) / 28u;
+    }
+    __syncthreads();
+  }
+  auto batch_cached = [&](uint32_t i, float sc) -> uint32_t {  // same value as batch_of(probs[i].st, sc)
+    const float want = sc * s_bf[i] * s_sq[i];
+    uint32_t B = uint32_t(want);
+    if (B < s_bmin[i]) B = s_bmin[i];
+    if (B > s_bcap[i]) B = s_bcap[i];
+    return B;
+  };
   auto waves_at = [&](float sc) -> uint32_t {  // block-wide sum, same value in every thread
     uint32_t w = 0;
     for (uint32_t i = tid; i < P; i += blockDim.x) {
-      const PlannerState* st = probs[i].st;
-      w += (batch_of(st, sc) + 27u) / 28u + (st->n_new + 27u) / 28u;
+      if (cached) {
+        w += (batch_cached(i, sc) + 27u) / 28u + s_probe_waves[i];
+      } else {
+        const PlannerState* st = probs[i].st;
+        w += (batch_of(st, sc) + 27u) / 28u + (st->n_new + 27u) / 28u;
+      }
     }
     __syncthreads();
     if (tid == 0) s_waves = 0u;
@@ -137,40 +168,46 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
       st->edges_speculated += B;
     }
     edges += B + st->n_new;
-    if (wave_base) {  // working waves of the two segments of this problem (two-lanes steer kernel); scanned below
-      wave_base[2 * i + 1] = (B + 27u) / 28u;
-      wave_base[2 * i + 2] = (st->n_new + 27u) / 28u;
+    // counts of the three compact launch mappings (scanned below): 28-edge waves per (candidates | probes) segment of
+    // the two-lanes steer kernel, single edges per segment of the one-wave-per-edge kernel, query blocks of the NN sweep
+    uint32_t* wb = cached ? s_scan[0] : wave_base;
+    uint32_t* eb = cached ? s_scan[1] : edge_base;
+    uint32_t* nb = cached ? s_scan[2] : nn_base;
+    if (wave_base) {
+      wb[2 * i + 1] = (B + 27u) / 28u;
+      wb[2 * i + 2] = (st->n_new + 27u) / 28u;
     }
-    if (nn_base) nn_base[i + 1] = (B + nn_queries - 1u) / nn_queries;  // query blocks of the NN sweep; scanned below
-    if (edge_base) {  // edges per segment (one-wave-per-edge steer kernel of the small rounds); scanned below
-      edge_base[2 * i + 1] = B;
-      edge_base[2 * i + 2] = st->n_new;
+    if (nn_base) nb[i + 1] = (B + nn_queries - 1u) / nn_queries;
+    if (edge_base) {
+      eb[2 * i + 1] = B;
+      eb[2 * i + 2] = st->n_new;
     }
   }
   if (edges) atomicAdd(&sel[parity], edges);
   __syncthreads();
-  if (wave_base && tid == 0) {  // exclusive prefix in place: wave_base[s] = waves before segment s, wave_base[2 P] = total
-    uint32_t acc = 0;
-    wave_base[0] = 0;
-    for (uint32_t k = 1; k <= 2 * P; ++k) {
-      acc += wave_base[k];
-      wave_base[k] = acc;
-    }
-  }
-  if (edge_base && tid == 128) {
-    uint32_t acc = 0;
-    edge_base[0] = 0;
-    for (uint32_t k = 1; k <= 2 * P; ++k) {
-      acc += edge_base[k];
-      edge_base[k] = acc;
-    }
-  }
-  if (nn_base && tid == 64) {
-    uint32_t acc = 0;
-    nn_base[0] = 0;
-    for (uint32_t k = 1; k <= P; ++k) {
-      acc += nn_base[k];
-      nn_base[k] = acc;
+  // exclusive prefixes in place (entry 0 = 0, last entry = total), one wave each; in LDS when cached, then copied out
+  {
+    uint32_t* wb = cached ? s_scan[0] : wave_base;
+    uint32_t* eb = cached ? s_scan[1] : edge_base;
+    uint32_t* nb = cached ? s_scan[2] : nn_base;
+    auto scan = [](uint32_t* a, uint32_t n) {
+      uint32_t acc = 0;
+      a[0] = 0;
+      for (uint32_t k = 1; k <= n; ++k) {
+        acc += a[k];
+        a[k] = acc;
+      }
+    };
+    if (wave_base && tid == 0) scan(wb, 2 * P);
+    if (edge_base && tid == 128) scan(eb, 2 * P);
+    if (nn_base && tid == 64) scan(nb, P);
+    if (cached) {
+      __syncthreads();
+      for (uint32_t k = tid; k <= 2 * P; k += blockDim.x) {
+        if (wave_base) wave_base[k] = s_scan[0][k];
+        if (edge_base) edge_base[k] = s_scan[1][k];
+        if (nn_base && k <= P) nn_base[k] = s_scan[2][k];
+      }
     }
   }
 }
