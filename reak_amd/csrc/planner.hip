@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <random>
 
@@ -677,7 +678,8 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, scene->ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
-      p->wave_slots = uint32_t(prop.multiProcessorCount) * 4u;
+      p->wave_slots = uint32_t(prop.multiProcessorCount) * lane_kernel_waves_per_cu(scene->host.n_dof);
+    if (getenv("RKH_VERBOSE")) fprintf(stderr, "rkh planner: %d CUs, %u resident steer waves\n", prop.multiProcessorCount, p->wave_slots);
   }
   if (const char* e = getenv("RKH_BATCH_MAX")) p->b_max = std::max(8, atoi(e));
   p->b_max = std::min<uint32_t>(p->b_max, 4096);

@@ -753,5 +753,21 @@ rkh_status launch_propagate_lanes(hipStream_t s, int n_dof, const SceneDev* d_sc
   return RKH_OK;
 }
 
+// resident 28-edge waves per CU of the two-lanes kernel for this chain size (LDS-bound: 4 for six joints)
+uint32_t lane_kernel_waves_per_cu(int n_dof) {
+  int blocks = 0;
+  hipError_t e = hipErrorInvalidValue;
+  switch (n_dof) {
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, propagate_lane_kernel<1>, 64, 0); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, propagate_lane_kernel<2>, 64, 0); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, propagate_lane_kernel<3>, 64, 0); break;
+    case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, propagate_lane_kernel<4>, 64, 0); break;
+    case 6: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, propagate_lane_kernel<6>, 64, 0); break;
+    case 7: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, propagate_lane_kernel<7>, 64, 0); break;
+    default: break;
+  }
+  return (e == hipSuccess && blocks > 0) ? uint32_t(blocks) : 4u;
+}
+
 #undef RKH_LD
 }  // namespace rkh
