@@ -361,6 +361,8 @@ struct Problem {  // host view of one planning problem
 struct rkh_planner {
   rkh_scene* scene = nullptr;
   hipStream_t stream = nullptr;
+  double* h_gd = nullptr;     // pinned read-back buffer of the goal-probe results (rkh_planner_sync)
+  uint64_t h_gd_cap = 0;
   hipStream_t copy_stream = nullptr;  // sample-stream uploads (beside the rounds enqueued on `stream`)
   bool quasi_static = false;  // false: steerable dynamic space (propagate kernel); true: manip_quasi_static_env (edge_check)
   double lower[RKH_MAX_STATE], upper[RKH_MAX_STATE];  // hyperbox the samples are drawn from
@@ -886,6 +888,7 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   for (hipEvent_t e : p->ev_steer) (void)hipEventDestroy(e);
   (void)hipStreamSynchronize(p->copy_stream);
   (void)hipStreamDestroy(p->copy_stream);
+  if (p->h_gd) (void)hipHostFree(p->h_gd);
   (void)hipStreamDestroy(p->stream);
   delete p;
   return RKH_OK;
@@ -984,6 +987,33 @@ rkh_status rkh_planner_sync(rkh_planner* p, rkh_planner_stats* stats) {
     st = read_states(p);
     if (st != RKH_OK) return st;
   }
+  // goal-probe results since the last call, all problems: asynchronous copies into one pinned buffer, one wait
+  std::vector<uint64_t> gd_off(p->P, 0), gd_cnt(p->P, 0);
+  {
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < p->P; ++i) {
+      Problem& q = p->prob[i];
+      const uint64_t probed = q.h_state.probed_n < 1 ? 1 : q.h_state.probed_n;
+      if (!q.truncated && probed > 1 && q.goal_checked < probed - 1) {
+        gd_off[i] = total;
+        gd_cnt[i] = probed - 1 - q.goal_checked;
+        total += gd_cnt[i];
+      }
+    }
+    if (total > p->h_gd_cap) {
+      if (p->h_gd) (void)hipHostFree(p->h_gd);
+      p->h_gd = nullptr;
+      p->h_gd_cap = total + total / 2 + 1024;
+      RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->h_gd), p->h_gd_cap * sizeof(double), hipHostMallocDefault));
+    }
+    if (total) {
+      for (uint32_t i = 0; i < p->P; ++i)
+        if (gd_cnt[i])
+          RKH_HIP(hipMemcpyAsync(p->h_gd + gd_off[i], p->prob[i].d_goal_dist + p->prob[i].goal_checked,
+                                 gd_cnt[i] * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+      RKH_HIP(hipStreamSynchronize(p->stream));
+    }
+  }
   for (uint32_t i = 0; i < p->P; ++i) {
     Problem& q = p->prob[i];
     PlannerState& hs = q.h_state;
@@ -997,8 +1027,7 @@ rkh_status rkh_planner_sync(rkh_planner* p, rkh_planner_stats* stats) {
     const uint64_t probed = hs.probed_n < 1 ? 1 : hs.probed_n;  // vertices [1, probed) have a goal-probe result
     if (!q.truncated && probed > 1 && q.goal_checked < probed - 1) {
       const uint64_t first = q.goal_checked, cnt = probed - 1 - first;
-      std::vector<double> gd(cnt);
-      RKH_HIP(hipMemcpy(gd.data(), q.d_goal_dist + first, cnt * sizeof(double), hipMemcpyDeviceToHost));
+      const double* gd = p->h_gd + gd_off[i];
       std::vector<double> pos;
       std::vector<uint32_t> par;
       for (uint64_t k = 0; k < cnt; ++k) {
