@@ -328,10 +328,11 @@ def main():
                                                  "4 waves per CU, 1024 per GPU); waves packed in dispatch order over the 8 "
                                                  "XCDs, batch sizes fitted to whole passes of 1024 waves",
                                     "note": "f-eval operations only (proximity excluded); rank-0 launches of the timed region"}
-        if not args.no_microbench:
+        # the microbenchmarks and the CPU baselines are single-GPU extras: rank 0 at N = 1 only
+        if not args.no_microbench and world == 1:
             out["nn_sweep_hbm"] = nn_sweep_microbench(lib, ctx, events, 4 * 1024 * 1024, 8, 20)
             out["nn_sweep_mfma"] = nn_mfma_microbench(lib, ctx, events)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scn)
             nv_used = int(out["cpu_baseline"]["sample"].split("first ")[1].split(" ")[0])
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(nv_used)
