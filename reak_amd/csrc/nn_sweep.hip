@@ -498,7 +498,10 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
       float m = fminf(fminf(c[0], c[1]), fminf(c[2], c[3]));
 #pragma unroll
       for (int k = 1; k < 4; ++k) m = fminf(m, fminf(fminf(c[4 * k], c[4 * k + 1]), fminf(c[4 * k + 2], c[4 * k + 3])));
+      // running minimum of the query, over both lane halves: the pair then meets a new minimum as often as ONE sequence
+      // of twice the length would (ln 2 more often), not twice as often -- and every such event stalls the whole wave
       cmin = fminf(cmin, m);
+      cmin = fminf(cmin, __shfl_xor(cmin, 32, 64));
       const float lim = cmin + band;
       if (m <= lim) {  // a new minimum, or a row within the band of the old one
         if (cnt > kCandCap - 3) compact();
