@@ -321,7 +321,7 @@ typedef float rkh_f16v __attribute__((ext_vector_type(16)));
 typedef float rkh_f4v __attribute__((ext_vector_type(4)));
 static constexpr int kMfmaThreads = 256;
 static constexpr int kMfmaQueries = 128;  // 4 waves x 32 queries (8 waves x 32 per block measured 25 % slower)
-static constexpr int kCandCap = 8;        // per-lane candidate list (compacted, then resolved exactly, when it fills)
+static constexpr int kCandCap = 8;  // per-lane candidate list (compacted, then resolved exactly, when it fills)
 
 template <int DP>
 __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs single, const NnArgs* __restrict__ table,
@@ -495,9 +495,11 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
         const float aop = tileT[(2 * j + hi) * TS + 32 * g + col];
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bop[j], c, 0, 0, 0);
       }
-      float m = fminf(fminf(c[0], c[1]), fminf(c[2], c[3]));
+      // minima of the four 4-row groups, then of the slab
+      float gm[4];
 #pragma unroll
-      for (int k = 1; k < 4; ++k) m = fminf(m, fminf(fminf(c[4 * k], c[4 * k + 1]), fminf(c[4 * k + 2], c[4 * k + 3])));
+      for (int k = 0; k < 4; ++k) gm[k] = fminf(fminf(c[4 * k], c[4 * k + 1]), fminf(c[4 * k + 2], c[4 * k + 3]));
+      const float m = fminf(fminf(gm[0], gm[1]), fminf(gm[2], gm[3]));
       // running minimum of the query, over both lane halves: the pair then meets a new minimum as often as ONE sequence
       // of twice the length would (ln 2 more often), not twice as often -- and every such event stalls the whole wave
       cmin = fminf(cmin, m);
@@ -507,14 +509,20 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
         if (cnt > kCandCap - 3) compact();
         bool overflow = false;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (c[i] <= lim) {
-            if (cnt < kCandCap) {
-              cand_c[cnt][tid] = c[i];
-              cand_row[cnt][tid] = row_base + uint32_t(32 * g + 8 * (i >> 2) + 4 * hi + (i & 3));
-              ++cnt;
-            } else {
-              overflow = true;
+        for (int k = 0; k < 4; ++k) {
+          if (gm[k] <= lim) {  // usually one group, one row
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int i = 4 * k + j;
+              if (c[i] <= lim) {
+                if (cnt < kCandCap) {
+                  cand_c[cnt][tid] = c[i];
+                  cand_row[cnt][tid] = row_base + uint32_t(32 * g + 8 * (i >> 2) + 4 * hi + (i & 3));
+                  ++cnt;
+                } else {
+                  overflow = true;
+                }
+              }
             }
           }
         }
