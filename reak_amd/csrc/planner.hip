@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
                                                            uint32_t round_slot, uint32_t* __restrict__ sel, uint32_t parity,
                                                            float fit_fill, uint32_t slots, uint32_t* __restrict__ wave_base,
                                                            uint32_t* __restrict__ nn_base, uint32_t nn_queries,
-                                                           uint32_t* __restrict__ edge_base) {
+                                                           uint32_t* __restrict__ edge_base, uint32_t epw) {
   __shared__ unsigned int s_waves;
   // per-problem inputs of the batch formula, cached once (the bisection below evaluates it ten times per problem) and the
   // three count arrays, scanned in LDS; problems beyond the cache capacity fall back to global memory
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
       s_sq[i] = sqrtf(float(st->n));
       s_bmin[i] = done ? 0u : st->b_min;
       s_bcap[i] = done ? 0u : (st->b_max < avail ? st->b_max : avail);  // min(b_max, avail): the two upper clamps
-      s_probe_waves[i] = (st->n_new + 27u) / 28u;
+      s_probe_waves[i] = (st->n_new + epw - 1u) / epw;
     }
     __syncthreads();
   }
@@ -125,10 +125,10 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
     uint32_t w = 0;
     for (uint32_t i = tid; i < P; i += blockDim.x) {
       if (cached) {
-        w += (batch_cached(i, sc) + 27u) / 28u + s_probe_waves[i];
+        w += (batch_cached(i, sc) + epw - 1u) / epw + s_probe_waves[i];
       } else {
         const PlannerState* st = probs[i].st;
-        w += (batch_of(st, sc) + 27u) / 28u + (st->n_new + 27u) / 28u;
+        w += (batch_of(st, sc) + epw - 1u) / epw + (st->n_new + epw - 1u) / epw;
       }
     }
     __syncthreads();
@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
     uint32_t* eb = cached ? s_scan[1] : edge_base;
     uint32_t* nb = cached ? s_scan[2] : nn_base;
     if (wave_base) {
-      wb[2 * i + 1] = (B + 27u) / 28u;
-      wb[2 * i + 2] = (st->n_new + 27u) / 28u;
+      wb[2 * i + 1] = (B + epw - 1u) / epw;
+      wb[2 * i + 2] = (st->n_new + epw - 1u) / epw;
     }
     if (nn_base) nb[i + 1] = (B + nn_queries - 1u) / nn_queries;
     if (edge_base) {
@@ -569,7 +569,7 @@ rkh_status enqueue_round(rkh_planner* p) {
   p->round_parity ^= 1u;
   hipLaunchKernelGGL(round_begin_kernel, dim3(1), dim3(256), 0, s, p->d_probs, p->P, slot, p->d_sel, p->round_parity,
                      fit ? float(p->wave_fill) : 0.0f, p->wave_slots, p->d_wave_base, p->d_nn_base, nn1_mfma_queries(),
-                     p->d_wave_base ? p->d_wave_base + (2 * p->P + 1) : nullptr);
+                     p->d_wave_base ? p->d_wave_base + (2 * p->P + 1) : nullptr, lane_kernel_edges_per_wave());
   // 1. NN sweep of every problem's samples over its snapshot
   rkh_status st = launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, batch_ub, p->part_blocks, ev0, ev1,
                              p->coord_bound, p->d_nn_base);

@@ -65,7 +65,7 @@ RKH_DI m33 lane_axis_angle_rotmat(double ca, double sa, d3 ax) {  // axis_angle:
   return m33{t11, t12 - t03, t13 + t02, t12 + t03, t22, t23 - t01, t13 - t02, t23 + t01, t33};
 }
 
-constexpr int kEdgesPerWave = 28;  // 180 LDS slots x 28 edges x 8 B = 40 320 B: four waves per CU, one per SIMD
+constexpr int kEdgesPerWave = 29;  // six joints: 174 LDS slots x 29 edges x 8 B = 40 368 B: four waves per CU, one per SIMD
 
 // per-edge arrays in LDS, [slot][edge]
 template <int N>
@@ -78,8 +78,7 @@ struct LdsLayout {
     FT = 13 * N + N * N,  // inertia_3D d'Alembert force / torque per link
     XE = 19 * N + N * N,  // state being differentiated / tested
     C1S1 = 21 * N + N * N,  // cos, sin of the full joint angles
-    U = 23 * N + N * N,     // held input
-    SLOTS = 24 * N + N * N
+    SLOTS = 23 * N + N * N  // (the held input u lives in the global workspace: N slots less make room for a 29th edge)
   };
 };
 template <int N>
@@ -98,7 +97,8 @@ struct WsLayout {
     W = 4 * N,    // RK4: state at the start of the inner step
     KA = 6 * N,   // RK4: k1, then (1/6) k1 + (2/6) k2
     K3 = 8 * N,   // RK4: k3
-    SLOTS = 10 * N
+    U = 10 * N,   // held input of the step
+    SLOTS = 11 * N
   };
 };
 #define RKH_WS(slot) ws[(slot) * 64]
@@ -107,8 +107,8 @@ struct WsLayout {
 // are the qd components of x).  el = the edge's LDS column, h = which of the edge's two lanes this is.
 template <int N, bool DIAG = false>
 __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict__ sc, LaneLds<N>& lds, int el, int h,
-                                                      double (&qdd)[N], bool& singular,
-                                                      unsigned long long* stamps = nullptr) {
+                                                      double (&qdd)[N], bool& singular, const double* __restrict__ u_ptr,
+                                                      int u_stride, unsigned long long* stamps = nullptr) {
   typedef LdsLayout<N> L_;
   // diagnostic instantiation only (rkh_diag_feval_cycles): per-phase cycle counts
   unsigned long long t_prev = DIAG ? __builtin_readcyclecounter() : 0ull;
@@ -265,7 +265,7 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
       const double ta = dot(ET, axis);
       LF = mul(Ra, tmp_force);
       LT = mul(Ra, ET - ta * axis);
-      const double uj = RKH_LD(L_::U + j);  // inertia_gen::doForce (q_ddot = 0), driving_actuator_gen::doForce
+      const double uj = u_ptr[j * u_stride];  // inertia_gen::doForce (q_ddot = 0), driving_actuator_gen::doForce
       if (!h) RKH_LD(L_::T + j) = ta + uj;
       LT = LT - uj * axis;
     }
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64, 1) void propagate_lane_kernel(const SceneDev* _
                  dyn.kd * (RKH_WS(W_::B + 2 * j + 1) - RKH_WS(W_::X + 2 * j + 1));
       if (v > dyn.u_max) v = dyn.u_max;
       else if (v < -dyn.u_max) v = -dyn.u_max;
-      RKH_LD(L_::U + j) = v;
+      RKH_WS(W_::U + j) = v;
     }
     // runge_kutta4_integrate_impl (runge_kutta4_integrator_sys.hpp:53-97): the four useful f-evals per inner step as
     // the stages of a rolled loop (one copy of the dynamics in the instruction stream)
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(64, 1) void propagate_lane_kernel(const SceneDev* _
 #pragma unroll 1
     for (int ev = 0; ev < n_evals; ++ev) {
       double qdd[N];
-      lane_state_derivative<N>(sc, lds, el, h, qdd, sing_now);
+      lane_state_derivative<N>(sc, lds, el, h, qdd, sing_now, &RKH_WS(W_::U), 64);
       const int stage = ev & 3;
 #pragma unroll
       for (int j = 0; j < N; ++j) {
@@ -679,14 +679,13 @@ __global__ __launch_bounds__(64, 1) void lane_cycles_kernel(const SceneDev* __re
   uint32_t e = blockIdx.x * kEdgesPerWave + el;
   if (e >= B) e = blockIdx.x * kEdgesPerWave;
   for (int d = 0; d < 2 * N; ++d) RKH_LD(L_::XE + d) = x[uint64_t(e) * 2 * N + d];
-  for (int j = 0; j < N; ++j) RKH_LD(L_::U + j) = u[uint64_t(e) * N + j];
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool singular = false;
   double accv = 0.0;
   const unsigned long long t_begin = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     double qdd[N];
-    lane_state_derivative<N, true>(sc, lds, el, h, qdd, singular, st);
+    lane_state_derivative<N, true>(sc, lds, el, h, qdd, singular, u + uint64_t(e) * N, 1, st);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       accv += qdd[j];
@@ -716,7 +715,7 @@ rkh_status launch_lane_cycles(hipStream_t s, int n_dof, const SceneDev* d_scene,
 // bytes of workspace a launch of (edges_a + edges_b) edges per problem needs
 size_t propagate_lanes_workspace_bytes(int n_dof, uint32_t edges_a, uint32_t edges_b, uint32_t n_problems) {
   const size_t waves = size_t((edges_a + kEdgesPerWave - 1) / kEdgesPerWave + (edges_b + kEdgesPerWave - 1) / kEdgesPerWave) * n_problems;
-  return waves * size_t(10 * n_dof) * 64 * sizeof(double);
+  return waves * size_t(11 * n_dof) * 64 * sizeof(double);
 }
 
 template <int N>
@@ -753,7 +752,9 @@ rkh_status launch_propagate_lanes(hipStream_t s, int n_dof, const SceneDev* d_sc
   return RKH_OK;
 }
 
-// resident 28-edge waves per CU of the two-lanes kernel for this chain size (LDS-bound: 4 for six joints)
+uint32_t lane_kernel_edges_per_wave() { return uint32_t(kEdgesPerWave); }
+
+// resident waves per CU of the two-lanes kernel for this chain size (LDS-bound: 4 for six joints)
 uint32_t lane_kernel_waves_per_cu(int n_dof) {
   int blocks = 0;
   hipError_t e = hipErrorInvalidValue;

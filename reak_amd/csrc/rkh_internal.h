@@ -270,6 +270,7 @@ rkh_status launch_feval_cycles(hipStream_t s, int n_dof, int n_env, const SceneD
                                int n_pairs, const double* d_x, const double* d_u, uint32_t B, int iters,
                                unsigned long long* d_out, double* d_sink);
 uint32_t lane_kernel_waves_per_cu(int n_dof);
+uint32_t lane_kernel_edges_per_wave();
 rkh_status launch_lane_cycles(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, const double* d_u,
                               uint32_t B, int iters, unsigned long long* d_out, double* d_sink);
 rkh_status build_dyn_dev(const rkh_dyn_space& sp, double fraction, DynDev* out);
