@@ -65,7 +65,7 @@ RKH_DI m33 lane_axis_angle_rotmat(double ca, double sa, d3 ax) {  // axis_angle:
   return m33{t11, t12 - t03, t13 + t02, t12 + t03, t22, t23 - t01, t13 - t02, t23 + t01, t33};
 }
 
-constexpr int kEdgesPerWave = 29;  // six joints: 174 LDS slots x 29 edges x 8 B = 40 368 B: four waves per CU, one per SIMD
+constexpr int kEdgesPerWave = 31;  // six joints: 162 LDS slots x 31 edges x 8 B = 40 176 B: four waves per CU, one per SIMD
 
 // per-edge arrays in LDS, [slot][edge]
 template <int N>
@@ -77,8 +77,9 @@ struct LdsLayout {
     MF = 13 * N,        // Tcm^T (Mcm Tcm) before symmetrisation
     FT = 13 * N + N * N,  // inertia_3D d'Alembert force / torque per link
     XE = 19 * N + N * N,  // state being differentiated / tested
-    C1S1 = 21 * N + N * N,  // cos, sin of the full joint angles
-    SLOTS = 23 * N + N * N  // (the held input u lives in the global workspace: N slots less make room for a 29th edge)
+    // (the held input u and cos / sin of the full joint angles -- written once and read once per joint and f-eval --
+    // live in the wave's global workspace: 3 N slots less make room for 31 edges per wave instead of 28)
+    SLOTS = 21 * N + N * N
   };
 };
 template <int N>
@@ -98,7 +99,8 @@ struct WsLayout {
     KA = 6 * N,   // RK4: k1, then (1/6) k1 + (2/6) k2
     K3 = 8 * N,   // RK4: k3
     U = 10 * N,   // held input of the step
-    SLOTS = 11 * N
+    C1S1 = 11 * N,  // cos, sin of the full joint angles of the state being differentiated
+    SLOTS = 13 * N
   };
 };
 #define RKH_WS(slot) ws[(slot) * 64]
@@ -107,8 +109,9 @@ struct WsLayout {
 // are the qd components of x).  el = the edge's LDS column, h = which of the edge's two lanes this is.
 template <int N, bool DIAG = false>
 __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict__ sc, LaneLds<N>& lds, int el, int h,
-                                                      double (&qdd)[N], bool& singular, const double* __restrict__ u_ptr,
+                                                      double (&qdd)[N], bool& singular, double* __restrict__ u_ptr,
                                                       int u_stride, unsigned long long* stamps = nullptr) {
+  // u_ptr: this lane's column of the wave's global workspace from WsLayout::U on (u[N], then cos / sin[2 N])
   typedef LdsLayout<N> L_;
   // diagnostic instantiation only (rkh_diag_feval_cycles): per-phase cycle counts
   unsigned long long t_prev = DIAG ? __builtin_readcyclecounter() : 0ull;
@@ -138,10 +141,9 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
     double sn, cs;
     sincos(h ? q : 0.5 * q, &sn, &cs);
     const double c2 = __shfl(cs, el, 64), s2 = __shfl(sn, el, 64);
-    if (h) {
-      RKH_LD(L_::C1S1 + 2 * j) = cs;
-      RKH_LD(L_::C1S1 + 2 * j + 1) = sn;
-    }
+    // every lane keeps its own copy of the full-angle pair (no cross-lane traffic through memory)
+    u_ptr[(N + 2 * j) * u_stride] = __shfl(cs, el + 32, 64);
+    u_ptr[(N + 2 * j + 1) * u_stride] = __shfl(sn, el + 32, 64);
     // revolute_joint_3D::doMotion (revolute_joint.cpp:121-148)
     const d4 tq = d4{c2, axis_n.x * s2, axis_n.y * s2, axis_n.z * s2};
     const m33 R2 = rotmat(tq);
@@ -260,7 +262,7 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
       const d3 op = ldg3(J.off_pos);
       const d3 tmp_force = mul(Ro, LF);
       const d3 ET = mul(Ro, LT) + cross(op, tmp_force);
-      const m33 Ra = lane_axis_angle_rotmat(RKH_LD(L_::C1S1 + 2 * j), RKH_LD(L_::C1S1 + 2 * j + 1),
+      const m33 Ra = lane_axis_angle_rotmat(u_ptr[(N + 2 * j) * u_stride], u_ptr[(N + 2 * j + 1) * u_stride],
                                             ldg3(J.axis_n));  // revolute_joint_3D::doForce (revolute_joint.cpp:170-181)
       const double ta = dot(ET, axis);
       LF = mul(Ra, tmp_force);
@@ -669,7 +671,7 @@ template <int N>
 __global__ __launch_bounds__(64, 1) void lane_cycles_kernel(const SceneDev* __restrict__ sc, const double* __restrict__ x,
                                                              const double* __restrict__ u, uint32_t B, int iters,
                                                              unsigned long long* __restrict__ out,
-                                                             double* __restrict__ sink_out) {
+                                                             double* __restrict__ sink_out, double* __restrict__ ws_all) {
   __shared__ LaneLds<N> lds;
   if (threadIdx.x < 3 * N) lds.axis[threadIdx.x / 3][threadIdx.x % 3] = sc->joints[threadIdx.x / 3].axis[threadIdx.x % 3];
   __syncthreads();
@@ -679,13 +681,15 @@ __global__ __launch_bounds__(64, 1) void lane_cycles_kernel(const SceneDev* __re
   uint32_t e = blockIdx.x * kEdgesPerWave + el;
   if (e >= B) e = blockIdx.x * kEdgesPerWave;
   for (int d = 0; d < 2 * N; ++d) RKH_LD(L_::XE + d) = x[uint64_t(e) * 2 * N + d];
+  double* ws_u = ws_all + uint64_t(blockIdx.x) * uint64_t(3 * N * 64) + lane;  // u[N], cos / sin[2 N] of this lane
+  for (int j = 0; j < N; ++j) ws_u[j * 64] = u[uint64_t(e) * N + j];
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool singular = false;
   double accv = 0.0;
   const unsigned long long t_begin = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     double qdd[N];
-    lane_state_derivative<N, true>(sc, lds, el, h, qdd, singular, u + uint64_t(e) * N, 1, st);
+    lane_state_derivative<N, true>(sc, lds, el, h, qdd, singular, ws_u, 64, st);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       accv += qdd[j];
@@ -703,19 +707,23 @@ __global__ __launch_bounds__(64, 1) void lane_cycles_kernel(const SceneDev* __re
 rkh_status launch_lane_cycles(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, const double* d_u,
                               uint32_t B, int iters, unsigned long long* d_out, double* d_sink) {
   const uint32_t waves = (B + kEdgesPerWave - 1) / kEdgesPerWave;
+  double* d_ws = nullptr;  // per wave: u[N] + cos / sin[2 N] per lane (the kernels' global workspace slots)
+  RKH_HIP(hipMalloc(&d_ws, size_t(waves) * 3 * n_dof * 64 * sizeof(double)));
   switch (n_dof) {
-    case 6: hipLaunchKernelGGL((lane_cycles_kernel<6>), dim3(waves), dim3(64), 0, s, d_scene, d_x, d_u, B, iters, d_out, d_sink); break;
-    case 3: hipLaunchKernelGGL((lane_cycles_kernel<3>), dim3(waves), dim3(64), 0, s, d_scene, d_x, d_u, B, iters, d_out, d_sink); break;
-    default: set_error("lane diagnostics: instantiated for 3 and 6 joints"); return RKH_ERR_UNSUPPORTED;
+    case 6: hipLaunchKernelGGL((lane_cycles_kernel<6>), dim3(waves), dim3(64), 0, s, d_scene, d_x, d_u, B, iters, d_out, d_sink, d_ws); break;
+    case 3: hipLaunchKernelGGL((lane_cycles_kernel<3>), dim3(waves), dim3(64), 0, s, d_scene, d_x, d_u, B, iters, d_out, d_sink, d_ws); break;
+    default: (void)hipFree(d_ws); set_error("lane diagnostics: instantiated for 3 and 6 joints"); return RKH_ERR_UNSUPPORTED;
   }
   RKH_HIP(hipGetLastError());
+  RKH_HIP(hipStreamSynchronize(s));  // diagnostic entry point: the scratch is released right away
+  (void)hipFree(d_ws);
   return RKH_OK;
 }
 
 // bytes of workspace a launch of (edges_a + edges_b) edges per problem needs
 size_t propagate_lanes_workspace_bytes(int n_dof, uint32_t edges_a, uint32_t edges_b, uint32_t n_problems) {
   const size_t waves = size_t((edges_a + kEdgesPerWave - 1) / kEdgesPerWave + (edges_b + kEdgesPerWave - 1) / kEdgesPerWave) * n_problems;
-  return waves * size_t(11 * n_dof) * 64 * sizeof(double);
+  return waves * size_t(13 * n_dof) * 64 * sizeof(double);
 }
 
 template <int N>

@@ -7,8 +7,8 @@ from reak_amd import lib, scenarios
 ctx = lib.Context(0); scn = scenarios.make_c2(1); sc = lib.Scene(ctx, scn)
 rng = np.random.default_rng(0)
 names = ["frames", "jac", "M", "bwd", "chol", "pFK", "pCull", "pExact"]
-for B in (28, 28 * 1024, 28 * 4096):
+for B in (31, 31 * 1024, 31 * 4096):
     x = rng.uniform(-1, 1, size=(B, 12)); u = rng.uniform(-10, 10, size=(B, 6))
     c = sc.diag_feval_cycles(x, u, iters=20).astype(np.float64) / 20
-    c = c[: B // 28]
-    print("waves=%d" % (B // 28), " ".join("%s=%.0f" % (n, v) for n, v in zip(names, np.median(c, axis=0))), flush=True)
+    c = c[: B // 31]
+    print("waves=%d" % (B // 31), " ".join("%s=%.0f" % (n, v) for n, v in zip(names, np.median(c, axis=0))), flush=True)
