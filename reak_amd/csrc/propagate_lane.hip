@@ -1,4 +1,4 @@
-// propagate_lane.hip -- the throughput mapping of the steer kernel: TWO LANES PER CANDIDATE EDGE, 28 edges per wave
+// propagate_lane.hip -- the throughput mapping of the steer kernel: TWO LANES PER CANDIDATE EDGE, 31 edges per wave
 // (gfx950, wave64).
 //
 // Same function as propagate_kernel (propagate.hip; reference citations there): RK4 forward dynamics of the KTE
@@ -18,8 +18,9 @@
 //     sincos in the instruction stream, ~25 KB in total);
 //   * every array those loops index at run time lives in LDS, [slot][edge]: joint end frames E[7N], the current body's
 //     Jacobian columns T[6N], the mass matrix Mf[N*N] (read-modify-written once per body), link forces FT[6N], the
-//     state being differentiated XE[2N], full-angle cos/sin[2N], the held input u[N]: 180 slots x 28 edges x 8 B =
-//     40 320 B per wave = the CU's 160 KB at one wave per SIMD (that is what fixes 28 edges, two lanes each);
+//     state being differentiated XE[2N]: 162 slots x 31 edges x 8 B = 40 176 B per wave = the CU's 160 KB at one wave
+//     per SIMD (that is what fixes 31 edges, two lanes each); full-angle cos/sin[2N] and the held input u[N] sit in the
+//     wave's global workspace (written and read once per joint and f-eval);
 //   * registers hold the sweep recurrences and the Cholesky factor only; the RK4 stage vectors, touched once per
 //     f-eval with independent loads, are in a global workspace [slot][lane];
 //   * the mass matrix is accumulated body by body while the forward sweep runs (Mf(i,j) receives its terms in the same
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(64, 1) void propagate_lane_kernel(const SceneDev* _
 }
 #undef RKH_WS
 
-// Diagnostic kernel (not on the product path): `iters` back-to-back f-evals + proximity tests of 28 states per wave
+// Diagnostic kernel (not on the product path): `iters` back-to-back f-evals + proximity tests of kEdgesPerWave states per wave
 // with cycle counts per phase: [frames + sincos, jacobian columns, mass matrix, force sweep, cholesky,
 // proximity: joint frames, cull, exact routines]
 template <int N>

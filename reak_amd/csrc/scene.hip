@@ -538,7 +538,7 @@ rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double
   RKH_HIP(hipMemcpyAsync(du.p, u, size_t(B) * n * 8, hipMemcpyHostToDevice, s));
   rkh_status st;
   const char* ev = getenv("RKH_LANES_PER_EDGE");
-  if (ev && atoi(ev) == 1) {  // two-lanes-per-edge kernel: one record of 8 counters per wave of 28 states
+  if (ev && atoi(ev) == 1) {  // two-lanes-per-edge kernel: one record of 8 counters per wave of states
     RKH_HIP(hipMemsetAsync(dout.p, 0, size_t(B) * 8 * 8, s));
     st = launch_lane_cycles(s, n, scene->d_scene, dx.as<double>(), du.as<double>(), B, iters,
                             dout.as<unsigned long long>(), dsink.as<double>());
