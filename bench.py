@@ -324,7 +324,7 @@ def main():
                                     "avg_round_ms": tot["steer_ms"] / max(1, tot["steer_launches"]),
                                     "edges_per_s_in_kernel": tot["spec"] / (tot["steer_ms"] * 1e-3),
                                     "achieved": rate, "peak": 39.3, "unit": "Tops/s (fp64, no FMA)", "frac": rate / 39.3,
-                                    "occupancy": "propagate_lane_kernel: one 31-edge wave per SIMD (40.3 KB LDS per wave, "
+                                    "occupancy": "propagate_lane_kernel: one 32-edge wave per SIMD (40.8 KB LDS per wave, "
                                                  "4 waves per CU, 1024 per GPU); waves packed in dispatch order over the 8 "
                                                  "XCDs, batch sizes fitted to whole passes of 1024 waves",
                                     "note": "f-eval operations only (proximity excluded); rank-0 launches of the timed region"}

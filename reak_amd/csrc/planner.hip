@@ -74,7 +74,7 @@ struct ProblemDev {  // device pointers of one problem
 constexpr uint32_t kProfRounds = 8192;  // profiled rounds per planner (RKH_PROFILE_NN)
 // One block for all problems.  Batch sizes: B = scale * batch_factor * sqrt(n) (results do not depend on them).  With
 // fit_fill > 0 the scale of the round is chosen here, from the exact counts: the two-lanes steer kernel runs one wave of
-// 31 edges per SIMD (`slots` waves at a time), so the steer time of a round is its number of waves divided by `slots`,
+// 32 edges per SIMD (`slots` waves at a time), so the steer time of a round is its number of waves divided by `slots`,
 // rounded UP; the scale (0.75 .. 1.4) is bisected so that the round's waves -- candidates plus the pending goal probes
 // of every problem -- fill fit_fill of a whole number of such passes.
 __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __restrict__ probs, uint32_t P,
@@ -503,7 +503,7 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
                             p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lanes_per_edge, tab_a, tab_b,
                             p->P, p->d_lane_ws);
   // automatic: both mappings are launched; on the device each compares the round's edge count with the threshold and
-  // the one that is not chosen exits at once.  Small rounds -> one wave per edge (latency), large -> 31 edges per wave.
+  // the one that is not chosen exits at once.  Small rounds -> one wave per edge (latency), large -> 32 edges per wave.
   KernelGate gate_wave{p->d_sel + p->round_parity, 0u, p->lane_threshold};
   KernelGate gate_lane{p->d_sel + p->round_parity, p->lane_threshold, 0xFFFFFFFFu};
   if (compact && p->d_wave_base) {  // a regular round: (candidates, probes) segments as round_begin_kernel counted them

@@ -1,4 +1,4 @@
-// propagate_lane.hip -- the throughput mapping of the steer kernel: TWO LANES PER CANDIDATE EDGE, 31 edges per wave
+// propagate_lane.hip -- the throughput mapping of the steer kernel: TWO LANES PER CANDIDATE EDGE, 32 edges per wave
 // (gfx950, wave64).
 //
 // Same function as propagate_kernel (propagate.hip; reference citations there): RK4 forward dynamics of the KTE
@@ -18,9 +18,10 @@
 //     sincos in the instruction stream, ~25 KB in total);
 //   * every array those loops index at run time lives in LDS, [slot][edge]: joint end frames E[7N], the current body's
 //     Jacobian columns T[6N], the mass matrix Mf[N*N] (read-modify-written once per body), link forces FT[6N], the
-//     state being differentiated XE[2N]: 162 slots x 31 edges x 8 B = 40 176 B per wave = the CU's 160 KB at one wave
-//     per SIMD (that is what fixes 31 edges, two lanes each); full-angle cos/sin[2N] and the held input u[N] sit in the
-//     wave's global workspace (written and read once per joint and f-eval);
+//     state being differentiated XE[2N]: 159 slots (joint 0's position is the chain base, not stored) x 32 edges x 8 B
+//     = 40 704 B per wave = the CU's 160 KB at one wave per SIMD (32 edges, two lanes each: every lane in use);
+//     full-angle cos/sin[2N] and the held input u[N] sit in the wave's global workspace (written and read once per
+//     joint and f-eval);
 //   * registers hold the sweep recurrences and the Cholesky factor only; the RK4 stage vectors, touched once per
 //     f-eval with independent loads, are in a global workspace [slot][lane];
 //   * the mass matrix is accumulated body by body while the forward sweep runs (Mf(i,j) receives its terms in the same
@@ -66,21 +67,22 @@ RKH_DI m33 lane_axis_angle_rotmat(double ca, double sa, d3 ax) {  // axis_angle:
   return m33{t11, t12 - t03, t13 + t02, t12 + t03, t22, t23 - t01, t13 - t02, t23 + t01, t33};
 }
 
-constexpr int kEdgesPerWave = 31;  // six joints: 162 LDS slots x 31 edges x 8 B = 40 176 B: four waves per CU, one per SIMD
+constexpr int kEdgesPerWave = 32;  // six joints: 159 LDS slots x 32 edges x 8 B = 40 704 B: four waves per CU, one per SIMD
 
 // per-edge arrays in LDS, [slot][edge]
 template <int N>
 struct LdsLayout {
   enum : int {
-    ECP = 0,            // joint end frames: position
-    ECQ = 3 * N,        //                   quaternion
-    T = 7 * N,          // Jacobian columns (v, w) of the current body; afterwards the generalized forces f[N]
-    MF = 13 * N,        // Tcm^T (Mcm Tcm) before symmetrisation
-    FT = 13 * N + N * N,  // inertia_3D d'Alembert force / torque per link
-    XE = 19 * N + N * N,  // state being differentiated / tested
+    ECP = 0,            // joint end frames: position of joints 1 .. N-1 (joint 0 sits at the chain base: a constant)
+    ECQ = 3 * N - 3,    //                   quaternion
+    T = 7 * N - 3,      // Jacobian columns (v, w) of the current body; afterwards the generalized forces f[N]
+    MF = 13 * N - 3,    // Tcm^T (Mcm Tcm) before symmetrisation
+    FT = 13 * N - 3 + N * N,  // inertia_3D d'Alembert force / torque per link
+    XE = 19 * N - 3 + N * N,  // state being differentiated / tested
     // (the held input u and cos / sin of the full joint angles -- written once and read once per joint and f-eval --
-    // live in the wave's global workspace: 3 N slots less make room for 31 edges per wave instead of 28)
-    SLOTS = 21 * N + N * N
+    // live in the wave's global workspace, and joint 0's position is not stored: 3 N + 3 slots less than everything in
+    // LDS make room for 32 edges per wave -- every lane of the wave -- instead of 28)
+    SLOTS = 21 * N - 3 + N * N
   };
 };
 template <int N>
@@ -130,6 +132,7 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
 
   // ---- base -> tip sweep (kte_map_chain::doMotion) with the Jacobian columns and M terms of each body
   d3 pos = ldg3(sc->base_pos);
+  const d3 base_pos0 = pos;  // = joint 0's end-frame position (not kept in LDS)
   d4 Q = ldg4(sc->base_quat);
   d3 w = mk3(0, 0, 0), alpha = mk3(0, 0, 0);
   d3 acc = ldg3(sc->base_acc);
@@ -154,7 +157,9 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
     const d3 Ew = wb + qa;
     const d3 Ealpha = mulT(alpha, R2) + cross(wb, qa);
     if (!h) {
-      RKH_LD(L_::ECP + 3 * j) = pos.x; RKH_LD(L_::ECP + 3 * j + 1) = pos.y; RKH_LD(L_::ECP + 3 * j + 2) = pos.z;
+      if (j > 0) {  // joint 0's end frame sits at the chain base
+        RKH_LD(L_::ECP + 3 * j - 3) = pos.x; RKH_LD(L_::ECP + 3 * j - 2) = pos.y; RKH_LD(L_::ECP + 3 * j - 1) = pos.z;
+      }
       RKH_LD(L_::ECQ + 4 * j) = EQ.w; RKH_LD(L_::ECQ + 4 * j + 1) = EQ.x;
       RKH_LD(L_::ECQ + 4 * j + 2) = EQ.y; RKH_LD(L_::ECQ + 4 * j + 3) = EQ.z;
     }
@@ -185,7 +190,9 @@ __device__ __forceinline__ void lane_state_derivative(const SceneDev* __restrict
       for (int r = 0; r < 2; ++r) {
         const int cr = ct - 2 * r;
         const int c = cr >= 0 ? cr : 0;
-        const d3 cp = mk3(RKH_LD(L_::ECP + 3 * c), RKH_LD(L_::ECP + 3 * c + 1), RKH_LD(L_::ECP + 3 * c + 2));
+        const int cs3 = c > 0 ? 3 * c - 3 : 0;
+        d3 cp = mk3(RKH_LD(L_::ECP + cs3), RKH_LD(L_::ECP + cs3 + 1), RKH_LD(L_::ECP + cs3 + 2));
+        if (c == 0) cp = base_pos0;  // joint 0: the chain base
         const d4 cq = d4{RKH_LD(L_::ECQ + 4 * c), RKH_LD(L_::ECQ + 4 * c + 1), RKH_LD(L_::ECQ + 4 * c + 2),
                          RKH_LD(L_::ECQ + 4 * c + 3)};
         const m33 Rc = rotmat(cq);
@@ -364,7 +371,9 @@ __device__ __forceinline__ bool lane_proximity_free(const SceneDev* __restrict__
       const d4 tq = d4{c2, axis_n.x * s2, axis_n.y * s2, axis_n.z * s2};
       const d4 EQ = qmul(Q, tq);
       if (!h) {
-        RKH_LD(L_::ECP + 3 * j) = pos.x; RKH_LD(L_::ECP + 3 * j + 1) = pos.y; RKH_LD(L_::ECP + 3 * j + 2) = pos.z;
+        if (j > 0) {
+          RKH_LD(L_::ECP + 3 * j - 3) = pos.x; RKH_LD(L_::ECP + 3 * j - 2) = pos.y; RKH_LD(L_::ECP + 3 * j - 1) = pos.z;
+        }
         RKH_LD(L_::ECQ + 4 * j) = EQ.w; RKH_LD(L_::ECQ + 4 * j + 1) = EQ.x;
         RKH_LD(L_::ECQ + 4 * j + 2) = EQ.y; RKH_LD(L_::ECQ + 4 * j + 3) = EQ.z;
       }
@@ -383,7 +392,9 @@ __device__ __forceinline__ bool lane_proximity_free(const SceneDev* __restrict__
     nxt = load_robot(r0 + 2);
     // robot shape -> global pose (pose_3D::getGlobalPose, pose_3D.hpp:102-110)
     const int j = sh.link;
-    const d3 Epos = mk3(RKH_LD(L_::ECP + 3 * j), RKH_LD(L_::ECP + 3 * j + 1), RKH_LD(L_::ECP + 3 * j + 2));
+    const int js3 = j > 0 ? 3 * j - 3 : 0;
+    d3 Epos = mk3(RKH_LD(L_::ECP + js3), RKH_LD(L_::ECP + js3 + 1), RKH_LD(L_::ECP + js3 + 2));
+    if (j == 0) Epos = ldg3(sc->base_pos);
     const d4 EQ = d4{RKH_LD(L_::ECQ + 4 * j), RKH_LD(L_::ECQ + 4 * j + 1), RKH_LD(L_::ECQ + 4 * j + 2),
                      RKH_LD(L_::ECQ + 4 * j + 3)};
     ShapeG A;
