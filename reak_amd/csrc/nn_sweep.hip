@@ -403,8 +403,8 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
       const double df = qq[0] - p[0];
       s = df * df;
     }
-#pragma unroll 1
-    for (int d = 1; d < DP; ++d) {
+#pragma unroll 3
+    for (int d = 1; d < DP; ++d) {  // (a few coordinates per memory round trip; fully unrolled it spills into the sweep)
       const double df = (d < D ? qq[d] : 0.0) - p[d];
       s = s + df * df;
     }
