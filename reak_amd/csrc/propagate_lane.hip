@@ -460,6 +460,30 @@ __device__ __forceinline__ bool lane_proximity_free(const SceneDev* __restrict__
 #pragma unroll 1
       for (int kind = 0; kind < 3; ++kind) {
         unsigned long long m = mask & (kind == 0 ? k_sphere : (kind == 1 ? k_box : k_ccyl));
+        if (kind == 1 && a_ccyl) {
+          // capped cylinder against a box = a golden-section search along the axis (prox_fundamentals_3D.cpp:108-115,
+          // ~7 k cycles that hold the whole wave while any lane runs one).  Every value that search can return is the
+          // distance of SOME point of the axis segment to the box, so a lower bound over the segment that already
+          // exceeds the radius settles the verdict "no collision" without it: separation along the box's own axes,
+          // |c_k| - hl |t_k| - half_k, in the box frame (fp64, margin 1e-9).  First pass: drop those pairs.
+          unsigned long long keep = 0ull, mm = m;
+          while (__any(mm != 0ull)) {
+            if (mm != 0ull) {
+              const int i = __builtin_ctzll(mm);
+              mm &= mm - 1ull;
+              const ShapeDev& es = sc->env[o0 + i];
+              const d4 bq = qinv(ldg4(es.quat));
+              const d3 crel = qrot(bq, ca - ldg3(es.pos));
+              const d3 trel = qrot(bq, a_ax);
+              const double hl = 0.5 * A.d0;
+              const double gx = fabs(crel.x) - fabs(trel.x) * hl - 0.5 * es.dims[0];
+              const double gy = fabs(crel.y) - fabs(trel.y) * hl - 0.5 * es.dims[1];
+              const double gz = fabs(crel.z) - fabs(trel.z) * hl - 0.5 * es.dims[2];
+              if (!(fmax(gx, fmax(gy, gz)) > A.d1 + 1e-9)) keep |= 1ull << i;
+            }
+          }
+          m = keep;
+        }
         while (__any(m != 0ull)) {
           if (m != 0ull) {
             const int i = __builtin_ctzll(m);
