@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --pmc $2 --output-format csv -d /tmp/pmc_$1 -o $1 -- python $ROOT/bench.py --steps 1 --warmup 0 --problems 128 --max-vertices 6000 --no-cpu-baseline --no-microbench > $OUT/$1_pmc.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc $2 --output-format csv -d /tmp/pmc_$1 -o $1 -- python $ROOT/bench.py --steps 1 --warmup 0 --problems ${PMC_PROBLEMS:-128} --max-vertices ${PMC_VERTICES:-6000} --no-cpu-baseline --no-microbench > $OUT/$1_pmc.log 2>&1
 echo "rc=$?"
 F=$(find /tmp/pmc_$1 -name "*counter_collection.csv" < /dev/null | head -1)
 if [ -n "$F" ]; then
