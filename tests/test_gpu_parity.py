@@ -851,3 +851,23 @@ def test_batch_scale_fit_and_wave_packing_do_not_change_results(L, ctx, oracle, 
     t = trees["1"][1]
     assert (t[0], t[1]) == (ro.num_vertices, ro.iterations)
     assert np.array_equal(t[2]["parent"], rt["parent"]) and np.array_equal(t[2]["accept"], rt["accept"])
+
+
+def test_planner_pool_splits_a_batch_without_changing_results(L, ctx, oracle, c2):
+    """RrtPlannerPool (problems split over planner handles = HIP streams, enqueued round-robin) returns, per global
+    problem index, what one handle with all problems returns."""
+    prms = [c2.rrt_params(seed=300 + i, max_vertices=600) for i in range(7)]
+    sc = L.Scene(ctx, c2)
+    one = L.RrtPlanner(sc, prms)
+    one.solve_planning_query()
+    pool = L.RrtPlannerPool(sc, prms, groups=3)
+    pool.solve_planning_query()
+    assert pool.done and len(pool.all_stats) == 7
+    for i in range(7):
+        a, b = one.tree(i), pool.tree(i)
+        assert int(one.all_stats[i].num_vertices) == int(pool.all_stats[i].num_vertices)
+        for k in ("parent", "nn_seq", "accept", "pos"):
+            assert np.array_equal(a[k], b[k]), (i, k)
+        assert one.solution(i)[1] == pool.solution(i)[1]
+    pool.close()
+    one.close()
