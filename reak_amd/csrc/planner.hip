@@ -372,7 +372,8 @@ struct rkh_planner {
   uint32_t P = 0;
   std::vector<Problem> prob;
   uint32_t b_max = 1024;
-  int lanes_per_edge = 64;  // 64: one wavefront per candidate edge; 16: four candidates per wave; 1: one lane per edge
+  int lanes_per_edge = 64;  // 64: one wavefront per candidate edge; 16: four candidates per wave; 1 / 2: two lanes per edge
+  int lane_variant = 2;     // throughput mapping of the automatic mode: 2 = propagate_pair.hip, 1 = propagate_lane.hip
   double* d_lane_ws = nullptr;  // workspace of the two-lanes-per-edge kernel
   double coord_bound = 0.0;     // max |coordinate| of vertices and samples (hyperbox bounds), 0 = unknown
   uint32_t* d_sel = nullptr;    // [2] edges of the current round (by round parity), see round_begin_kernel
@@ -517,7 +518,7 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
                                    nullptr, gate_wave);
   if (st != RKH_OK) return st;
   return launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                          p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, 1, tab_a, tab_b, p->P,
+                          p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b, p->P,
                           p->d_lane_ws, gate_lane);
 }
 
@@ -675,19 +676,21 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   RKH_HIP(hipSetDevice(scene->ctx->device));
   RKH_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   RKH_HIP(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+  if (const char* e = getenv("RKH_LANE_VARIANT")) p->lane_variant = (atoi(e) == 1) ? 1 : 2;
   if (const char* e = getenv("RKH_WAVE_FIT")) p->wave_fit = atoi(e);
   if (const char* e = getenv("RKH_WAVE_FILL")) p->wave_fill = atof(e);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, scene->ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
-      p->wave_slots = uint32_t(prop.multiProcessorCount) * lane_kernel_waves_per_cu(scene->host.n_dof);
+      p->wave_slots = uint32_t(prop.multiProcessorCount) * (p->lane_variant == 2 ? pair_kernel_waves_per_cu(scene->host.n_dof)
+                                                                                 : lane_kernel_waves_per_cu(scene->host.n_dof));
     if (getenv("RKH_VERBOSE")) fprintf(stderr, "rkh planner: %d CUs, %u resident steer waves\n", prop.multiProcessorCount, p->wave_slots);
   }
   if (const char* e = getenv("RKH_BATCH_MAX")) p->b_max = std::max(8, atoi(e));
   p->b_max = std::min<uint32_t>(p->b_max, 4096);
   if (const char* e = getenv("RKH_LANE_THRESHOLD")) p->lane_threshold = uint32_t(std::max(0, atoi(e)));
   if (const char* e = getenv("RKH_LANES_PER_EDGE")) {
-    p->lanes_per_edge = (atoi(e) == 1) ? 1 : ((atoi(e) == 16) ? 16 : (atoi(e) == 0 ? 0 : 64));
+    p->lanes_per_edge = (atoi(e) == 1) ? 1 : ((atoi(e) == 2) ? 2 : ((atoi(e) == 16) ? 16 : (atoi(e) == 0 ? 0 : 64)));
   } else if (p->n_dof <= 6 && scene_fits_lane_kernel(scene->host)) {
     p->lanes_per_edge = 0;  // automatic, per round
   } else {
@@ -695,7 +698,8 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     // has slots (256 CUs x 4 SIMDs x 2 waves) four candidates share a wave
     p->lanes_per_edge = (uint64_t(n_problems) * 2 * p->b_max > 4096) ? 16 : 64;
   }
-  if ((p->lanes_per_edge == 1 || p->lanes_per_edge == 0) && !(p->n_dof <= 7 && scene_fits_lane_kernel(scene->host)))
+  if ((p->lanes_per_edge == 1 || p->lanes_per_edge == 2 || p->lanes_per_edge == 0) &&
+      !(p->n_dof <= 7 && scene_fits_lane_kernel(scene->host)))
     p->lanes_per_edge = 64;  // the two-lanes-per-edge kernel does not take this scene
   if (p->lanes_per_edge == 16 && 2 * p->n_dof > 16) p->lanes_per_edge = 64;  // a 16-lane group holds at most 16 components
   if (const char* e = getenv("RKH_PROFILE_NN")) p->profile_nn = atoi(e) != 0;
@@ -712,8 +716,9 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   RKH_HIP(hipMalloc(&p->d_nn_args, P * sizeof(NnArgs)));
   RKH_HIP(hipMalloc(&p->d_io_steer, P * sizeof(EdgeIO)));
   RKH_HIP(hipMalloc(&p->d_io_probe, P * sizeof(EdgeIO)));
-  if (!p->quasi_static && (p->lanes_per_edge == 1 || p->lanes_per_edge == 0))
-    RKH_HIP(hipMalloc(&p->d_lane_ws, propagate_lanes_workspace_bytes(p->n_dof, p->b_max, p->b_max, P)));
+  if (!p->quasi_static && (p->lanes_per_edge == 1 || p->lanes_per_edge == 2 || p->lanes_per_edge == 0))
+    RKH_HIP(hipMalloc(&p->d_lane_ws, std::max(propagate_lanes_workspace_bytes(p->n_dof, p->b_max, p->b_max, P),
+                                              propagate_pairs_workspace_bytes(p->n_dof, p->b_max, p->b_max, P))));
   if (p->d_lane_ws) {
     // two prefix arrays of 2 P + 1 entries: waves of the two-lanes kernel, then single edges (one-wave-per-edge kernel)
     RKH_HIP(hipMalloc(&p->d_wave_base, 2 * (2 * size_t(P) + 1) * sizeof(uint32_t)));

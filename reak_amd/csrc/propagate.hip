@@ -1105,8 +1105,11 @@ rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev*
                             uint32_t n_problems, double* d_lane_ws, KernelGate gate) {
   const uint32_t eb = (io_b || tab_b) ? grid_b : 0u;
   if (grid_edges + eb == 0 || n_problems == 0) return RKH_OK;
-  if (lanes_per_edge == 1)  // one lane per edge (propagate_lane.hip)
+  if (lanes_per_edge == 1)  // two lanes per edge, first generation (propagate_lane.hip)
     return launch_propagate_lanes(s, n_dof, d_scene, dyn, io, grid_edges, io_b, grid_b, tab_a, tab_b, n_problems, d_lane_ws,
+                                  gate);
+  if (lanes_per_edge == 2)  // two lanes per edge, two waves per SIMD (propagate_pair.hip)
+    return launch_propagate_pairs(s, n_dof, d_scene, dyn, io, grid_edges, io_b, grid_b, tab_a, tab_b, n_problems, d_lane_ws,
                                   gate);
   const EdgeIO second = io_b ? *io_b : EdgeIO();
   const PairDev* pp = static_cast<const PairDev*>(d_pairs);

@@ -271,6 +271,16 @@ rkh_status launch_feval_cycles(hipStream_t s, int n_dof, int n_env, const SceneD
                                unsigned long long* d_out, double* d_sink);
 uint32_t lane_kernel_waves_per_cu(int n_dof);
 uint32_t lane_kernel_edges_per_wave();
+// second-generation two-lanes-per-edge kernel (propagate_pair.hip): registers + DPP instead of LDS, two waves per SIMD.
+// Same edges per wave, same scenes (scene_fits_lane_kernel), same results.
+size_t propagate_pairs_workspace_bytes(int n_dof, uint32_t edges_a, uint32_t edges_b, uint32_t n_problems);
+rkh_status launch_propagate_pairs(hipStream_t s, int n_dof, const SceneDev* d_scene, const DynDev& dyn, const EdgeIO& io,
+                                  uint32_t grid_edges, const EdgeIO* io_b, uint32_t grid_b, const EdgeIO* tab_a,
+                                  const EdgeIO* tab_b, uint32_t n_problems, double* d_ws, KernelGate gate = KernelGate());
+uint32_t pair_kernel_waves_per_cu(int n_dof);
+uint32_t pair_kernel_edges_per_wave();
+rkh_status launch_pair_cycles(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, const double* d_u,
+                              uint32_t B, int iters, unsigned long long* d_out, double* d_sink);
 rkh_status launch_lane_cycles(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, const double* d_u,
                               uint32_t B, int iters, unsigned long long* d_out, double* d_sink);
 rkh_status build_dyn_dev(const rkh_dyn_space& sp, double fraction, DynDev* out);

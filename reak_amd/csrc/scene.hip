@@ -507,12 +507,14 @@ rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const dou
   io.record = record ? drec.as<double>() : nullptr;
   io.record_stride = rec_stride;
   io.err_flag = scene->d_err;
-  int lanes = 64;  // RKH_LANES_PER_EDGE = 64 | 16 | 1 selects the kernel mapping (identical results)
-  if (const char* ev = getenv("RKH_LANES_PER_EDGE")) lanes = (atoi(ev) == 1) ? 1 : (atoi(ev) == 16 ? 16 : 64);
-  if (lanes == 1 && !(n <= 7 && scene_fits_lane_kernel(scene->host))) lanes = 64;  // not a scene for that mapping
+  int lanes = 64;  // RKH_LANES_PER_EDGE = 64 | 16 | 2 | 1 selects the kernel mapping (identical results)
+  if (const char* ev = getenv("RKH_LANES_PER_EDGE"))
+    lanes = (atoi(ev) == 1) ? 1 : (atoi(ev) == 2 ? 2 : (atoi(ev) == 16 ? 16 : 64));
+  if ((lanes == 1 || lanes == 2) && !(n <= 7 && scene_fits_lane_kernel(scene->host))) lanes = 64;  // not a scene for that mapping
   if (lanes == 16 && 2 * n > 16) lanes = 64;
   DevBuf dws;
   if (lanes == 1) RKH_HIP(hipMalloc(&dws.p, propagate_lanes_workspace_bytes(n, B, 0, 1)));
+  if (lanes == 2) RKH_HIP(hipMalloc(&dws.p, propagate_pairs_workspace_bytes(n, B, 0, 1)));
   st = launch_propagate(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, dyn, io, B, nullptr, 0,
                         lanes, nullptr, nullptr, 1, dws.as<double>());
   if (st != RKH_OK) return st;
@@ -541,6 +543,10 @@ rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double
   if (ev && atoi(ev) == 1) {  // two-lanes-per-edge kernel: one record of 8 counters per wave of states
     RKH_HIP(hipMemsetAsync(dout.p, 0, size_t(B) * 8 * 8, s));
     st = launch_lane_cycles(s, n, scene->d_scene, dx.as<double>(), du.as<double>(), B, iters,
+                            dout.as<unsigned long long>(), dsink.as<double>());
+  } else if (ev && atoi(ev) == 2) {  // its second generation
+    RKH_HIP(hipMemsetAsync(dout.p, 0, size_t(B) * 8 * 8, s));
+    st = launch_pair_cycles(s, n, scene->d_scene, dx.as<double>(), du.as<double>(), B, iters,
                             dout.as<unsigned long long>(), dsink.as<double>());
   } else {
     st = launch_feval_cycles(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, dx.as<double>(),

@@ -415,10 +415,10 @@ def test_propagate_mappings_are_bit_identical(L, ctx, oracle, c2, monkeypatch):
     a = a[osc.min_distance(a) > 0.01][:200]   # not a multiple of 64: the last wave is ragged
     b = rng.uniform(lo, hi, size=(a.shape[0], 12))
     res = {}
-    for lanes in ("64", "16", "1"):
+    for lanes in ("64", "16", "1", "2"):
         monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
         res[lanes] = sc.steer_position_toward(a, b, record=True)
-    for lanes in ("16", "1"):
+    for lanes in ("16", "1", "2"):
         assert np.array_equal(res[lanes][1], res["64"][1])
         assert np.array_equal(res[lanes][0], res["64"][0])
         assert np.array_equal(res[lanes][2], res["64"][2], equal_nan=True)
@@ -427,8 +427,10 @@ def test_propagate_mappings_are_bit_identical(L, ctx, oracle, c2, monkeypatch):
     assert res["1"][1].min() < 20 <= res["1"][1].max()
 
 
-def test_rrt_tree_with_one_lane_per_edge(L, ctx, oracle, c2, monkeypatch):
-    monkeypatch.setenv("RKH_LANES_PER_EDGE", "1")
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_rrt_tree_with_one_lane_per_edge(L, ctx, oracle, c2, monkeypatch, lanes):
+    """Every round through one of the two-lanes-per-edge kernels (1: LDS-resident, 2: registers + DPP, two waves / SIMD)."""
+    monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
     sc, osc = L.Scene(ctx, c2), oracle.OracleScene(c2)
     prm = c2.rrt_params(seed=2, max_vertices=1500)
     rc, rout, rtree = osc.rrt_dyn(prm)
@@ -465,10 +467,11 @@ def test_flexible_beam_dynamics_and_planner(L, ctx, oracle, monkeypatch):
     a = a[osc.min_distance(a) > 0.01][:60]
     b = rng.uniform(lo, hi, size=(a.shape[0], 12))
     res = {}
-    for lanes in ("64", "1"):
+    for lanes in ("64", "1", "2"):
         monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
         res[lanes] = sc.steer_position_toward(a, b)
     assert np.array_equal(res["1"][0], res["64"][0]) and np.array_equal(res["1"][1], res["64"][1])
+    assert np.array_equal(res["2"][0], res["64"][0]) and np.array_equal(res["2"][1], res["64"][1])
     rc, rout, rsteps, _ = osc.steer(a, b)
     assert np.array_equal(res["64"][1], rsteps) and np.allclose(res["64"][0], rout, rtol=1e-9, atol=1e-10)
     monkeypatch.delenv("RKH_LANES_PER_EDGE")
@@ -508,7 +511,7 @@ def test_steer_kernels_ragged_wave_sizes(L, ctx, oracle, c2, monkeypatch):
     b = rng.uniform(lo, hi, size=(a.shape[0], 12))
     for B in (1, 27, 28, 29, 57):
         rc, rout, rsteps, _ = osc.steer(a[:B], b[:B])
-        for lanes in ("64", "1"):
+        for lanes in ("64", "1", "2"):
             monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
             out, steps, _ = sc.steer_position_toward(a[:B], b[:B])
             assert np.array_equal(steps, rsteps) and np.allclose(out, rout, rtol=STATE_RTOL, atol=1e-12)
@@ -656,10 +659,11 @@ def test_random_chains_of_other_sizes(L, ctx, oracle, n, monkeypatch):
     a = x[osc.min_distance(x) > 0.01][:40]
     b = rng.uniform(lo, hi, size=(a.shape[0], 2 * n))
     res = {}
-    for lanes in ("64", "1"):
+    for lanes in ("64", "1", "2"):
         monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
         res[lanes] = sc.steer_position_toward(a, b)
     assert np.array_equal(res["1"][0], res["64"][0]) and np.array_equal(res["1"][1], res["64"][1])
+    assert np.array_equal(res["2"][0], res["64"][0]) and np.array_equal(res["2"][1], res["64"][1])
     rc, rout, rsteps, _ = osc.steer(a, b)
     assert np.array_equal(res["64"][1], rsteps) and np.allclose(res["64"][0], rout, rtol=1e-9, atol=1e-10)
     monkeypatch.delenv("RKH_LANES_PER_EDGE")
