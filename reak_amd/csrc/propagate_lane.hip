@@ -511,8 +511,11 @@ __device__ __forceinline__ bool lane_proximity_free(const SceneDev* __restrict__
         }
       }
     }
-    // what the edge's other lane found counts for both
-    hit = hit || (__shfl_xor(hit ? 1 : 0, 32, 64) != 0);
+    // What the edge's other lane found counts for both.  The exchange is its own statement: inside `hit || shfl(..)` it
+    // would run only on the lanes that have not hit, and a cross-lane read of a lane that is switched off returns 0
+    // (the second lane's collisions went unnoticed unless the first lane's shape collided too).
+    const int other_hit = __shfl_xor(hit ? 1 : 0, 32, 64);
+    hit = hit || (other_hit != 0);
     RKH_STAMP(7)
   }
   return !(hit && active);

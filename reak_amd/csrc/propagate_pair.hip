@@ -557,8 +557,10 @@ __device__ __forceinline__ bool pair_proximity_free(ScenePtr sc_in, PairLds<N>& 
         }
       }
     }
-    // what the edge's other lane found counts for both
-    hit = hit || (xchg_i(hit ? 1 : 0) != 0);
+    // What the edge's other lane found counts for both.  The exchange is its own statement: inside `hit || xchg(..)` it
+    // would run only on the lanes that have not hit, and a cross-lane read of a lane that is switched off returns 0.
+    const int other_hit = xchg_i(hit ? 1 : 0);
+    hit = hit || (other_hit != 0);
     RKH_STAMP(7)
   }
   return !(hit && active);

@@ -52,6 +52,31 @@ def build():
 _libs = {}
 
 
+def feval_op_count(scn, x, u):
+    """Exact fp64 operation counts of ONE x' = f(x, u) evaluation by the restated reference (oracle/flop_count.cpp):
+    dict with add / mul / div / sqrt / trig / cmp, the structure-aware add_useful / mul_useful, and the totals
+    `all` (every operation the reference's dense code performs) and `useful` (without its products over structural zeros)."""
+    path = os.path.join(_ORACLE_DIR, "liboracle_flops.so")
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    lib.oracle_feval_op_count.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_uint64)]
+    ops = scn.ops_array()
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    u = np.ascontiguousarray(u, dtype=np.float64).ravel()
+    cnt = (C.c_uint64 * 8)()
+    rc = lib.oracle_feval_op_count(C.cast(ops, C.c_void_p), len(scn.ops), C.cast(C.byref(scn.base), C.c_void_p),
+                                   T.dptr(x), T.dptr(u), cnt)
+    if rc != 0:
+        raise RuntimeError("oracle_feval_op_count: singular mass matrix")
+    names = ["add", "mul", "div", "sqrt", "trig", "cmp", "add_useful", "mul_useful"]
+    r = dict(zip(names, [int(v) for v in cnt]))
+    r["all"] = r["add"] + r["mul"] + r["div"] + r["sqrt"] + r["trig"]
+    r["useful"] = r["add_useful"] + r["mul_useful"] + r["div"] + r["sqrt"] + r["trig"]
+    return r
+
+
 def load(fast=False):
     name = "liboracle_fast.so" if fast else "liboracle.so"
     if name in _libs:

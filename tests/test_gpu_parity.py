@@ -427,6 +427,55 @@ def test_propagate_mappings_are_bit_identical(L, ctx, oracle, c2, monkeypatch):
     assert res["1"][1].min() < 20 <= res["1"][1].max()
 
 
+def test_every_robot_shape_is_tested_by_every_mapping(L, ctx, oracle, c2, monkeypatch):
+    """An obstacle sitting ON link k must stop the edge at once, whichever lane of the edge's pair tests that link's
+    shape (the two-lanes kernels split the robot shapes between the edge's lanes; round 1 lost the second lane's
+    verdict in a short-circuited cross-lane exchange).  Obstacle kinds: sphere, box, capped cylinder."""
+    import copy
+    osc = oracle.OracleScene(c2)
+    rng = np.random.default_rng(3)
+    lo = np.array([c2.dyn.lower[i] for i in range(12)])
+    hi = np.array([c2.dyn.upper[i] for i in range(12)])
+    x = rng.uniform(lo, hi, size=(1, 12)) * 0.5
+    t = rng.uniform(lo, hi, size=(1, 12))
+    robot = [s for s in c2.shapes if s.anchor >= 0]
+    fr = osc.fk(x)[0]
+    for k in (2, 3, 4, 5):
+        p = fr[2 * k + 1][:3]  # joint k's end frame = the base of link k's capsule
+        for kind, dims in ((T.SHAPE_SPHERE, [0.08, 0, 0]), (T.SHAPE_BOX, [0.15, 0.2, 0.1]), (T.SHAPE_CCYLINDER, [0.2, 0.05, 0])):
+            ob = T.Shape(kind=kind, anchor=-1)
+            ob.pose = T.make_pose(tuple(p), (1.0, 0.0, 0.0, 0.0))
+            ob.dims[:] = dims
+            for order in ([0, k], [k, 0], [0, 1, 2, 3, 4, 5]):
+                s2 = copy.copy(c2)
+                s2.shapes = [robot[i] for i in order] + [ob]
+                sc, o2 = L.Scene(ctx, s2), oracle.OracleScene(s2)
+                rc, rout, rsteps, _ = o2.steer(x, t)
+                assert rsteps[0] == 0
+                for lanes in ("64", "16", "1", "2"):
+                    monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
+                    assert sc.steer_position_toward(x, t)[1][0] == 0, (k, kind, order, lanes)
+
+
+def test_steer_from_colliding_and_free_starts_matches_oracle(L, ctx, oracle, c2, monkeypatch):
+    """Unfiltered random start states (some already inside an obstacle): free-step counts of every mapping against the
+    oracle, states within tolerance."""
+    sc, osc = L.Scene(ctx, c2), oracle.OracleScene(c2)
+    rng = np.random.default_rng(0)
+    lo = np.array([c2.dyn.lower[i] for i in range(12)])
+    hi = np.array([c2.dyn.upper[i] for i in range(12)])
+    B = 1536
+    a = rng.uniform(lo, hi, size=(B, 12)) * 0.6
+    b = rng.uniform(lo, hi, size=(B, 12))
+    rc, rout, rsteps, _ = osc.steer(a, b)
+    assert (rsteps == 0).sum() > 20 and (rsteps == 20).sum() > 500
+    for lanes in ("64", "1", "2"):
+        monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
+        out, steps, _ = sc.steer_position_toward(a, b)
+        assert np.array_equal(steps, rsteps), lanes
+        assert np.allclose(out, rout, rtol=STATE_RTOL, atol=1e-12), lanes
+
+
 @pytest.mark.parametrize("lanes", ["1", "2"])
 def test_rrt_tree_with_one_lane_per_edge(L, ctx, oracle, c2, monkeypatch, lanes):
     """Every round through one of the two-lanes-per-edge kernels (1: LDS-resident, 2: registers + DPP, two waves / SIMD)."""
