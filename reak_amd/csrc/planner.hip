@@ -311,6 +311,38 @@ __global__ __launch_bounds__(256) void commit_kernel(const ProblemDev* __restric
 }
 
 // after a probe-only flush launch: nothing is pending any more
+// One contiguous host->device copy carries the new stretch of every problem's sample stream; block b moves segment b to
+// its place behind the problem's samples and only then raises the problem's samples_ready (a round that still sees the
+// old value just takes a smaller batch).  Replaces two small copies per problem and call.
+struct SampleSeg {
+  double* dst;
+  uint64_t src_off;      // doubles into the staging buffer
+  uint64_t count;        // doubles (a multiple of D)
+  uint32_t* ready_ptr;   // &PlannerState::samples_ready of the problem
+  uint32_t ready_new;
+  uint32_t pad;
+};
+__global__ __launch_bounds__(256) void scatter_samples_kernel(const SampleSeg* __restrict__ tab,
+                                                               const double* __restrict__ stage) {
+  const SampleSeg sg = tab[blockIdx.x];
+  const double* __restrict__ src = stage + sg.src_off;
+  for (uint64_t i = threadIdx.x; i < sg.count; i += 256) sg.dst[i] = src[i];
+  __threadfence();  // the samples are visible device-wide before the count says so
+  __syncthreads();
+  if (threadIdx.x == 0) *sg.ready_ptr = sg.ready_new;
+}
+
+// Goal-probe results since the last sync: block b copies problem b's new stretch into one buffer (one device->host copy
+// for all problems instead of one per problem).
+struct GoalSeg {
+  const double* src;
+  uint64_t dst_off, count;
+};
+__global__ __launch_bounds__(256) void gather_goal_dist_kernel(const GoalSeg* __restrict__ tab, double* __restrict__ out) {
+  const GoalSeg g = tab[blockIdx.x];
+  for (uint64_t i = threadIdx.x; i < g.count; i += 256) out[g.dst_off + i] = g.src[i];
+}
+
 __global__ void probes_flushed_kernel(const ProblemDev* __restrict__ probs) {
   if (threadIdx.x != 0) return;
   PlannerState* st = probs[blockIdx.x].st;
@@ -399,12 +431,18 @@ struct rkh_planner {
   // pinned staging for the sample stream: [0] what the enqueued rounds need, [1] the next call's share, generated and
   // copied while the GPU works on the rounds just enqueued
   struct Staging {
-    double* h = nullptr;
-    uint32_t* h_sr = nullptr;
+    double* h = nullptr;        // pinned: the new samples of all problems, back to back
+    double* d = nullptr;        // the same on the device, before scatter_samples_kernel
+    SampleSeg* h_tab = nullptr; // pinned segment table [P]
+    SampleSeg* d_tab = nullptr;
     size_t cap = 0;
     hipEvent_t done = nullptr;
     bool pending = false;
   } staging[2];
+  GoalSeg* h_gd_tab = nullptr;  // pinned [P]
+  GoalSeg* d_gd_tab = nullptr;
+  double* d_gd = nullptr;       // gathered goal-probe results (rkh_planner_sync)
+  uint64_t d_gd_cap = 0;
   // optional HIP-event timing of the NN sweep kernel (RKH_PROFILE_NN=1)
   bool profile_nn = false;
   std::vector<hipEvent_t> ev;  // pairs
@@ -440,14 +478,21 @@ rkh_status upload_samples_all(rkh_planner* p, uint64_t ahead, int which) {
     sg.pending = false;
   }
   if (!sg.done) RKH_HIP(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
-  if (!sg.h_sr) RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&sg.h_sr), p->P * sizeof(uint32_t), hipHostMallocDefault));
+  if (!sg.h_tab) {
+    RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&sg.h_tab), p->P * sizeof(SampleSeg), hipHostMallocDefault));
+    RKH_HIP(hipMalloc(&sg.d_tab, p->P * sizeof(SampleSeg)));
+  }
   if (total > sg.cap) {
     if (sg.h) (void)hipHostFree(sg.h);
+    if (sg.d) (void)hipFree(sg.d);
     sg.h = nullptr;
+    sg.d = nullptr;
     sg.cap = total + total / 4;
     RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&sg.h), sg.cap * sizeof(double), hipHostMallocDefault));
+    RKH_HIP(hipMalloc(&sg.d, sg.cap * sizeof(double)));
   }
   size_t off = 0;
+  uint32_t n_seg = 0;
   for (uint32_t i = 0; i < p->P; ++i) {
     if (!upto[i]) continue;
     Problem& q = p->prob[i];
@@ -461,14 +506,20 @@ rkh_status upload_samples_all(rkh_planner* p, uint64_t ahead, int which) {
         } while (!(u < 1.0));
         dst[k * D + d] = p->lower[d] + u * (p->upper[d] - p->lower[d]);
       }
-    RKH_HIP(hipMemcpyAsync(q.d_samples + q.samples_ready * D, dst, cnt * D * sizeof(double), hipMemcpyHostToDevice,
-                           p->copy_stream));
+    SampleSeg& seg = sg.h_tab[n_seg++];
+    seg.dst = q.d_samples + q.samples_ready * D;
+    seg.src_off = off;
+    seg.count = cnt * D;
+    seg.ready_ptr = &p->d_states[i].samples_ready;
+    seg.ready_new = uint32_t(upto[i]);
+    seg.pad = 0;
     q.samples_ready = upto[i];
-    sg.h_sr[i] = uint32_t(upto[i]);
-    RKH_HIP(hipMemcpyAsync(&p->d_states[i].samples_ready, &sg.h_sr[i], sizeof(uint32_t), hipMemcpyHostToDevice,
-                           p->copy_stream));
     off += size_t(cnt) * D;
   }
+  RKH_HIP(hipMemcpyAsync(sg.d, sg.h, off * sizeof(double), hipMemcpyHostToDevice, p->copy_stream));
+  RKH_HIP(hipMemcpyAsync(sg.d_tab, sg.h_tab, n_seg * sizeof(SampleSeg), hipMemcpyHostToDevice, p->copy_stream));
+  hipLaunchKernelGGL(scatter_samples_kernel, dim3(n_seg), dim3(256), 0, p->copy_stream, sg.d_tab, sg.d);
+  RKH_HIP(hipGetLastError());
   // The copies run on their own stream, beside the rounds already enqueued on the planner stream: they write beyond every
   // problem's samples_ready (no round reads there) and then raise samples_ready (a round that sees the old value just
   // takes a smaller batch).  Work enqueued on the planner stream from here on waits for them.
@@ -882,7 +933,9 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   for (auto& sg : p->staging) {
     if (sg.pending) (void)hipEventSynchronize(sg.done);
     if (sg.h) (void)hipHostFree(sg.h);
-    if (sg.h_sr) (void)hipHostFree(sg.h_sr);
+    if (sg.d) (void)hipFree(sg.d);
+    if (sg.h_tab) (void)hipHostFree(sg.h_tab);
+    if (sg.d_tab) (void)hipFree(sg.d_tab);
     if (sg.done) (void)hipEventDestroy(sg.done);
   }
   (void)hipFree(p->d_lane_ws);
@@ -894,6 +947,9 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   (void)hipStreamSynchronize(p->copy_stream);
   (void)hipStreamDestroy(p->copy_stream);
   if (p->h_gd) (void)hipHostFree(p->h_gd);
+  if (p->h_gd_tab) (void)hipHostFree(p->h_gd_tab);
+  if (p->d_gd_tab) (void)hipFree(p->d_gd_tab);
+  if (p->d_gd) (void)hipFree(p->d_gd);
   (void)hipStreamDestroy(p->stream);
   delete p;
   return RKH_OK;
@@ -1012,10 +1068,28 @@ rkh_status rkh_planner_sync(rkh_planner* p, rkh_planner_stats* stats) {
       RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->h_gd), p->h_gd_cap * sizeof(double), hipHostMallocDefault));
     }
     if (total) {
+      if (!p->h_gd_tab) {
+        RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->h_gd_tab), p->P * sizeof(GoalSeg), hipHostMallocDefault));
+        RKH_HIP(hipMalloc(&p->d_gd_tab, p->P * sizeof(GoalSeg)));
+      }
+      if (total > p->d_gd_cap) {
+        if (p->d_gd) (void)hipFree(p->d_gd);
+        p->d_gd = nullptr;
+        p->d_gd_cap = total + total / 2 + 1024;
+        RKH_HIP(hipMalloc(&p->d_gd, p->d_gd_cap * sizeof(double)));
+      }
+      uint32_t n_seg = 0;
       for (uint32_t i = 0; i < p->P; ++i)
-        if (gd_cnt[i])
-          RKH_HIP(hipMemcpyAsync(p->h_gd + gd_off[i], p->prob[i].d_goal_dist + p->prob[i].goal_checked,
-                                 gd_cnt[i] * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        if (gd_cnt[i]) {
+          GoalSeg& g = p->h_gd_tab[n_seg++];
+          g.src = p->prob[i].d_goal_dist + p->prob[i].goal_checked;
+          g.dst_off = gd_off[i];
+          g.count = gd_cnt[i];
+        }
+      RKH_HIP(hipMemcpyAsync(p->d_gd_tab, p->h_gd_tab, n_seg * sizeof(GoalSeg), hipMemcpyHostToDevice, p->stream));
+      hipLaunchKernelGGL(gather_goal_dist_kernel, dim3(n_seg), dim3(256), 0, p->stream, p->d_gd_tab, p->d_gd);
+      RKH_HIP(hipGetLastError());
+      RKH_HIP(hipMemcpyAsync(p->h_gd, p->d_gd, total * sizeof(double), hipMemcpyDeviceToHost, p->stream));
       RKH_HIP(hipStreamSynchronize(p->stream));
     }
   }

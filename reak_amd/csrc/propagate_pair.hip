@@ -91,6 +91,8 @@ template <int N>
 struct PairLds {
   double v[PairLayout<N>::SLOTS][kPairEdges];
   double axis[N + 1][3];  // revolute_joint_3D::mAxis of every joint (indexed per lane: column 2r + h); one spare row
+  // proximity test: queues of surviving (edge, robot shape, obstacle) pairs, their fill counts, one verdict per edge
+  uint32_t q1[128], q2[64], qn[2], hit[kPairEdges];
 };
 #define RKH_LD(slot) lds.v[(slot)][el]
 
@@ -379,12 +381,126 @@ __device__ __forceinline__ void pair_state_derivative(ScenePtr sc_in, PairLds<N>
 #undef RKH_STAMP
 }
 
+// ---- proximity test: work queues in LDS --------------------------------------------------------------------------
+// The bounding cull runs per lane (lane h of an edge takes the robot shapes r0 + h); what survives it is NOT evaluated
+// by the lane that found it but pushed, as (edge, robot shape, obstacle), into a queue in LDS and handed out one entry
+// per lane: a wave spends one pass of the closed forms per 64 surviving pairs instead of one pass per pair of its
+// unluckiest lane.  Pairs that need the golden-section search of findProximityBoxToLine (capped cylinder against box)
+// go through a second queue, so the ~1.5 k instructions of a search are spent by full lanes only.
+constexpr int kQ1Cap = 128, kQ2Cap = 64;
+constexpr uint32_t kQEmpty = 0xFFFFFFFFu;
+RKH_DI uint32_t q_pack(int el, int r, int o) { return (uint32_t(el) << 16) | (uint32_t(r) << 8) | uint32_t(o); }
+
+// global pose of robot shape r of the edge in LDS column e (pose_3D::getGlobalPose, pose_3D.hpp:102-110)
+template <int N>
+RKH_DI ShapeG pair_robot_pose(ScenePtr sc, PairLds<N>& lds, int e, int r) {
+  typedef PairLayout<N> L_;
+  const auto& sh = sc->robot[r];
+  const int j = sh.link;
+  const int js3 = j > 0 ? 3 * j - 3 : 0;
+  d3 Epos = mk3(lds.v[L_::ECP + js3][e], lds.v[L_::ECP + js3 + 1][e], lds.v[L_::ECP + js3 + 2][e]);
+  if (j == 0) Epos = ldg3(sc->base_pos);
+  const d4 EQ = d4{lds.v[L_::ECQ + 4 * j][e], lds.v[L_::ECQ + 4 * j + 1][e], lds.v[L_::ECQ + 4 * j + 2][e],
+                   lds.v[L_::ECQ + 4 * j + 3][e]};
+  ShapeG A;
+  A.kind = sh.kind;
+  A.pos = Epos + qrot(EQ, ldg3(sh.pos));
+  A.q = qmul(EQ, ldg4(sh.quat));
+  A.d0 = sh.dims[0]; A.d1 = sh.dims[1]; A.d2 = sh.dims[2];
+  return A;
+}
+template <class EnvRef>
+RKH_DI ShapeG pair_env_shape(const EnvRef& es) {
+  ShapeG Bv;
+  Bv.kind = es.kind;
+  Bv.pos = ldg3(es.pos);
+  Bv.q = ldg4(es.quat);
+  Bv.d0 = es.dims[0]; Bv.d1 = es.dims[1]; Bv.d2 = es.dims[2];
+  return Bv;
+}
+
+// golden-section pairs of the second queue (all lanes of the wave call this together)
+template <int N>
+RKH_DI void pair_drain_q2(ScenePtr sc, PairLds<N>& lds) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t n2 = lds.qn[1] < uint32_t(kQ2Cap) ? lds.qn[1] : uint32_t(kQ2Cap);
+  if (n2 == 0) return;  // uniform
+  const uint32_t ent = (uint32_t(lane) < n2) ? lds.q2[lane] : kQEmpty;
+  if (ent != kQEmpty) {
+    const int e = int(ent >> 16), r = int((ent >> 8) & 0xFFu), o = int(ent & 0xFFu);
+    if (lds.hit[e] == 0u) {
+      const ShapeG A = pair_robot_pose<N>(sc, lds, e, r);
+      const ShapeG Bv = pair_env_shape(sc->env[o]);
+      const double d = (A.kind == RKH_SHAPE_CCYLINDER) ? dist_ccyl_box(A, Bv) : dist_ccyl_box(Bv, A);
+      if (d < 0.0) lds.hit[e] = 1u;
+    }
+  }
+  if (lane == 0) lds.qn[1] = 0u;
+}
+
+// the first queue: closed forms, and the separating-axis screen in front of the golden-section pairs
+template <int N>
+RKH_DI void pair_drain_q1(ScenePtr sc, PairLds<N>& lds) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t n1 = lds.qn[0] < uint32_t(kQ1Cap) ? lds.qn[0] : uint32_t(kQ1Cap);
+#pragma unroll 1
+  for (uint32_t k0 = 0; k0 < n1; k0 += 64u) {
+    const uint32_t idx = k0 + uint32_t(lane);
+    const uint32_t ent = (idx < n1) ? lds.q1[idx] : kQEmpty;
+    bool golden = false;
+    if (ent != kQEmpty) {
+      const int e = int(ent >> 16), r = int((ent >> 8) & 0xFFu), o = int(ent & 0xFFu);
+      if (lds.hit[e] == 0u) {
+        const ShapeG A = pair_robot_pose<N>(sc, lds, e, r);
+        const ShapeG Bv = pair_env_shape(sc->env[o]);
+        const bool a_sphere = (A.kind == RKH_SHAPE_SPHERE), a_ccyl = (A.kind == RKH_SHAPE_CCYLINDER);
+        const bool b_sphere = (Bv.kind == RKH_SHAPE_SPHERE), b_ccyl = (Bv.kind == RKH_SHAPE_CCYLINDER);
+        if ((a_ccyl && !b_sphere && !b_ccyl) || (b_ccyl && !a_sphere && !a_ccyl)) {
+          // capped cylinder against a box = a golden-section search along the axis (prox_fundamentals_3D.cpp:108-115).
+          // Every value that search can return is the distance of SOME point of the axis segment to the box, so a lower
+          // bound over the segment that already exceeds the radius settles "no collision" without it: separation along the
+          // box's own axes, |c_k| - hl |t_k| - half_k, in the box frame (fp64, margin 1e-9).
+          const ShapeG& cc = a_ccyl ? A : Bv;
+          const ShapeG& bx = a_ccyl ? Bv : A;
+          const d3 cy_c = pose_to_parent(cc.pos, cc.q, mk3(0, 0, 0));
+          const d3 cy_t = qrot(cc.q, mk3(0.0, 0.0, 1.0));
+          const d4 bq = qinv(bx.q);
+          const d3 crel = qrot(bq, cy_c - bx.pos);
+          const d3 trel = qrot(bq, cy_t);
+          const double hl = 0.5 * cc.d0;
+          const double gx = fabs(crel.x) - fabs(trel.x) * hl - 0.5 * bx.d0;
+          const double gy = fabs(crel.y) - fabs(trel.y) * hl - 0.5 * bx.d1;
+          const double gz = fabs(crel.z) - fabs(trel.z) * hl - 0.5 * bx.d2;
+          golden = !(fmax(gx, fmax(gy, gz)) > cc.d1 + 1e-9);
+        } else {
+          double d;
+          if (b_sphere) d = a_sphere ? dist_sphere_sphere(A, Bv) : (a_ccyl ? dist_sphere_ccyl(Bv, A) : dist_sphere_box(Bv, A));
+          else if (b_ccyl) d = a_sphere ? dist_sphere_ccyl(A, Bv) : dist_ccyl_ccyl(A, Bv);
+          else d = dist_sphere_box(A, Bv);  // box obstacle: only a sphere gets here (box-box has no finder)
+          if (d < 0.0) lds.hit[e] = 1u;
+        }
+      }
+    }
+    // golden-section pairs move on to the second queue; when it is full it is drained first (uniform decisions)
+    while (__any(golden)) {
+      uint32_t slot = kQ2Cap;
+      if (golden) slot = atomicAdd(&lds.qn[1], 1u);
+      if (golden && slot < uint32_t(kQ2Cap)) {
+        lds.q2[slot] = ent;
+        golden = false;
+      }
+      if (__any(golden)) pair_drain_q2<N>(sc, lds);  // some did not fit: empty the queue, then they try again
+    }
+  }
+  if (lane == 0) lds.qn[0] = 0u;
+}
+
 // is the configuration in LD(XE..) (joint angles) collision-free?  (manip_dk_proxy_env_impl::is_free, proximity only)
-// The edge's two lanes take alternate robot shapes; the verdict is combined across them.
 template <int N, bool DIAG = false>
 __device__ __forceinline__ bool pair_proximity_free(ScenePtr sc_in, PairLds<N>& lds, int el, int h,
                                                     bool active, unsigned long long* stamps = nullptr) {
   typedef PairLayout<N> L_;
+  constexpr int R = L_::R;
   ScenePtr sc = sc_in;  // laundered, see pair_state_derivative
   asm volatile("" : "+s"(sc), "+v"(h), "+v"(el) : : "memory");
   unsigned long long t_prev = DIAG ? __builtin_readcyclecounter() : 0ull;
@@ -394,29 +510,34 @@ __device__ __forceinline__ bool pair_proximity_free(ScenePtr sc_in, PairLds<N>& 
     stamps[i] += t_now - t_prev;                                    \
     t_prev = t_now;                                                 \
   }
-  bool hit = !active;  // inactive lanes take no part in the scan
-  struct RobotConst {
-    d3 pos; d4 q; double d0, d1, d2, brad; int kind, link;
-  };
+  const int lane = threadIdx.x & 63;
   const int n_env = sc->n_env, n_robot = sc->n_robot;
-  auto load_robot = [&](int r0) {
-    const int r = (r0 + h < n_robot) ? r0 + h : (r0 < n_robot ? r0 : 0);
-    const auto& sh = sc->robot[r];
-    return RobotConst{ldg3(sh.pos), ldg4(sh.quat), sh.dims[0], sh.dims[1], sh.dims[2], sh.brad, sh.kind, sh.link};
-  };
-  RobotConst nxt = load_robot(0);
-  const int ol0 = (int(threadIdx.x & 63) < n_env) ? int(threadIdx.x & 63) : 0;
+  if (lane < 2) lds.qn[lane] = 0u;
+  if (lane < kPairEdges) lds.hit[lane] = 0u;
+  // this lane's cull record of the first obstacle chunk, fetched ahead of the kinematics
+  const int ol0 = (lane < n_env) ? lane : 0;
   const float e0x = float(sc->env_cull[ol0][0]), e0y = float(sc->env_cull[ol0][1]), e0z = float(sc->env_cull[ol0][2]),
               e0r = float(sc->env_cull[ol0][3]);
-  {  // joint end frames: revolute_joint_3D / rigid_link_3D kinematics, position + orientation only
+  {  // joint end frames: revolute_joint_3D / rigid_link_3D kinematics, position + orientation only.  The half-angle
+     // sin / cos of the joints 2r + h are this lane's; both lanes read them back from the (idle) cos / sin slots.
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int j = 2 * r + h;
+      const int jc = j < N ? j : N - 1;
+      double s2, c2;
+      sincos(0.5 * RKH_LD(L_::XE + 2 * jc), &s2, &c2);
+      if (j < N) {
+        RKH_LD(L_::CS + 2 * jc) = c2;
+        RKH_LD(L_::CS + 2 * jc + 1) = s2;
+      }
+    }
     d3 pos = ldg3(sc->base_pos);
     d4 Q = ldg4(sc->base_quat);
 #pragma unroll 1
     for (int j = 0; j < N; ++j) {
       const auto& J = sc->joints[j];
       const d3 axis_n = ldg3(J.axis_n);
-      double s2, c2;
-      sincos(0.5 * RKH_LD(L_::XE + 2 * j), &s2, &c2);
+      const double c2 = RKH_LD(L_::CS + 2 * j), s2 = RKH_LD(L_::CS + 2 * j + 1);
       const d4 tq = d4{c2, axis_n.x * s2, axis_n.y * s2, axis_n.z * s2};
       const d4 EQ = qmul(Q, tq);
       if (!h) {
@@ -434,35 +555,27 @@ __device__ __forceinline__ bool pair_proximity_free(ScenePtr sc_in, PairLds<N>& 
   RKH_STAMP(5)
 #pragma unroll 1
   for (int r0 = 0; r0 < n_robot; r0 += 2) {
-    if (__all(hit)) break;
     const int r = r0 + h;
-    const bool have = r < n_robot;
-    const RobotConst sh = nxt;
-    nxt = load_robot(r0 + 2);
-    // robot shape -> global pose (pose_3D::getGlobalPose, pose_3D.hpp:102-110)
-    const int j = sh.link;
-    const int js3 = j > 0 ? 3 * j - 3 : 0;
-    d3 Epos = mk3(RKH_LD(L_::ECP + js3), RKH_LD(L_::ECP + js3 + 1), RKH_LD(L_::ECP + js3 + 2));
-    if (j == 0) Epos = ldg3(sc->base_pos);
-    const d4 EQ = d4{RKH_LD(L_::ECQ + 4 * j), RKH_LD(L_::ECQ + 4 * j + 1), RKH_LD(L_::ECQ + 4 * j + 2),
-                     RKH_LD(L_::ECQ + 4 * j + 3)};
-    ShapeG A;
-    A.kind = sh.kind;
-    A.pos = Epos + qrot(EQ, sh.pos);
-    A.q = qmul(EQ, sh.q);
-    A.d0 = sh.d0; A.d1 = sh.d1; A.d2 = sh.d2;
+    const bool open = active && (lds.hit[el] == 0u);
+    if (!__any(open)) break;  // every edge of the wave is settled
+    const bool have = (r < n_robot) && open;
+    const int rc = (r < n_robot) ? r : r0;
+    const ShapeG A = pair_robot_pose<N>(sc, lds, el, rc);
     const d3 ca = pose_to_parent(A.pos, A.q, mk3(0, 0, 0));
-    const double ra = sh.brad;
-    const bool a_sphere = (sh.kind == RKH_SHAPE_SPHERE), a_ccyl = (sh.kind == RKH_SHAPE_CCYLINDER);
+    const bool a_sphere = (A.kind == RKH_SHAPE_SPHERE), a_ccyl = (A.kind == RKH_SHAPE_CCYLINDER);
+    const bool a_box = !a_sphere && !a_ccyl;
     // capped cylinder: its axis segment (for the cull below)
     const d3 a_ax = qrot(A.q, mk3(0.0, 0.0, 1.0));
-    const bool a_box = !a_sphere && !a_ccyl;
+    const double ra = sc->robot[rc].brad;
     const double seg_hl = a_ccyl ? 0.5 * A.d0 : 0.0, seg_rad_m = (a_ccyl ? A.d1 : ra) + 1e-9;
+    // static reach (SceneDev::robot_n_reach): the obstacles this lane's shape can touch at all are a prefix of the table
+    const int my_reach = sc->robot_n_reach[rc];
+    const int reach0 = sc->robot_n_reach[r0], reach1 = (r0 + 1 < n_robot) ? sc->robot_n_reach[r0 + 1] : 0;
+    const int n_scan = reach0 > reach1 ? reach0 : reach1;  // uniform
 #pragma unroll 1
-    for (int o0 = 0; o0 < n_env; o0 += 64) {
-      const int on = (n_env - o0 < 64) ? n_env - o0 : 64;
-      const unsigned long long k_sphere = sc->env_kind_mask[0][o0 >> 6], k_box = sc->env_kind_mask[1][o0 >> 6],
-                               k_ccyl = sc->env_kind_mask[2][o0 >> 6];
+    for (int o0 = 0; o0 < n_scan; o0 += 64) {
+      const int on = (n_scan - o0 < 64) ? n_scan - o0 : 64;
+      const unsigned long long k_box = sc->env_kind_mask[1][o0 >> 6];
       // Cull, one bit per surviving obstacle.  Lane l fetches the cull record of obstacle o0 + l once; the uniform loop
       // over the obstacles reads it back with v_readlane (no memory latency in the loop).  A pair is dropped only if a
       // lower bound on its distance is positive -- the bounding-sphere test of proxy_query_model.cpp:384-389 or, for
@@ -471,9 +584,9 @@ __device__ __forceinline__ bool pair_proximity_free(ScenePtr sc_in, PairLds<N>& 
       // conservative filter, not part of the reference's arithmetic): records and the shape's segment are rounded to
       // fp32 and the reach carries a 1 mm margin, three orders of magnitude above the rounding of the fp32 evaluation at
       // these magnitudes (coordinates of a few metres).
-      const int ol = (o0 + int(threadIdx.x & 63) < n_env) ? o0 + int(threadIdx.x & 63) : o0;
       float ecx = e0x, ecy = e0y, ecz = e0z, ecr = e0r;
       if (o0 != 0) {  // further chunks of 64 obstacles (uniform branch)
+        const int ol = (o0 + lane < n_env) ? o0 + lane : o0;
         ecx = float(sc->env_cull[ol][0]); ecy = float(sc->env_cull[ol][1]); ecz = float(sc->env_cull[ol][2]);
         ecr = float(sc->env_cull[ol][3]);
       }
@@ -497,72 +610,36 @@ __device__ __forceinline__ bool pair_proximity_free(ScenePtr sc_in, PairLds<N>& 
         const unsigned nib = cull_one(i) | (cull_one(i + 1) << 1) | (cull_one(i + 2) << 2) | (cull_one(i + 3) << 3);
         mask |= (unsigned long long)nib << i;
       }
-      // obstacles past the end of the chunk; box-box has no finder in the reference (proxy_query_model.cpp:367)
-      mask &= (on == 64) ? ~0ull : ((1ull << on) - 1ull);
+      // obstacles past this lane's own reach; box-box has no finder in the reference (proxy_query_model.cpp:367)
+      const int mine = my_reach - o0;
+      mask &= (mine >= 64) ? ~0ull : (mine <= 0 ? 0ull : ((1ull << mine) - 1ull));
       mask &= a_box ? ~k_box : ~0ull;
-      if (hit || !have) mask = 0ull;
-      RKH_STAMP(6)
-      // survivors, kind by kind
-#pragma unroll 1
-      for (int kind = 0; kind < 3; ++kind) {
-        unsigned long long m = mask & (kind == 0 ? k_sphere : (kind == 1 ? k_box : k_ccyl));
-        if (kind == 1 && a_ccyl) {
-          // capped cylinder against a box = a golden-section search along the axis (prox_fundamentals_3D.cpp:108-115,
-          // ~7 k cycles that hold the whole wave while any lane runs one).  Every value that search can return is the
-          // distance of SOME point of the axis segment to the box, so a lower bound over the segment that already
-          // exceeds the radius settles the verdict "no collision" without it: separation along the box's own axes,
-          // |c_k| - hl |t_k| - half_k, in the box frame (fp64, margin 1e-9).  First pass: drop those pairs.
-          unsigned long long keep = 0ull, mm = m;
-          while (__any(mm != 0ull)) {
-            if (mm != 0ull) {
-              const int i = __builtin_ctzll(mm);
-              mm &= mm - 1ull;
-              const auto& es = sc->env[o0 + i];
-              const d4 bq = qinv(ldg4(es.quat));
-              const d3 crel = qrot(bq, ca - ldg3(es.pos));
-              const d3 trel = qrot(bq, a_ax);
-              const double hl = 0.5 * A.d0;
-              const double gx = fabs(crel.x) - fabs(trel.x) * hl - 0.5 * es.dims[0];
-              const double gy = fabs(crel.y) - fabs(trel.y) * hl - 0.5 * es.dims[1];
-              const double gz = fabs(crel.z) - fabs(trel.z) * hl - 0.5 * es.dims[2];
-              if (!(fmax(gx, fmax(gy, gz)) > A.d1 + 1e-9)) keep |= 1ull << i;
-            }
+      if (!have) mask = 0ull;
+      // survivors -> first queue.  A lane whose entries do not all fit writes placeholders into the part of its range
+      // that lies inside the queue and keeps its mask for the next turn.
+      while (__any(mask != 0ull)) {
+        const uint32_t cnt = uint32_t(__popcll(mask));
+        uint32_t base = 0u;
+        if (cnt) base = atomicAdd(&lds.qn[0], cnt);
+        const bool fits = base + cnt <= uint32_t(kQ1Cap);
+        if (cnt) {
+          unsigned long long mm = mask;
+          for (uint32_t k = 0; k < cnt; ++k) {
+            const int i = __builtin_ctzll(mm);
+            mm &= mm - 1ull;
+            if (base + k < uint32_t(kQ1Cap)) lds.q1[base + k] = fits ? q_pack(el, rc, o0 + i) : kQEmpty;
           }
-          m = keep;
+          if (fits) mask = 0ull;
         }
-        while (__any(m != 0ull)) {
-          if (m != 0ull) {
-            const int i = __builtin_ctzll(m);
-            m &= m - 1ull;
-            const auto& es = sc->env[o0 + i];  // per-lane gather (L1 / L2 resident table)
-            ShapeG Bv;
-            Bv.kind = es.kind;
-            Bv.pos = ldg3(es.pos);
-            Bv.q = ldg4(es.quat);
-            Bv.d0 = es.dims[0]; Bv.d1 = es.dims[1]; Bv.d2 = es.dims[2];
-            double d;
-            if (kind == 0) {
-              d = a_sphere ? dist_sphere_sphere(A, Bv) : (a_ccyl ? dist_sphere_ccyl(Bv, A) : dist_sphere_box(Bv, A));
-            } else if (kind == 1) {
-              d = a_sphere ? dist_sphere_box(A, Bv) : dist_ccyl_box(A, Bv);
-            } else {
-              d = a_sphere ? dist_sphere_ccyl(A, Bv) : (a_ccyl ? dist_ccyl_ccyl(A, Bv) : dist_ccyl_box(Bv, A));
-            }
-            if (d < 0.0) {
-              hit = true;
-              m = 0ull;
-              mask = 0ull;
-            }
-          }
-        }
+        if (__any(mask != 0ull) || lds.qn[0] >= 64u) pair_drain_q1<N>(sc, lds);
       }
     }
-    // What the edge's other lane found counts for both.  The exchange is its own statement: inside `hit || xchg(..)` it
-    // would run only on the lanes that have not hit, and a cross-lane read of a lane that is switched off returns 0.
-    const int other_hit = xchg_i(hit ? 1 : 0);
-    hit = hit || (other_hit != 0);
-    RKH_STAMP(7)
+    RKH_STAMP(6)
   }
+  pair_drain_q1<N>(sc, lds);
+  pair_drain_q2<N>(sc, lds);
+  RKH_STAMP(7)
+  const bool hit = (lds.hit[el] != 0u);
   return !(hit && active);
 #undef RKH_STAMP
 }

@@ -140,6 +140,12 @@ struct SceneDev {
   // flexible_beam_3D (flexible_beam.cpp:155-193): rest length, stiffness, torsion stiffness, world anchor pose
   double beam_rest, beam_k, beam_kt;
   double beam_pos[3], beam_quat[4];
+  // Static reach of the robot shapes (serial chains).  The environment shapes are stored in ascending order of
+  // "closeness" = |centre - chain base| - bounding radius, and robot shape r can only ever touch the first
+  // robot_n_reach[r] of them: its centre stays within (sum of the link offsets below its joint) + |local position| of the
+  // chain base, plus its bounding radius.  Pairs beyond that have a positive bounding-sphere gap in every configuration,
+  // i.e. they are the pairs the cull of proxy_query_pair_3D::findMinimumDistance (proxy_query_model.cpp:384-389) drops.
+  int32_t robot_n_reach[kMaxDof * 2];
 };
 
 }  // namespace rkh

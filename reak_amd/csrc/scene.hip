@@ -162,6 +162,7 @@ static rkh_status create_planar_scene(rkh_ctx* ctx, const rkh_kte_op* prog, int 
       S.env[S.n_env++] = d;
     }
   }
+  for (int r = 0; r < S.n_robot; ++r) S.robot_n_reach[r] = S.n_env;
   // proxy_query_pair_2D::createProxFinderList (proxy_query_model.cpp:75-161), kept in its i-major / j-minor order:
   // findMinimumDistance (:163-189) culls against the running minimum with a radius the capped rectangle's caps
   // reach beyond, so the result depends on the order and the device replays the sequence
@@ -319,9 +320,25 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
     for (int i = 0; i < 3; ++i) S.beam_pos[i] = bm.offset.pos[i];
     for (int i = 0; i < 4; ++i) S.beam_quat[i] = bm.offset.quat[i];
   }
-  // shapes: robot model (anchored) / environment model (world)
+  // shapes: robot model (anchored) / environment model (world).  The environment shapes are stored nearest-to-the-base
+  // first (see SceneDev::robot_n_reach; the verdict "some pair is closer than 0" does not depend on the pair order).
   std::vector<int> robot_src, env_src;
-  for (int i = 0; i < n_shapes; ++i) {
+  std::vector<int> order(n_shapes);
+  {
+    std::vector<double> key(n_shapes, -INFINITY);  // robot shapes first, in their given order
+    for (int i = 0; i < n_shapes; ++i) {
+      order[i] = i;
+      const rkh_shape& s = shapes[i];
+      if (s.anchor >= 0) continue;
+      double d2 = 0.0;
+      for (int k = 0; k < 3; ++k) d2 += (s.pose.pos[k] - S.base_pos[k]) * (s.pose.pos[k] - S.base_pos[k]);
+      key[i] = std::sqrt(d2) - bounding_radius(s);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+  }
+  std::vector<double> env_key;
+  for (int oi = 0; oi < n_shapes; ++oi) {
+    const int i = order[oi];
     const rkh_shape& s = shapes[i];
     if (s.kind < RKH_SHAPE_SPHERE || s.kind > RKH_SHAPE_CCYLINDER) {
       delete sc;
@@ -358,7 +375,25 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
       S.env_kind_mask[d.kind == RKH_SHAPE_SPHERE ? 0 : (d.kind == RKH_SHAPE_BOX ? 1 : 2)][S.n_env / 64] |= 1ull << (S.n_env % 64);
       S.env[S.n_env++] = d;
       env_src.push_back(i);
+      double d2 = 0.0;
+      for (int k = 0; k < 3; ++k) d2 += (d.pos[k] - S.base_pos[k]) * (d.pos[k] - S.base_pos[k]);
+      env_key.push_back(std::sqrt(d2) - d.brad);
     }
+  }
+  for (int r = 0; r < S.n_robot; ++r) {
+    S.robot_n_reach[r] = S.n_env;
+    if (S.n_branches != 0 || S.planar) continue;  // serial 3D chains only: every joint hangs off the previous link
+    double reach = 0.0;
+    for (int i = 0; i < S.robot[r].link; ++i) {
+      const double* o = S.joints[i].off_pos;
+      reach += std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    }
+    const double* lp = S.robot[r].pos;
+    reach += std::sqrt(lp[0] * lp[0] + lp[1] * lp[1] + lp[2] * lp[2]) + S.robot[r].brad;
+    reach *= 1.0 + 1e-9;  // the sums above are rounded
+    int cnt = 0;
+    while (cnt < S.n_env && env_key[cnt] <= reach + 1e-6) ++cnt;
+    S.robot_n_reach[r] = cnt;
   }
   // proxy_query_pair_3D::createProxFinderList (proxy_query_model.cpp:215-374), then grouped by routine so
   // that the lanes of a wave run the same closed form (the verdict does not depend on the pair order)
