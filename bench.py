@@ -12,17 +12,22 @@ Multi-GPU: independent seeds shard across ranks ("scaling": "weak"), no data-pat
 region one all-reduce(min) of the best solution cost and all-reduce(sum) of the counters.
 
 Extra objects on the JSON line:
-  roofline      NN-sweep kernel of the timed region, HIP-event timed on the planner streams.  In the planner a sweep serves
-                hundreds of queries per tree, so it is bound by the (vertex, query) pair arithmetic on the fp32 matrix
-                cores: 24 flops per pair against the 157.3 TFLOP/s dense fp32 MFMA peak (algorithmic bytes n*D*8 per
-                launch, SURVEY.md 8(d), are reported beside it as algorithmic_GBps).
-  nn_sweep_hbm  the same kernel in its HBM-bound regime (tree larger than the 256 MiB Infinity Cache, 8 queries
-                per sweep), measured outside the timed region
-  steer_kernels the dominant kernels of the timed region (the two mappings of the steer kernel): share of the step time,
-                edges/s inside the kernel, achieved fp64 operation rate against the no-FMA VALU peak
-  cpu_baseline_all_cores  the same sample on every host core (one oracle process per core, independent seeds)
+  roofline      NN-sweep kernel of the timed region against HBM, exactly as SURVEY.md 8(d) defines it: achieved =
+                sweeps * n * D * 8 bytes / kernel time (HIP events on the planner stream), peak 8 TB/s; `traffic` = HBM bytes
+                per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload
+                (profiles/r02_nn_planner_pmc.json).  In the planner a sweep serves hundreds of queries per tree, so the
+                kernel is bound by the (vertex, query) pair arithmetic, not by these bytes: see nn_sweep_mfma_timed.
+  nn_sweep_mfma_timed  the same launches against the dense fp32 MFMA peak (24 flops per pair on the matrix cores)
+  nn_sweep_hbm  the fp64 sweep in its HBM-bound regime (tree larger than the 256 MiB Infinity Cache, 8 queries per
+                sweep), measured outside the timed region
+  nn_sweep_mfma the matrix-core sweep alone on one 1 Mi-row tree
+  steer_kernels the dominant kernels of the timed region: share of the step time, edges/s inside the kernel, fp64
+                operation rate against the no-FMA VALU peak with the EXACT operation count of one f-eval as the restated
+                reference performs it (oracle/flop_count.cpp; `useful` = without its products over structural zeros)
+  single_problem  P = 1 and P = 16 (one / sixteen problems per GPU, 20 000 vertices each), outside the timed region
   cpu_baseline  the CPU oracle (restatement of the reference planner, -O3 -march=native) on a bounded sample of the
-                same workload, single thread like ReaK itself
+                same workload, single thread like ReaK itself; host CPU model and core count stated
+  cpu_baseline_all_cores  the same sample on every host core (one oracle process per core, independent seeds)
 """
 import argparse
 import ctypes as C
@@ -131,7 +136,19 @@ def nn_mfma_microbench(lib, ctx, events, n_rows=1 << 20, B=1024, reps=10):
             "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}
 
 
-def cpu_baseline(scn, seconds_target=15.0):
+def host_description():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "usable_cores": len(os.sched_getaffinity(0))}
+
+
+def cpu_baseline(scn, max_vertices, seconds_target=15.0):
     """Oracle (kind 'port': the reference cannot be built here) on a bounded sample."""
     import oracle_lib
 
@@ -142,10 +159,31 @@ def cpu_baseline(scn, seconds_target=15.0):
     nv2 = int(min(20000, max(nv, rate * seconds_target)))
     rc, out, _ = osc.rrt_dyn(scn.rrt_params(seed=1, max_vertices=nv2))
     assert rc == 0
+    # The CPU's cost per iteration grows with the tree (linear-search NN): the rate it would hold at the bench's final
+    # tree size, from the measured steer cost per iteration of the sample and the measured linear search at that size.
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-2, 2, size=(max_vertices, 12))
+    q = rng.uniform(-2, 2, size=(16, 12))
+    oracle_lib.nn1(q[:2], pts[:1000], fast=True)
+    t0 = time.perf_counter()
+    oracle_lib.nn1(q, pts, fast=True)
+    t_nn_full = (time.perf_counter() - t0) / len(q)
+    t0 = time.perf_counter()
+    oracle_lib.nn1(q, pts[: nv2 // 2], fast=True)
+    t_nn_half = (time.perf_counter() - t0) / len(q)  # the sample's average tree size
+    it_per_v = out.iterations / max(1, out.num_vertices - 1)
+    t_iter_sample = out.seconds / out.iterations
+    t_iter_full = max(t_iter_sample - t_nn_half, 0.0) + t_nn_full
     return {"value": (out.num_vertices - 1) / out.seconds, "unit": "valid node expansions/s", "cores": 1, "kind": "port",
             "edges_checked_per_s": out.edges_checked / out.seconds,
             "sample": f"seed 1 of the same C2 world, first {nv2} vertices ({out.iterations} iterations, "
                       f"{out.seconds:.1f} s), oracle -O3 -march=native, 1 thread (ReaK is single-threaded)",
+            "rate_at_final_tree_size": {"value": 1.0 / (it_per_v * t_iter_full), "unit": "valid node expansions/s",
+                                        "tree_size": max_vertices,
+                                        "how": "steer cost per iteration of the sample + the oracle's linear search timed "
+                                               f"at {max_vertices} vertices ({t_nn_full * 1e6:.0f} us per query); an estimate, "
+                                               "the sample itself stops earlier"},
+            "host": host_description(),
             "note": "ReaK planner, CPU restatement (reference binary unavailable: needs Boost + BGL-Extra)"}
 
 
@@ -166,7 +204,49 @@ def cpu_baseline_all_cores(nv, max_workers=16):
     return {"value": nodes / busy, "unit": "valid node expansions/s", "cores": cores, "kind": "port",
             "edges_checked_per_s": sum(o["edges"] for o in outs) / busy,
             "sample": f"{cores} processes x seeds 1..{cores}, first {nv} vertices each ({busy:.1f} s planner time, "
-                      f"{wall:.1f} s wall incl. process start), oracle -O3 -march=native"}
+                      f"{wall:.1f} s wall incl. process start), oracle -O3 -march=native",
+            "host": host_description()}
+
+
+def feval_ops(scn, samples=32):
+    """Exact fp64 operation count of one x' = f(x, u) of the restated reference (mean over random states of the C2 box)."""
+    import oracle_lib
+
+    rng = np.random.default_rng(11)
+    lo = np.array([scn.dyn.lower[i] for i in range(2 * scn.n_dof)])
+    hi = np.array([scn.dyn.upper[i] for i in range(2 * scn.n_dof)])
+    acc = {}
+    for _ in range(samples):
+        c = oracle_lib.feval_op_count(scn, rng.uniform(lo, hi), rng.uniform(-50.0, 50.0, size=scn.n_dof))
+        for k, v in c.items():
+            acc[k] = acc.get(k, 0) + v
+    return {k: v / samples for k, v in acc.items()}
+
+
+def nn_planner_traffic(problems, max_vertices):
+    """HBM bytes per launch of the planner-regime NN sweep from the committed PMC passes, if they match this run."""
+    path = os.path.join(ROOT, "profiles", "r02_nn_planner_pmc.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    if rec.get("problems_per_gpu") == problems and rec.get("max_vertices") == max_vertices:
+        return rec.get("hbm_bytes_per_launch")
+    return None
+
+
+def single_problem_rate(lib, scene, scn, P, max_vertices):
+    """P problems per GPU (P = 1: the latency-bound case), wall clock of a whole solve."""
+    prms = [scn.rrt_params(seed=5000 + i, max_vertices=max_vertices) for i in range(P)]
+    pl = lib.RrtPlannerPool(scene, prms, groups=1)
+    pl.enqueue(0)
+    t0 = time.perf_counter()
+    pl.solve_planning_query()
+    dt = time.perf_counter() - t0
+    nodes = sum(int(st.num_vertices) - 1 for st in pl.all_stats)
+    edges = sum(int(st.edges_checked) for st in pl.all_stats)
+    pl.close()
+    return {"problems": P, "max_vertices": max_vertices, "value": nodes / dt, "unit": "valid node expansions/s",
+            "edges_collision_checked_per_s": edges / dt, "seconds": dt}
 
 
 def main():
@@ -185,9 +265,24 @@ def main():
     ap.add_argument("--no-microbench", action="store_true")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL rendezvous on
+    # 127.0.0.1) before anything touches the GPU, and relay their output; under torchrun the world must match --gpus.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (world == 1 and args.gpus <= 1):
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                 f"(or run `python bench.py --gpus {args.gpus}` without a launcher)")
     import torch
 
     # RKH_BENCH_BACKEND=gloo + RKH_BENCH_SHARE_GPU=1: rehearsal of the N > 1 path on a box with fewer GPUs than ranks
@@ -274,6 +369,7 @@ def main():
     if rank == 0:
         nn_gbps = (tot["nn_bytes"] / (tot["nn_ms"] * 1e-3) / 1e9) if tot["nn_ms"] > 0 else 0.0
         nn_tflops = (tot["nn_pairs"] * 24.0 / (tot["nn_ms"] * 1e-3) / 1e12) if tot["nn_ms"] > 0 else 0.0
+        nn_traffic = nn_planner_traffic(P, args.max_vertices)
         out = {
             "metric": "valid RRT node-expansions/sec (+ edges-collision-checked/sec)",
             "value": nodes_all / elapsed,
@@ -297,43 +393,58 @@ def main():
             "rounds": tot["rounds"],
             "speculation_efficiency": (tot["edges"] / tot["spec"]) if tot["spec"] else None,
             "best_solution_cost": None if best == float("inf") else best,
-            # NN sweep of the timed region (rank 0).  In the planner every launch sweeps the trees of all problems for a
-            # whole speculative batch of queries each (a few hundred per tree), so it is bound by the arithmetic of the
-            # (vertex, query) pairs, not by HBM: the pre-filter evaluates each pair as a rank-Dp product on the fp32 matrix
-            # cores (v_mfma_f32_32x32x2_f32, 2 * Dp flops per pair, Dp = 12); peak = dense fp32 MFMA (MI355X_MICROARCH.md).
-            "roofline": {"kernel": nn_kernel[0], "bound": "mfma", "achieved": nn_tflops, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": nn_tflops / 157.3, "traffic": None, "launches": tot["nn_launches"],
+            # NN sweep of the timed region (rank 0) by SURVEY.md 8(d): algorithmic bytes = n * D * 8 per swept tree, against
+            # the 8 TB/s HBM peak.  Every launch sweeps the trees of all problems for a whole speculative batch of queries
+            # each (a few hundred per tree), which makes the kernel compute-bound: the HBM fraction is low by design and
+            # the matrix-core view of the same launches is nn_sweep_mfma_timed.
+            "roofline": {"kernel": nn_kernel[0], "bound": "hbm", "achieved": nn_gbps, "peak": 8000.0, "unit": "GB/s",
+                         "frac": nn_gbps / 8000.0, "traffic": nn_traffic, "launches": tot["nn_launches"],
+                         "algorithmic_bytes_per_launch": (tot["nn_bytes"] / tot["nn_launches"]) if tot["nn_launches"] else None,
                          "avg_launch_us": (tot["nn_ms"] * 1e3 / tot["nn_launches"]) if tot["nn_launches"] else None,
-                         "pairs_per_launch": (tot["nn_pairs"] / tot["nn_launches"]) if tot["nn_launches"] else None,
-                         "algorithmic_GBps": nn_gbps,
-                         "note": "algorithmic flops = 24 per (vertex, query) pair of the profiled sweeps / HIP-event kernel "
-                                 "time on the planner streams; the survivors' exact fp64 recheck is not counted "
-                                 "(with --groups 2 a sweep runs beside the other group's steer kernel and its elapsed "
-                                 "time includes the share of the machine it did not have); nn_sweep_mfma = the same "
-                                 "kernel alone on one large tree, nn_sweep_hbm = the fp64 sweep in its HBM-bound regime"},
+                         "queries_per_launch": tot["spec"] / max(1, tot["nn_launches"]),
+                         "note": "algorithmic bytes (sum over the swept trees of n * D * 8, SURVEY 8(d)) / HIP-event kernel "
+                                 "time on the planner stream; traffic = HBM bytes per launch, FETCH_SIZE x 2 + WRITE_SIZE of "
+                                 "separate --pmc passes (profiles/r02_nn_planner_pmc.json; null if not collected for "
+                                 "this configuration)"},
+            "nn_sweep_mfma_timed": {"kernel": nn_kernel[0], "bound": "mfma", "achieved": nn_tflops, "peak": 157.3,
+                                    "unit": "TFLOP/s", "frac": nn_tflops / 157.3,
+                                    "pairs_per_launch": (tot["nn_pairs"] / tot["nn_launches"]) if tot["nn_launches"] else None,
+                                    "note": "the same launches as `roofline`: 24 flops per (vertex, query) pair on the fp32 "
+                                            "matrix cores (v_mfma_f32_32x32x2_f32), the survivors' exact fp64 recheck not "
+                                            "counted"},
         }
-        # the dominant kernels of the timed region (rank 0): the two steer mappings, fp64-VALU / latency bound.
-        # Algorithmic work per propagated edge: 20 RK4 steps x 4 f-evals x ~7.5 k fp64 operations (6 joints)
-        # + 20 proximity tests; the reference's operation order forbids FMA contraction, so the usable peak is one
-        # operation per lane and cycle = half of the 78.6 TFLOP/s FMA figure.
+        # the dominant kernels of the timed region (rank 0): the two steer mappings, fp64 VALU bound.  Work per propagated
+        # edge: 20 RK4 steps x 4 f-evals, each the EXACT operation count of the restated reference's get_state_derivative
+        # (oracle/flop_count.cpp, mean over sampled states) + 20 proximity tests (not counted).  The reference's operation
+        # order forbids FMA contraction, so the usable peak is one operation per lane and cycle = half of the 78.6 TFLOP/s
+        # FMA figure.
         if tot["steer_ms"] > 0:
-            ops_per_edge = 20 * 4 * 7.5e3
+            fe = feval_ops(scn)
+            ops_per_edge = 20 * 4 * fe["useful"]
             rate = tot["spec"] * ops_per_edge / (tot["steer_ms"] * 1e-3) / 1e12
-            out["steer_kernels"] = {"kernels": "propagate_lane_kernel (large rounds) + propagate_kernel (small rounds)",
-                                    "bound": "fp64_valu_latency", "share_of_step_time": tot["steer_ms"] * 1e-3 / tot["seconds"],
+            out["steer_kernels"] = {"kernels": "propagate_pair_kernel (large rounds) + propagate_kernel (small rounds)",
+                                    "bound": "fp64_valu", "share_of_step_time": tot["steer_ms"] * 1e-3 / tot["seconds"],
                                     "avg_round_ms": tot["steer_ms"] / max(1, tot["steer_launches"]),
                                     "edges_per_s_in_kernel": tot["spec"] / (tot["steer_ms"] * 1e-3),
+                                    "f_eval_ops": fe,
                                     "achieved": rate, "peak": 39.3, "unit": "Tops/s (fp64, no FMA)", "frac": rate / 39.3,
-                                    "occupancy": "propagate_lane_kernel: one 32-edge wave per SIMD (40.8 KB LDS per wave, "
-                                                 "4 waves per CU, 1024 per GPU); waves packed in dispatch order over the 8 "
-                                                 "XCDs, batch sizes fitted to whole passes of 1024 waves",
-                                    "note": "f-eval operations only (proximity excluded); rank-0 launches of the timed region"}
+                                    "frac_counting_the_reference_dense_products": rate / 39.3 * fe["all"] / fe["useful"],
+                                    "occupancy": "propagate_pair_kernel: 32 edges per wave (two adjacent lanes per edge), 220 "
+                                                 "VGPRs, 0 scratch, 20.3 KB LDS per wave = 8 waves per CU = two per SIMD "
+                                                 "(2048 per GPU); waves packed in dispatch order over the 8 XCDs, batch "
+                                                 "sizes fitted to whole passes of the machine",
+                                    "note": "f-eval operations only (proximity tests excluded); rank-0 launches of the "
+                                            "timed region; `useful` operations of the reference's f-eval, i.e. without its "
+                                            "dense products over structural zeros"}
         # the microbenchmarks and the CPU baselines are single-GPU extras: rank 0 at N = 1 only
         if not args.no_microbench and world == 1:
             out["nn_sweep_hbm"] = nn_sweep_microbench(lib, ctx, events, 4 * 1024 * 1024, 8, 20)
             out["nn_sweep_mfma"] = nn_mfma_microbench(lib, ctx, events)
+        if not args.no_microbench and world == 1:
+            out["single_problem"] = [single_problem_rate(lib, scene, scn, 1, 20000),
+                                     single_problem_rate(lib, scene, scn, 16, 20000)]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scn)
+            out["cpu_baseline"] = cpu_baseline(scn, args.max_vertices)
             nv_used = int(out["cpu_baseline"]["sample"].split("first ")[1].split(" ")[0])
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(nv_used)
         print(json.dumps(out))

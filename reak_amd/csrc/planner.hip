@@ -311,25 +311,76 @@ __global__ __launch_bounds__(256) void commit_kernel(const ProblemDev* __restric
 }
 
 // after a probe-only flush launch: nothing is pending any more
-// One contiguous host->device copy carries the new stretch of every problem's sample stream; block b moves segment b to
-// its place behind the problem's samples and only then raises the problem's samples_ready (a round that still sees the
-// old value just takes a smaller batch).  Replaces two small copies per problem and call.
+// The sample stream is generated ON THE DEVICE: hyperbox_topology::random_point (hyperbox_topology.hpp:97-103) draws D
+// times uniform_01<mt19937&, double> = eng() * 2^-32 per sample (Boost.Random on a 32-bit engine: one draw per
+// coordinate), so draw number k * D + d is coordinate d of sample k whatever happens in the planner.  One block per
+// problem keeps that problem's mt19937 state (624 words + position, global_rng.hpp:44-54 seeded like std::mt19937) in LDS,
+// regenerates it 624 words at a time in the three data-parallel stretches of the recurrence (words 0..226 read only old
+// words, 227..453 the new 0..226, 454..622 the new 227..395, word 623 the new 396 and 0) and writes the samples behind the
+// ones the rounds may read; only then it raises the problem's samples_ready (a round that still sees the old value just
+// takes a smaller batch).  (Round 1 generated the stream on one host thread and uploaded it: ~15 M draws per 16 rounds,
+// as long as the GPU needed for those rounds.)
 struct SampleSeg {
-  double* dst;
-  uint64_t src_off;      // doubles into the staging buffer
-  uint64_t count;        // doubles (a multiple of D)
+  double* dst;           // first new sample of the problem
+  uint64_t count;        // doubles to produce (a multiple of D)
+  uint32_t* mt;          // the problem's generator: 624 state words + position
   uint32_t* ready_ptr;   // &PlannerState::samples_ready of the problem
   uint32_t ready_new;
   uint32_t pad;
 };
-__global__ __launch_bounds__(256) void scatter_samples_kernel(const SampleSeg* __restrict__ tab,
-                                                               const double* __restrict__ stage) {
+constexpr int kMtN = 624, kMtM = 397;
+__device__ __forceinline__ uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_t far) {
+  const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+  return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__global__ __launch_bounds__(256) void generate_samples_kernel(const SampleSeg* __restrict__ tab,
+                                                                const double* __restrict__ bounds, int D) {
+  __shared__ uint32_t mt[kMtN];
   const SampleSeg sg = tab[blockIdx.x];
-  const double* __restrict__ src = stage + sg.src_off;
-  for (uint64_t i = threadIdx.x; i < sg.count; i += 256) sg.dst[i] = src[i];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < uint32_t(kMtN); i += 256) mt[i] = sg.mt[i];
+  uint32_t idx = sg.mt[kMtN];
+  __syncthreads();
+  uint64_t produced = 0;
+  while (produced < sg.count) {  // uniform
+    if (idx == uint32_t(kMtN)) {
+      // words [a, b): new[i] = twist(old[i], old[i + 1], word (i + 397) mod 624 as it stands at this point)
+      auto stretch = [&](uint32_t a, uint32_t b) {
+        const uint32_t i = a + tid;
+        uint32_t v = 0;
+        if (i < b) v = mt_twist(mt[i], mt[i + 1], mt[i + kMtM < uint32_t(kMtN) ? i + kMtM : i + kMtM - kMtN]);
+        __syncthreads();  // every thread has read its old neighbour before anybody overwrites it
+        if (i < b) mt[i] = v;
+        __syncthreads();
+      };
+      stretch(0, kMtN - kMtM);                  // 0 .. 226
+      stretch(kMtN - kMtM, 2 * (kMtN - kMtM));  // 227 .. 453
+      stretch(2 * (kMtN - kMtM), kMtN - 1);     // 454 .. 622
+      if (tid == 0) mt[kMtN - 1] = mt_twist(mt[kMtN - 1], mt[0], mt[kMtM - 1]);
+      __syncthreads();
+      idx = 0;
+    }
+    const uint64_t left = sg.count - produced;
+    const uint32_t chunk = (uint64_t(kMtN - idx) < left) ? uint32_t(kMtN - idx) : uint32_t(left);
+    for (uint32_t t = tid; t < chunk; t += 256) {
+      uint32_t y = mt[idx + t];
+      y ^= (y >> 11);
+      y ^= (y << 7) & 0x9d2c5680u;
+      y ^= (y << 15) & 0xefc60000u;
+      y ^= (y >> 18);
+      const double u = double(y) * (1.0 / 4294967296.0);  // < 1 for every 32-bit y: uniform_01 never redraws
+      const int d = int((produced + t) % uint64_t(D));
+      sg.dst[produced + t] = bounds[d] + u * (bounds[D + d] - bounds[d]);
+    }
+    produced += chunk;
+    idx += chunk;
+    __syncthreads();
+  }
+  for (uint32_t i = tid; i < uint32_t(kMtN); i += 256) sg.mt[i] = mt[i];
+  if (tid == 0) sg.mt[kMtN] = idx;
   __threadfence();  // the samples are visible device-wide before the count says so
   __syncthreads();
-  if (threadIdx.x == 0) *sg.ready_ptr = sg.ready_new;
+  if (tid == 0) *sg.ready_ptr = sg.ready_new;
 }
 
 // Goal-probe results since the last sync: block b copies problem b's new stretch into one buffer (one device->host copy
@@ -358,7 +409,7 @@ using namespace rkh;
 namespace {
 struct Problem {  // host view of one planning problem
   rkh_rrt_params prm;
-  std::mt19937 eng;
+  uint32_t* d_mt = nullptr;  // the problem's mt19937 on the device: 624 state words + position
   // device buffers
   double* d_tree = nullptr;
   uint32_t* d_parent = nullptr;
@@ -428,14 +479,12 @@ struct rkh_planner {
   NnArgs* d_nn_args = nullptr;
   EdgeIO* d_io_steer = nullptr;
   EdgeIO* d_io_probe = nullptr;
-  // pinned staging for the sample stream: [0] what the enqueued rounds need, [1] the next call's share, generated and
-  // copied while the GPU works on the rounds just enqueued
+  // segment tables of the sample generator: [0] what the enqueued rounds need, [1] the next call's share, generated
+  // while the GPU works on the rounds just enqueued
+  double* d_bounds = nullptr;  // lower[D], upper[D] of the sampled hyperbox
   struct Staging {
-    double* h = nullptr;        // pinned: the new samples of all problems, back to back
-    double* d = nullptr;        // the same on the device, before scatter_samples_kernel
     SampleSeg* h_tab = nullptr; // pinned segment table [P]
     SampleSeg* d_tab = nullptr;
-    size_t cap = 0;
     hipEvent_t done = nullptr;
     bool pending = false;
   } staging[2];
@@ -453,16 +502,14 @@ struct rkh_planner {
 
 namespace {
 
-// Extend every problem's device-resident sample stream by `ahead` samples beyond its (last known) cursor.
-// hyperbox_topology::random_point (hyperbox_topology.hpp:97-103): D draws of uniform_01 per sample,
-// uniform_01<mt19937&,double> = eng() * 2^-32 (Boost.Random; one 32-bit draw per coordinate).
-// All copies are asynchronous on the planner's copy stream out of one pinned staging buffer; the buffer's previous use
-// is awaited through its event, so no stream synchronisation happens here.
+// Extend every problem's device-resident sample stream by `ahead` samples beyond its (last known) cursor
+// (generate_samples_kernel).  The launch goes to the planner's second stream, beside the rounds already enqueued on the
+// first one; the table's previous use is awaited through its event, so no stream synchronisation happens here.
 rkh_status upload_samples_all(rkh_planner* p, uint64_t ahead, int which) {
   rkh_planner::Staging& sg = p->staging[which];
   const int D = p->D;
   std::vector<uint64_t> upto(p->P, 0);
-  size_t total = 0;
+  bool any = false;
   for (uint32_t i = 0; i < p->P; ++i) {
     Problem& q = p->prob[i];
     if (q.truncated || q.h_state.done == 1) continue;
@@ -470,9 +517,9 @@ rkh_status upload_samples_all(rkh_planner* p, uint64_t ahead, int which) {
     if (want > q.sample_cap) want = q.sample_cap;
     if (want <= q.samples_ready) continue;
     upto[i] = want;
-    total += size_t(want - q.samples_ready) * D;
+    any = true;
   }
-  if (total == 0) return RKH_OK;
+  if (!any) return RKH_OK;
   if (sg.pending) {
     RKH_HIP(hipEventSynchronize(sg.done));
     sg.pending = false;
@@ -482,47 +529,25 @@ rkh_status upload_samples_all(rkh_planner* p, uint64_t ahead, int which) {
     RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&sg.h_tab), p->P * sizeof(SampleSeg), hipHostMallocDefault));
     RKH_HIP(hipMalloc(&sg.d_tab, p->P * sizeof(SampleSeg)));
   }
-  if (total > sg.cap) {
-    if (sg.h) (void)hipHostFree(sg.h);
-    if (sg.d) (void)hipFree(sg.d);
-    sg.h = nullptr;
-    sg.d = nullptr;
-    sg.cap = total + total / 4;
-    RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&sg.h), sg.cap * sizeof(double), hipHostMallocDefault));
-    RKH_HIP(hipMalloc(&sg.d, sg.cap * sizeof(double)));
-  }
-  size_t off = 0;
   uint32_t n_seg = 0;
   for (uint32_t i = 0; i < p->P; ++i) {
     if (!upto[i]) continue;
     Problem& q = p->prob[i];
-    const uint64_t cnt = upto[i] - q.samples_ready;
-    double* dst = sg.h + off;
-    for (uint64_t k = 0; k < cnt; ++k)
-      for (int d = 0; d < D; ++d) {
-        double u;
-        do {
-          u = double(q.eng()) * (1.0 / 4294967296.0);
-        } while (!(u < 1.0));
-        dst[k * D + d] = p->lower[d] + u * (p->upper[d] - p->lower[d]);
-      }
     SampleSeg& seg = sg.h_tab[n_seg++];
     seg.dst = q.d_samples + q.samples_ready * D;
-    seg.src_off = off;
-    seg.count = cnt * D;
+    seg.count = (upto[i] - q.samples_ready) * D;
+    seg.mt = q.d_mt;
     seg.ready_ptr = &p->d_states[i].samples_ready;
     seg.ready_new = uint32_t(upto[i]);
     seg.pad = 0;
     q.samples_ready = upto[i];
-    off += size_t(cnt) * D;
   }
-  RKH_HIP(hipMemcpyAsync(sg.d, sg.h, off * sizeof(double), hipMemcpyHostToDevice, p->copy_stream));
   RKH_HIP(hipMemcpyAsync(sg.d_tab, sg.h_tab, n_seg * sizeof(SampleSeg), hipMemcpyHostToDevice, p->copy_stream));
-  hipLaunchKernelGGL(scatter_samples_kernel, dim3(n_seg), dim3(256), 0, p->copy_stream, sg.d_tab, sg.d);
+  hipLaunchKernelGGL(generate_samples_kernel, dim3(n_seg), dim3(256), 0, p->copy_stream, sg.d_tab, p->d_bounds, D);
   RKH_HIP(hipGetLastError());
-  // The copies run on their own stream, beside the rounds already enqueued on the planner stream: they write beyond every
-  // problem's samples_ready (no round reads there) and then raise samples_ready (a round that sees the old value just
-  // takes a smaller batch).  Work enqueued on the planner stream from here on waits for them.
+  // The generator runs on its own stream, beside the rounds already enqueued on the planner stream: it writes beyond every
+  // problem's samples_ready (no round reads there) and then raises samples_ready.  Work enqueued on the planner stream
+  // from here on waits for it.
   RKH_HIP(hipEventRecord(sg.done, p->copy_stream));
   RKH_HIP(hipStreamWaitEvent(p->stream, sg.done, 0));
   sg.pending = true;
@@ -652,7 +677,7 @@ rkh_status enqueue_round(rkh_planner* p) {
 void free_problem(Problem& q) {
   void* bufs[] = {q.d_tree, q.d_parent, q.d_node_sample, q.d_goal_dist, q.d_samples, q.d_nn_seq, q.d_accept_log,
                   q.d_nn_idx, q.d_nn_dist, q.d_x_out, q.d_steps, q.d_accept, q.d_probe_x, q.d_probe_steps, q.d_goal,
-                  q.d_part_dist, q.d_part_idx, q.d_round_n};
+                  q.d_part_dist, q.d_part_idx, q.d_round_n, q.d_mt};
   for (void* b : bufs) (void)hipFree(b);
 }
 
@@ -727,6 +752,15 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   RKH_HIP(hipSetDevice(scene->ctx->device));
   RKH_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   RKH_HIP(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+  {
+    std::vector<double> bounds(2 * p->D);
+    for (int d = 0; d < p->D; ++d) {
+      bounds[d] = p->lower[d];
+      bounds[p->D + d] = p->upper[d];
+    }
+    RKH_HIP(hipMalloc(&p->d_bounds, bounds.size() * sizeof(double)));
+    RKH_HIP(hipMemcpy(p->d_bounds, bounds.data(), bounds.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   if (const char* e = getenv("RKH_LANE_VARIANT")) p->lane_variant = (atoi(e) == 1) ? 1 : 2;
   if (const char* e = getenv("RKH_WAVE_FIT")) p->wave_fit = atoi(e);
   if (const char* e = getenv("RKH_WAVE_FILL")) p->wave_fill = atof(e);
@@ -793,7 +827,14 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   for (uint32_t i = 0; i < P; ++i) {
     Problem& q = p->prob[i];
     q.prm = prms[i];
-    q.eng.seed(prms[i].seed);
+    {  // get_global_rng().seed(s): std::mt19937 / boost::mt19937 seeding, position at the end of the state
+      std::vector<uint32_t> mt(kMtN + 1);
+      mt[0] = uint32_t(prms[i].seed);
+      for (int k = 1; k < kMtN; ++k) mt[k] = 1812433253u * (mt[k - 1] ^ (mt[k - 1] >> 30)) + uint32_t(k);
+      mt[kMtN] = uint32_t(kMtN);
+      RKH_HIP(hipMalloc(&q.d_mt, mt.size() * sizeof(uint32_t)));
+      RKH_HIP(hipMemcpy(q.d_mt, mt.data(), mt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     const uint64_t max_total = uint64_t(prms[i].max_vertices) + 1;
     q.capacity = (max_total + 255) / 256 * 256;
     RKH_HIP(hipMalloc(&q.d_tree, q.capacity * DP * sizeof(double)));
@@ -932,8 +973,6 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   (void)hipFree(p->d_io_probe);
   for (auto& sg : p->staging) {
     if (sg.pending) (void)hipEventSynchronize(sg.done);
-    if (sg.h) (void)hipHostFree(sg.h);
-    if (sg.d) (void)hipFree(sg.d);
     if (sg.h_tab) (void)hipHostFree(sg.h_tab);
     if (sg.d_tab) (void)hipFree(sg.d_tab);
     if (sg.done) (void)hipEventDestroy(sg.done);
@@ -946,6 +985,7 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   for (hipEvent_t e : p->ev_steer) (void)hipEventDestroy(e);
   (void)hipStreamSynchronize(p->copy_stream);
   (void)hipStreamDestroy(p->copy_stream);
+  if (p->d_bounds) (void)hipFree(p->d_bounds);
   if (p->h_gd) (void)hipHostFree(p->h_gd);
   if (p->h_gd_tab) (void)hipHostFree(p->h_gd_tab);
   if (p->d_gd_tab) (void)hipFree(p->d_gd_tab);
