@@ -72,7 +72,11 @@ enum rkh_shape_kind {
   /* shape_2D subclasses (geometry/shapes/{circle,rectangle,capped_rectangle}.hpp), pose = pose_2D (see above) */
   RKH_SHAPE_CIRCLE = 4,    /* dims[0] = radius                                                      */
   RKH_SHAPE_RECTANGLE = 5, /* dims[0..1] = full side lengths (mDimensions)                          */
-  RKH_SHAPE_CRECT = 6      /* capped_rectangle: dims[0] = length along local x, dims[1] = width = cap diameter */
+  RKH_SHAPE_CRECT = 6,     /* capped_rectangle: dims[0] = length along local x, dims[1] = width = cap diameter */
+  /* more shape_3D subclasses (geometry/shapes/{plane,cylinder}.hpp) */
+  RKH_SHAPE_PLANE = 7,     /* dims[0..1] = mDimensions (x, y extents; they only enter the bounding radius of the cull:
+                            * the enabled prox_plane_* routines treat the plane as infinite), normal = local z          */
+  RKH_SHAPE_CYLINDER = 8   /* dims[0] = length, dims[1] = radius (flat ends, axis = local z)                          */
 };
 
 typedef struct rkh_shape {

@@ -200,7 +200,7 @@ double orc_pair_distance(const rkh_shape* a, const rkh_shape* b) {
   std::vector<rkh_shape> sh = {*a, *b};
   sh[0].anchor = 0;  // model 1
   sh[1].anchor = -1; // model 2
-  if (sh[0].kind >= RKH_SHAPE_CIRCLE || sh[1].kind >= RKH_SHAPE_CIRCLE) {  // planar pair (proxy_query_pair_2D)
+  if ((sh[0].kind >= RKH_SHAPE_CIRCLE && sh[0].kind <= RKH_SHAPE_CRECT) || (sh[1].kind >= RKH_SHAPE_CIRCLE && sh[1].kind <= RKH_SHAPE_CRECT)) {  // planar pair (proxy_query_pair_2D)
     std::vector<ProxFinder2> f2;
     createProxFinderList2D(sh, {0}, {1}, f2);
     if (f2.empty()) return std::numeric_limits<double>::quiet_NaN();

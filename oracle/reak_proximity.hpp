@@ -42,6 +42,13 @@ struct ShapeG {
         return std::sqrt(s) * 0.5;
       }
       case RKH_SHAPE_CCYLINDER: return dims[0] * 0.5 + dims[1];
+      case RKH_SHAPE_PLANE: {  // plane.cpp:31-33: norm_2(mDimensions) * 0.5
+        double s = 0.0;
+        for (int i = 0; i < 2; ++i) s += dims[i] * dims[i];
+        return std::sqrt(s) * 0.5;
+      }
+      case RKH_SHAPE_CYLINDER:  // cylinder.cpp:33-35
+        return std::sqrt(dims[1] * dims[1] + 0.25 * dims[0] * dims[0]);
     }
     return 0.0;
   }
@@ -254,27 +261,211 @@ inline ProxRecord prox_ccylinder_box(const ShapeG& cc, const ShapeG& bx) {
   return r;
 }
 
+// ---- the plane / cylinder finders enabled in createProxFinderList (proxy_query_model.cpp:226-300) ----------------
+// pose_3D::rotateToGlobal = Quat * V, rotateFromGlobal = invert(Quat) * V (pose_3D.hpp:154-170)
+
+// prox_plane_sphere::computeProximity: prox_plane_sphere.cpp:106-122 (the infinite-plane version; the finite one is
+// commented out in the reference)
+inline ProxRecord prox_plane_sphere(const ShapeG& pl, const ShapeG& sp) {
+  ProxRecord r;
+  V3 sp_c = sp.g.transformToParent(V3(0, 0, 0));
+  V3 sp_c_rel = pl.g.transformFromParent(sp_c);
+  r.mPoint1 = pl.g.transformToParent(V3(sp_c_rel[0], sp_c_rel[1], 0.0));
+  r.mPoint2 = pl.g.transformToParent(V3(sp_c_rel[0], sp_c_rel[1], sp_c_rel[2] - sp.dims[0]));
+  r.mDistance = sp_c_rel[2] - sp.dims[0];
+  return r;
+}
+
+// prox_plane_box::computeProximity: prox_plane_box.cpp:43-71.  The reference builds bx_x, bx_y and bx_z all from the
+// box's local x axis (1,0,0) (:53-55); kept as is.
+inline ProxRecord prox_plane_box(const ShapeG& pl, const ShapeG& bx) {
+  ProxRecord r;
+  V3 bx_c = bx.g.transformToParent(V3(0, 0, 0));
+  V3 bx_x = invert(pl.g.Q) * (bx.g.Q * V3(1.0, 0.0, 0.0));
+  V3 bx_y = invert(pl.g.Q) * (bx.g.Q * V3(1.0, 0.0, 0.0));
+  V3 bx_z = invert(pl.g.Q) * (bx.g.Q * V3(1.0, 0.0, 0.0));
+  if (bx_x[2] > 0.0) bx_x = -bx_x;
+  if (bx_y[2] > 0.0) bx_y = -bx_y;
+  if (bx_z[2] > 0.0) bx_z = -bx_z;
+  V3 bx_c_rel = pl.g.transformFromParent(bx_c);
+  V3 bx_pt_rel = bx_c_rel + 0.5 * (bx.dims[0] * bx_x + bx.dims[1] * bx_y + bx.dims[2] * bx_z);
+  r.mPoint1 = pl.g.transformToParent(V3(bx_pt_rel[0], bx_pt_rel[1], 0.0));
+  r.mPoint2 = pl.g.transformToParent(bx_pt_rel);
+  r.mDistance = bx_pt_rel[2];
+  return r;
+}
+
+// prox_plane_ccylinder::computeProximity: prox_plane_ccylinder.cpp:43-74
+inline ProxRecord prox_plane_ccylinder(const ShapeG& pl, const ShapeG& cc) {
+  ProxRecord r;
+  const double L = cc.dims[0], R = cc.dims[1];
+  V3 cy_c = cc.g.transformToParent(V3(0, 0, 0));
+  V3 cy_t = cc.g.Q * V3(0.0, 0.0, 1.0);
+  V3 cy_c_rel = pl.g.transformFromParent(cy_c);
+  V3 cy_t_rel = invert(pl.g.Q) * cy_t;
+  if (std::fabs(cy_t_rel[2]) < 1e-6) {
+    r.mPoint1 = pl.g.transformToParent(V3(cy_c_rel[0], cy_c_rel[1], 0.0));
+    r.mPoint2 = pl.g.transformToParent(V3(cy_c_rel[0], cy_c_rel[1], cy_c_rel[2] - R));
+    r.mDistance = cy_c_rel[2] - R;
+  } else {
+    if (cy_t_rel[2] > 0.0) cy_t_rel = -cy_t_rel;
+    V3 cypt_rel = cy_c_rel + (0.5 * L) * cy_t_rel + V3(0.0, 0.0, -R);
+    r.mPoint1 = pl.g.transformToParent(V3(cypt_rel[0], cypt_rel[1], 0.0));
+    r.mPoint2 = pl.g.transformToParent(cypt_rel);
+    r.mDistance = cypt_rel[2];
+  }
+  return r;
+}
+
+// prox_plane_cylinder::computeProximity: prox_plane_cylinder.cpp:42-78
+inline ProxRecord prox_plane_cylinder(const ShapeG& pl, const ShapeG& cy) {
+  ProxRecord r;
+  const double L = cy.dims[0], R = cy.dims[1];
+  V3 cy_c = cy.g.transformToParent(V3(0, 0, 0));
+  V3 cy_t = cy.g.Q * V3(0.0, 0.0, 1.0);
+  V3 cy_c_rel = pl.g.transformFromParent(cy_c);
+  V3 cy_t_rel = invert(pl.g.Q) * cy_t;
+  if (std::fabs(cy_t_rel[2]) < 1e-6) {
+    r.mPoint1 = pl.g.transformToParent(V3(cy_c_rel[0], cy_c_rel[1], 0.0));
+    r.mPoint2 = pl.g.transformToParent(V3(cy_c_rel[0], cy_c_rel[1], cy_c_rel[2] - R));
+    r.mDistance = cy_c_rel[2] - R;
+  } else if (std::sqrt(cy_t_rel[0] * cy_t_rel[0] + cy_t_rel[1] * cy_t_rel[1]) < 1e-6) {
+    r.mPoint1 = pl.g.transformToParent(V3(cy_c_rel[0], cy_c_rel[1], 0.0));
+    r.mPoint2 = pl.g.transformToParent(V3(cy_c_rel[0], cy_c_rel[1], cy_c_rel[2] - 0.5 * L));
+    r.mDistance = cy_c_rel[2] - 0.5 * L;
+  } else {
+    if (cy_t_rel[2] > 0.0) cy_t_rel = -cy_t_rel;
+    V3 cy_r_rel = unit(V3(0.0, 0.0, -1.0) + cy_t_rel[2] * cy_t_rel);
+    V3 cypt_rel = cy_c_rel + (0.5 * L) * cy_t_rel + R * cy_r_rel;
+    r.mPoint1 = pl.g.transformToParent(V3(cypt_rel[0], cypt_rel[1], 0.0));
+    r.mPoint2 = pl.g.transformToParent(cypt_rel);
+    r.mDistance = cypt_rel[2];
+  }
+  return r;
+}
+
+// prox_plane_plane::computeProximityOfPoint: prox_plane_plane.cpp:43-95 (here the plane IS finite)
+inline void plane_proximity_of_point(const ShapeG& pl, const V3& aPoint, V3& aPointRec, double& aDistance) {
+  V3 pt_rel = pl.g.transformFromParent(aPoint);
+  const double hx = 0.5 * pl.dims[0], hy = 0.5 * pl.dims[1];
+  if ((pt_rel[0] > -hx) && (pt_rel[0] < hx) && (pt_rel[1] > -hy) && (pt_rel[1] < hy)) {
+    double fact = 1.0;
+    if (pt_rel[2] < 0.0) fact = -1.0;
+    aPointRec = pl.g.transformToParent(V3(pt_rel[0], pt_rel[1], 0.0));
+    aDistance = fact * pt_rel[2];
+  } else {
+    if ((pt_rel[0] > -hx) && (pt_rel[0] < hx)) {
+      double fact = 1.0;
+      if (pt_rel[1] < 0.0) fact = -1.0;
+      aPointRec = pl.g.transformToParent(V3(pt_rel[0], fact * 0.5 * pl.dims[1], 0.0));
+    } else if ((pt_rel[1] > -hy) && (pt_rel[1] < hy)) {
+      double fact = 1.0;
+      if (pt_rel[0] < 0.0) fact = -1.0;
+      aPointRec = pl.g.transformToParent(V3(fact * 0.5 * pl.dims[0], pt_rel[1], 0.0));
+    } else {
+      V3 rim_pt(0.5 * pl.dims[0], 0.5 * pl.dims[1], 0.0);
+      if (pt_rel[0] < 0.0) rim_pt[0] = -rim_pt[0];
+      if (pt_rel[1] < 0.0) rim_pt[1] = -rim_pt[1];
+      aPointRec = pl.g.transformToParent(rim_pt);
+    }
+    aDistance = norm_2(aPointRec - aPoint);
+  }
+}
+
+// prox_plane_plane::computeProximity: prox_plane_plane.cpp:98-183 (the four corners of plane 2 against plane 1, then
+// the four corners of plane 1 against plane 2; corner order (+,+), (+,-), (-,-), (-,+))
+inline ProxRecord prox_plane_plane(const ShapeG& p1, const ShapeG& p2) {
+  ProxRecord r;  // mDistance = +inf
+  V3 temp_pt;
+  double temp_dist;
+  for (int side = 0; side < 2; ++side) {
+    const ShapeG& of = side == 0 ? p2 : p1;       // whose corners
+    const ShapeG& against = side == 0 ? p1 : p2;  // tested against
+    V3 corner(0.5 * of.dims[0], 0.5 * of.dims[1], 0.0);
+    for (int k = 0; k < 4; ++k) {
+      if (k == 1 || k == 3) corner[1] = -corner[1];
+      if (k == 2) corner[0] = -corner[0];
+      V3 corner_gbl = of.g.transformToParent(corner);
+      plane_proximity_of_point(against, corner_gbl, temp_pt, temp_dist);
+      if (temp_dist < r.mDistance) {
+        r.mDistance = temp_dist;
+        if (side == 0) { r.mPoint1 = temp_pt; r.mPoint2 = corner_gbl; }
+        else { r.mPoint2 = temp_pt; r.mPoint1 = corner_gbl; }
+      }
+    }
+  }
+  return r;
+}
+
+// prox_sphere_cylinder::computeProximity: prox_sphere_cylinder.cpp:43-92
+inline ProxRecord prox_sphere_cylinder(const ShapeG& sp, const ShapeG& cy) {
+  ProxRecord r;
+  const double L = cy.dims[0], R = cy.dims[1], sr = sp.dims[0];
+  V3 sp_c = sp.g.transformToParent(V3(0, 0, 0));
+  V3 sp_c_rel = cy.g.transformFromParent(sp_c);
+  double sp_c_rel_rad = std::sqrt(sp_c_rel[0] * sp_c_rel[0] + sp_c_rel[1] * sp_c_rel[1]);
+  if (std::fabs(sp_c_rel[2]) <= 0.5 * L) {
+    V3 sp_c_proj(sp_c_rel[0], sp_c_rel[1], 0.0);
+    double sp_c_proj_d = norm_2(sp_c_proj);
+    r.mPoint2 = cy.g.transformToParent(V3(0.0, 0.0, sp_c_rel[2]) + sp_c_proj * (R / sp_c_proj_d));
+    r.mPoint1 = cy.g.transformToParent(sp_c_rel - sp_c_proj * (sr / sp_c_proj_d));
+    r.mDistance = sp_c_proj_d - sr - R;
+  } else if (sp_c_rel_rad < R) {
+    double fact = 1.0;
+    if (sp_c_rel[2] < 0.0) fact = -1.0;
+    r.mPoint2 = cy.g.transformToParent(V3(sp_c_rel[0], sp_c_rel[1], fact * 0.5 * L));
+    r.mPoint1 = cy.g.transformToParent(V3(sp_c_rel[0], sp_c_rel[1], sp_c_rel[2] - fact * sr));
+    r.mDistance = fact * sp_c_rel[2] - 0.5 * L - sr;
+  } else {
+    V3 sp_c_proj(sp_c_rel[0], sp_c_rel[1], 0.0);
+    double sp_c_proj_d = norm_2(sp_c_proj);
+    double fact = 1.0;
+    if (sp_c_rel[2] < 0.0) fact = -1.0;
+    V3 rim_pt = (R / sp_c_proj_d) * sp_c_proj + V3(0.0, 0.0, fact * 0.5 * L);
+    r.mPoint2 = cy.g.transformToParent(rim_pt);
+    sp_c_proj = r.mPoint2 - sp_c;
+    sp_c_proj_d = norm_2(sp_c_proj);
+    r.mPoint1 = sp_c + (sr / sp_c_proj_d) * sp_c_proj;
+    r.mDistance = sp_c_proj_d - sr;
+  }
+  return r;
+}
+
 // One entry of proxy_query_pair_3D::mProxFinders: which closed form, and (shape1, shape2) in the
 // finder's own argument order (createProxFinderList: proxy_query_model.cpp:215-374).
 struct ProxFinder {
-  int routine;  // 1 sphere-sphere, 2 sphere-ccyl, 3 sphere-box, 4 ccyl-ccyl, 5 ccyl-box
+  // 1 sphere-sphere, 2 sphere-ccyl, 3 sphere-box, 4 ccyl-ccyl, 5 ccyl-box,
+  // 6 plane-plane, 7 plane-sphere, 8 plane-ccyl, 9 plane-cylinder, 10 plane-box, 11 sphere-cylinder
+  int routine;
   int s1, s2;   // indices into the combined shape table
 };
 
-// createProxFinderList: i-major / j-minor over (model1 shapes, model2 shapes); pairs without an
-// implemented routine (box-box; anything with the disabled cylinder) produce no finder.
+// createProxFinderList: i-major / j-minor over (model1 shapes, model2 shapes), the reference's cascade of kinds (plane,
+// then sphere, then capped cylinder, then cylinder, then box: proxy_query_model.cpp:225-370); pairs without an enabled
+// routine (ccyl-cylinder :317-320, cylinder-cylinder :341-344, cylinder-box :346-349, box-box :366-369) produce no
+// finder.
 inline void createProxFinderList(const std::vector<rkh_shape>& shapes, const std::vector<int>& model1,
                                  const std::vector<int>& model2, std::vector<ProxFinder>& out) {
   out.clear();
   for (int i : model1)
     for (int j : model2) {
       const int ki = shapes[i].kind, kj = shapes[j].kind;
-      if (ki == RKH_SHAPE_SPHERE || kj == RKH_SHAPE_SPHERE) {
+      if (ki == RKH_SHAPE_PLANE || kj == RKH_SHAPE_PLANE) {
+        int pl = (ki == RKH_SHAPE_PLANE) ? i : j;
+        int other = (ki == RKH_SHAPE_PLANE) ? j : i;
+        int ko = shapes[other].kind;
+        if (ko == RKH_SHAPE_PLANE) out.push_back({6, pl, other});
+        else if (ko == RKH_SHAPE_SPHERE) out.push_back({7, pl, other});
+        else if (ko == RKH_SHAPE_CCYLINDER) out.push_back({8, pl, other});
+        else if (ko == RKH_SHAPE_CYLINDER) out.push_back({9, pl, other});
+        else if (ko == RKH_SHAPE_BOX) out.push_back({10, pl, other});
+      } else if (ki == RKH_SHAPE_SPHERE || kj == RKH_SHAPE_SPHERE) {
         int sp = (ki == RKH_SHAPE_SPHERE) ? i : j;
         int other = (ki == RKH_SHAPE_SPHERE) ? j : i;
         int ko = shapes[other].kind;
         if (ko == RKH_SHAPE_SPHERE) out.push_back({1, sp, other});
         else if (ko == RKH_SHAPE_CCYLINDER) out.push_back({2, sp, other});
+        else if (ko == RKH_SHAPE_CYLINDER) out.push_back({11, sp, other});
         else if (ko == RKH_SHAPE_BOX) out.push_back({3, sp, other});
       } else if (ki == RKH_SHAPE_CCYLINDER || kj == RKH_SHAPE_CCYLINDER) {
         int cc = (ki == RKH_SHAPE_CCYLINDER) ? i : j;
@@ -283,7 +474,7 @@ inline void createProxFinderList(const std::vector<rkh_shape>& shapes, const std
         if (ko == RKH_SHAPE_CCYLINDER) out.push_back({4, cc, other});
         else if (ko == RKH_SHAPE_BOX) out.push_back({5, cc, other});
       }
-      // box-box: no finder (proxy_query_model.cpp:367, prox_box_box.cpp:24-34)
+      // cylinder-cylinder, cylinder-box, box-box: no finder
     }
 }
 
@@ -294,6 +485,12 @@ inline ProxRecord computeProximity(const ProxFinder& f, const std::vector<ShapeG
     case 3: return prox_sphere_box(g[f.s1], g[f.s2]);
     case 4: return prox_ccylinder_ccylinder(g[f.s1], g[f.s2]);
     case 5: return prox_ccylinder_box(g[f.s1], g[f.s2]);
+    case 6: return prox_plane_plane(g[f.s1], g[f.s2]);
+    case 7: return prox_plane_sphere(g[f.s1], g[f.s2]);
+    case 8: return prox_plane_ccylinder(g[f.s1], g[f.s2]);
+    case 9: return prox_plane_cylinder(g[f.s1], g[f.s2]);
+    case 10: return prox_plane_box(g[f.s1], g[f.s2]);
+    case 11: return prox_sphere_cylinder(g[f.s1], g[f.s2]);
   }
   return ProxRecord();
 }
@@ -333,7 +530,7 @@ struct ProxyEnv {
   ProxyEnv() {}
   ProxyEnv(const rkh_shape* s, int n) : shapes(s, s + n) {
     for (int i = 0; i < n; ++i) (shapes[i].anchor >= 0 ? robot : env).push_back(i);
-    for (int i = 0; i < n; ++i) planar = planar || shapes[i].kind >= RKH_SHAPE_CIRCLE;
+    for (int i = 0; i < n; ++i) planar = planar || (shapes[i].kind >= RKH_SHAPE_CIRCLE && shapes[i].kind <= RKH_SHAPE_CRECT);
     if (planar) createProxFinderList2D(shapes, robot, env, finders2);
     else createProxFinderList(shapes, robot, env, finders);
   }

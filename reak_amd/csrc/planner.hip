@@ -681,6 +681,38 @@ void free_problem(Problem& q) {
   for (void* b : bufs) (void)hipFree(b);
 }
 
+// generate_rrt has no iteration cap (rr_tree.hpp:192-196: keep_going() looks at the vertex count only), so the device-
+// resident sample stream and its per-iteration logs must not have one either: when a problem's cursor comes near the
+// end of its buffers they are re-allocated at twice the size.  Called with both streams idle (rkh_planner_sync).
+rkh_status grow_sample_buffers(rkh_planner* p, uint32_t i, uint64_t new_cap) {
+  Problem& q = p->prob[i];
+  const int D = p->D;
+  double* ns = nullptr;
+  uint32_t* nq = nullptr;
+  uint8_t* na = nullptr;
+  RKH_HIP(hipMalloc(&ns, new_cap * D * sizeof(double)));
+  RKH_HIP(hipMalloc(&nq, new_cap * sizeof(uint32_t)));
+  RKH_HIP(hipMalloc(&na, new_cap));
+  RKH_HIP(hipMemcpy(ns, q.d_samples, q.samples_ready * D * sizeof(double), hipMemcpyDeviceToDevice));
+  RKH_HIP(hipMemcpy(nq, q.d_nn_seq, q.sample_cap * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+  RKH_HIP(hipMemcpy(na, q.d_accept_log, q.sample_cap, hipMemcpyDeviceToDevice));
+  (void)hipFree(q.d_samples);
+  (void)hipFree(q.d_nn_seq);
+  (void)hipFree(q.d_accept_log);
+  q.d_samples = ns;
+  q.d_nn_seq = nq;
+  q.d_accept_log = na;
+  q.sample_cap = new_cap;
+  // the device tables that point into these buffers
+  const double* cs = ns;
+  RKH_HIP(hipMemcpy(&p->d_probs[i].samples, &cs, sizeof(cs), hipMemcpyHostToDevice));
+  RKH_HIP(hipMemcpy(&p->d_probs[i].nn_seq, &nq, sizeof(nq), hipMemcpyHostToDevice));
+  RKH_HIP(hipMemcpy(&p->d_probs[i].accept_log, &na, sizeof(na), hipMemcpyHostToDevice));
+  RKH_HIP(hipMemcpy(&p->d_nn_args[i].q, &cs, sizeof(cs), hipMemcpyHostToDevice));
+  RKH_HIP(hipMemcpy(&p->d_io_steer[i].tgt, &cs, sizeof(cs), hipMemcpyHostToDevice));
+  return RKH_OK;
+}
+
 rkh_status read_states(rkh_planner* p) {
   std::vector<PlannerState> hs(p->P);
   RKH_HIP(hipMemcpyAsync(hs.data(), p->d_states, p->P * sizeof(PlannerState), hipMemcpyDeviceToHost, p->stream));
@@ -776,7 +808,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   if (const char* e = getenv("RKH_LANE_THRESHOLD")) p->lane_threshold = uint32_t(std::max(0, atoi(e)));
   if (const char* e = getenv("RKH_LANES_PER_EDGE")) {
     p->lanes_per_edge = (atoi(e) == 1) ? 1 : ((atoi(e) == 2) ? 2 : ((atoi(e) == 16) ? 16 : (atoi(e) == 0 ? 0 : 64)));
-  } else if (p->n_dof <= 6 && scene_fits_lane_kernel(scene->host)) {
+  } else if (p->n_dof <= 6 && scene_fits_lane_kernel(scene->host, p->lane_variant)) {
     p->lanes_per_edge = 0;  // automatic, per round
   } else {
     // one wavefront per candidate is the latency-optimal mapping; once a round can offer more waves than the chip
@@ -784,7 +816,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     p->lanes_per_edge = (uint64_t(n_problems) * 2 * p->b_max > 4096) ? 16 : 64;
   }
   if ((p->lanes_per_edge == 1 || p->lanes_per_edge == 2 || p->lanes_per_edge == 0) &&
-      !(p->n_dof <= 7 && scene_fits_lane_kernel(scene->host)))
+      !(p->n_dof <= 7 && scene_fits_lane_kernel(scene->host, p->lanes_per_edge == 1 ? 1 : p->lane_variant)))
     p->lanes_per_edge = 64;  // the two-lanes-per-edge kernel does not take this scene
   if (p->lanes_per_edge == 16 && 2 * p->n_dof > 16) p->lanes_per_edge = 64;  // a 16-lane group holds at most 16 components
   if (const char* e = getenv("RKH_PROFILE_NN")) p->profile_nn = atoi(e) != 0;
@@ -1136,6 +1168,11 @@ rkh_status rkh_planner_sync(rkh_planner* p, rkh_planner_stats* stats) {
   for (uint32_t i = 0; i < p->P; ++i) {
     Problem& q = p->prob[i];
     PlannerState& hs = q.h_state;
+    if (!q.truncated && hs.done != 1 && uint64_t(hs.s0) + 64ull * p->b_max > q.sample_cap) {
+      RKH_HIP(hipStreamSynchronize(p->copy_stream));
+      const rkh_status gs = grow_sample_buffers(p, i, std::max<uint64_t>(2 * q.sample_cap, uint64_t(hs.s0) + 256ull * p->b_max));
+      if (gs != RKH_OK) return gs;
+    }
     if (hs.done == 2 && q.samples_ready < q.sample_cap) {  // sample stream ran dry mid-enqueue: refill and carry on
       hs.done = 0;
       RKH_HIP(hipMemcpy(&p->d_states[i].done, &hs.done, sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1242,7 +1279,7 @@ rkh_status rkh_planner_solve(rkh_planner* p, rkh_planner_stats* stats) {
       if (!local[i].done) all = false;
       Problem& q = p->prob[i];
       if (!local[i].done && q.samples_ready >= q.sample_cap && q.h_state.s0 + p->b_max > q.sample_cap) {
-        set_error("planner: sample stream capacity exhausted (raise RKH_SAMPLE_CAP)");
+        set_error("planner: sample stream buffers did not grow (out of device memory?)");  // rkh_planner_sync grows them
         return RKH_ERR_CAPACITY;
       }
     }

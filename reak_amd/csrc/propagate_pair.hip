@@ -431,7 +431,7 @@ RKH_DI void pair_drain_q2(ScenePtr sc, PairLds<N>& lds) {
     if (lds.hit[e] == 0u) {
       const ShapeG A = pair_robot_pose<N>(sc, lds, e, r);
       const ShapeG Bv = pair_env_shape(sc->env[o]);
-      const double d = (A.kind == RKH_SHAPE_CCYLINDER) ? dist_ccyl_box(A, Bv) : dist_ccyl_box(Bv, A);
+      const double d = (A.kind == RKH_SHAPE_CCYLINDER) ? dist_ccyl_box(A, Bv) : dist_ccyl_box(Bv, A);  // PR_CCYL_BOX only
       if (d < 0.0) lds.hit[e] = 1u;
     }
   }
@@ -453,15 +453,15 @@ RKH_DI void pair_drain_q1(ScenePtr sc, PairLds<N>& lds) {
       if (lds.hit[e] == 0u) {
         const ShapeG A = pair_robot_pose<N>(sc, lds, e, r);
         const ShapeG Bv = pair_env_shape(sc->env[o]);
-        const bool a_sphere = (A.kind == RKH_SHAPE_SPHERE), a_ccyl = (A.kind == RKH_SHAPE_CCYLINDER);
-        const bool b_sphere = (Bv.kind == RKH_SHAPE_SPHERE), b_ccyl = (Bv.kind == RKH_SHAPE_CCYLINDER);
-        if ((a_ccyl && !b_sphere && !b_ccyl) || (b_ccyl && !a_sphere && !a_ccyl)) {
+        bool a_first = true;
+        const int rt = pair_routine(A.kind, Bv.kind, &a_first);  // createProxFinderList's cascade of kinds
+        if (rt == PR_CCYL_BOX) {
           // capped cylinder against a box = a golden-section search along the axis (prox_fundamentals_3D.cpp:108-115).
           // Every value that search can return is the distance of SOME point of the axis segment to the box, so a lower
           // bound over the segment that already exceeds the radius settles "no collision" without it: separation along the
           // box's own axes, |c_k| - hl |t_k| - half_k, in the box frame (fp64, margin 1e-9).
-          const ShapeG& cc = a_ccyl ? A : Bv;
-          const ShapeG& bx = a_ccyl ? Bv : A;
+          const ShapeG& cc = a_first ? A : Bv;
+          const ShapeG& bx = a_first ? Bv : A;
           const d3 cy_c = pose_to_parent(cc.pos, cc.q, mk3(0, 0, 0));
           const d3 cy_t = qrot(cc.q, mk3(0.0, 0.0, 1.0));
           const d4 bq = qinv(bx.q);
@@ -472,11 +472,8 @@ RKH_DI void pair_drain_q1(ScenePtr sc, PairLds<N>& lds) {
           const double gy = fabs(crel.y) - fabs(trel.y) * hl - 0.5 * bx.d1;
           const double gz = fabs(crel.z) - fabs(trel.z) * hl - 0.5 * bx.d2;
           golden = !(fmax(gx, fmax(gy, gz)) > cc.d1 + 1e-9);
-        } else {
-          double d;
-          if (b_sphere) d = a_sphere ? dist_sphere_sphere(A, Bv) : (a_ccyl ? dist_sphere_ccyl(Bv, A) : dist_sphere_box(Bv, A));
-          else if (b_ccyl) d = a_sphere ? dist_sphere_ccyl(A, Bv) : dist_ccyl_ccyl(A, Bv);
-          else d = dist_sphere_box(A, Bv);  // box obstacle: only a sphere gets here (box-box has no finder)
+        } else if (rt != PR_NONE) {
+          const double d = a_first ? pair_distance(rt, A, Bv) : pair_distance(rt, Bv, A);
           if (d < 0.0) lds.hit[e] = 1u;
         }
       }
@@ -562,8 +559,7 @@ __device__ __forceinline__ bool pair_proximity_free(ScenePtr sc_in, PairLds<N>& 
     const int rc = (r < n_robot) ? r : r0;
     const ShapeG A = pair_robot_pose<N>(sc, lds, el, rc);
     const d3 ca = pose_to_parent(A.pos, A.q, mk3(0, 0, 0));
-    const bool a_sphere = (A.kind == RKH_SHAPE_SPHERE), a_ccyl = (A.kind == RKH_SHAPE_CCYLINDER);
-    const bool a_box = !a_sphere && !a_ccyl;
+    const bool a_ccyl = (A.kind == RKH_SHAPE_CCYLINDER);
     // capped cylinder: its axis segment (for the cull below)
     const d3 a_ax = qrot(A.q, mk3(0.0, 0.0, 1.0));
     const double ra = sc->robot[rc].brad;
@@ -575,7 +571,7 @@ __device__ __forceinline__ bool pair_proximity_free(ScenePtr sc_in, PairLds<N>& 
 #pragma unroll 1
     for (int o0 = 0; o0 < n_scan; o0 += 64) {
       const int on = (n_scan - o0 < 64) ? n_scan - o0 : 64;
-      const unsigned long long k_box = sc->env_kind_mask[1][o0 >> 6];
+      const unsigned long long has_finder = sc->env_finder_mask[A.kind][o0 >> 6];  // per lane (its shape's kind)
       // Cull, one bit per surviving obstacle.  Lane l fetches the cull record of obstacle o0 + l once; the uniform loop
       // over the obstacles reads it back with v_readlane (no memory latency in the loop).  A pair is dropped only if a
       // lower bound on its distance is positive -- the bounding-sphere test of proxy_query_model.cpp:384-389 or, for
@@ -610,10 +606,10 @@ __device__ __forceinline__ bool pair_proximity_free(ScenePtr sc_in, PairLds<N>& 
         const unsigned nib = cull_one(i) | (cull_one(i + 1) << 1) | (cull_one(i + 2) << 2) | (cull_one(i + 3) << 3);
         mask |= (unsigned long long)nib << i;
       }
-      // obstacles past this lane's own reach; box-box has no finder in the reference (proxy_query_model.cpp:367)
+      // obstacles past this lane's own reach; pairs of kinds the reference has no finder for
       const int mine = my_reach - o0;
       mask &= (mine >= 64) ? ~0ull : (mine <= 0 ? 0ull : ((1ull << mine) - 1ull));
-      mask &= a_box ? ~k_box : ~0ull;
+      mask &= has_finder;
       if (!have) mask = 0ull;
       // survivors -> first queue.  A lane whose entries do not all fit writes placeholders into the part of its range
       // that lies inside the queue and keeps its mask for the next turn.

@@ -9,6 +9,7 @@
 //   with golden_section_search_impl (core/optimization/line_search.hpp:71-95).
 // Only the distance is produced (mPoint1/mPoint2 are not needed for the verdict).
 #pragma once
+#include "../../include/rkh_types.h"
 #include "device_math.h"
 
 namespace rkh {
@@ -20,7 +21,48 @@ struct ShapeG {  // shape with resolved global pose
   double d0, d1, d2;  // dims
 };
 
-enum PairRoutine : int { PR_SPHERE_SPHERE = 1, PR_SPHERE_CCYL = 2, PR_SPHERE_BOX = 3, PR_CCYL_CCYL = 4, PR_CCYL_BOX = 5 };
+enum PairRoutine : int {
+  PR_NONE = 0,  // the reference has no finder for the pair (proxy_query_model.cpp:317-320,341-349,366-369)
+  PR_SPHERE_SPHERE = 1, PR_SPHERE_CCYL = 2, PR_SPHERE_BOX = 3, PR_CCYL_CCYL = 4, PR_CCYL_BOX = 5,
+  PR_PLANE_PLANE = 6, PR_PLANE_SPHERE = 7, PR_PLANE_CCYL = 8, PR_PLANE_CYL = 9, PR_PLANE_BOX = 10, PR_SPHERE_CYL = 11
+};
+
+// createProxFinderList's cascade of kinds (proxy_query_model.cpp:225-370) for one pair: the routine, and whether the
+// FIRST shape is the routine's shape1 (plane before sphere before capped cylinder; equal kinds: model 1's shape).
+RKH_DI int pair_routine(int ka, int kb, bool* a_is_shape1) {
+  auto other = [&](int first_kind) { return (ka == first_kind) ? kb : ka; };
+  if (ka == RKH_SHAPE_PLANE || kb == RKH_SHAPE_PLANE) {
+    *a_is_shape1 = (ka == RKH_SHAPE_PLANE);
+    switch (other(RKH_SHAPE_PLANE)) {
+      case RKH_SHAPE_PLANE: return PR_PLANE_PLANE;
+      case RKH_SHAPE_SPHERE: return PR_PLANE_SPHERE;
+      case RKH_SHAPE_CCYLINDER: return PR_PLANE_CCYL;
+      case RKH_SHAPE_CYLINDER: return PR_PLANE_CYL;
+      case RKH_SHAPE_BOX: return PR_PLANE_BOX;
+    }
+    return PR_NONE;
+  }
+  if (ka == RKH_SHAPE_SPHERE || kb == RKH_SHAPE_SPHERE) {
+    *a_is_shape1 = (ka == RKH_SHAPE_SPHERE);
+    switch (other(RKH_SHAPE_SPHERE)) {
+      case RKH_SHAPE_SPHERE: return PR_SPHERE_SPHERE;
+      case RKH_SHAPE_CCYLINDER: return PR_SPHERE_CCYL;
+      case RKH_SHAPE_CYLINDER: return PR_SPHERE_CYL;
+      case RKH_SHAPE_BOX: return PR_SPHERE_BOX;
+    }
+    return PR_NONE;
+  }
+  if (ka == RKH_SHAPE_CCYLINDER || kb == RKH_SHAPE_CCYLINDER) {
+    *a_is_shape1 = (ka == RKH_SHAPE_CCYLINDER);
+    switch (other(RKH_SHAPE_CCYLINDER)) {
+      case RKH_SHAPE_CCYLINDER: return PR_CCYL_CCYL;
+      case RKH_SHAPE_BOX: return PR_CCYL_BOX;
+    }
+    return PR_NONE;
+  }
+  *a_is_shape1 = true;
+  return PR_NONE;  // cylinder-cylinder, cylinder-box, box-box
+}
 
 // findProximityBoxToPoint (prox_fundamentals_3D.cpp:35-82): signed distance only
 RKH_DI double box_point_distance(const ShapeG& bx, d3 pt) {
@@ -147,6 +189,115 @@ RKH_DI double dist_ccyl_box(const ShapeG& cc, const ShapeG& bx) {
   return box_line_distance(bx, cy_c, cy_t, 0.5 * cc.d0) - cc.d1;
 }
 
+// ---- plane / cylinder finders (prox_plane_{sphere,box,ccylinder,cylinder,plane}.cpp, prox_sphere_cylinder.cpp) -------
+// The enabled prox_plane_* routines treat the plane as infinite (normal = local z); only prox_plane_plane looks at its
+// extents.  pose_3D::rotateToGlobal = Quat * V, rotateFromGlobal = invert(Quat) * V (pose_3D.hpp:154-170).
+
+RKH_DI double dist_plane_sphere(const ShapeG& pl, const ShapeG& sp) {  // prox_plane_sphere.cpp:106-122
+  const d3 sp_c = pose_to_parent(sp.pos, sp.q, mk3(0, 0, 0));
+  const d3 rel = pose_from_parent(pl.pos, pl.q, sp_c);
+  return rel.z - sp.d0;
+}
+
+// prox_plane_box.cpp:43-71: bx_x, bx_y and bx_z are ALL built from the box's local x axis in the reference (:53-55)
+RKH_DI double dist_plane_box(const ShapeG& pl, const ShapeG& bx) {
+  const d3 bx_c = pose_to_parent(bx.pos, bx.q, mk3(0, 0, 0));
+  d3 bx_x = qrot(qinv(pl.q), qrot(bx.q, mk3(1.0, 0.0, 0.0)));
+  if (bx_x.z > 0.0) bx_x = -bx_x;
+  const d3 bx_y = bx_x, bx_z = bx_x;
+  const d3 c_rel = pose_from_parent(pl.pos, pl.q, bx_c);
+  const d3 pt = c_rel + 0.5 * (bx.d0 * bx_x + bx.d1 * bx_y + bx.d2 * bx_z);
+  return pt.z;
+}
+
+RKH_DI double dist_plane_ccyl(const ShapeG& pl, const ShapeG& cc) {  // prox_plane_ccylinder.cpp:43-74
+  const d3 cy_c = pose_to_parent(cc.pos, cc.q, mk3(0, 0, 0));
+  const d3 cy_t = qrot(cc.q, mk3(0.0, 0.0, 1.0));
+  const d3 c_rel = pose_from_parent(pl.pos, pl.q, cy_c);
+  d3 t_rel = qrot(qinv(pl.q), cy_t);
+  if (fabs(t_rel.z) < 1e-6) return c_rel.z - cc.d1;
+  if (t_rel.z > 0.0) t_rel = -t_rel;
+  const d3 pt = c_rel + (0.5 * cc.d0) * t_rel + mk3(0.0, 0.0, -cc.d1);
+  return pt.z;
+}
+
+RKH_DI double dist_plane_cyl(const ShapeG& pl, const ShapeG& cy) {  // prox_plane_cylinder.cpp:42-78
+  const d3 cy_c = pose_to_parent(cy.pos, cy.q, mk3(0, 0, 0));
+  const d3 cy_t = qrot(cy.q, mk3(0.0, 0.0, 1.0));
+  const d3 c_rel = pose_from_parent(pl.pos, pl.q, cy_c);
+  d3 t_rel = qrot(qinv(pl.q), cy_t);
+  if (fabs(t_rel.z) < 1e-6) return c_rel.z - cy.d1;
+  if (sqrt(t_rel.x * t_rel.x + t_rel.y * t_rel.y) < 1e-6) return c_rel.z - 0.5 * cy.d0;
+  if (t_rel.z > 0.0) t_rel = -t_rel;
+  const d3 v = mk3(0.0, 0.0, -1.0) + t_rel.z * t_rel;
+  const double n = norm_2(v);
+  const d3 r_rel = mk3(v.x / n, v.y / n, v.z / n);  // unit(): vect_alg.hpp:2378-2382
+  const d3 pt = c_rel + (0.5 * cy.d0) * t_rel + cy.d1 * r_rel;
+  return pt.z;
+}
+
+// prox_plane_plane::computeProximityOfPoint (prox_plane_plane.cpp:43-95): here the plane is finite
+RKH_DI double plane_point_distance(const ShapeG& pl, d3 pt) {
+  const d3 p = pose_from_parent(pl.pos, pl.q, pt);
+  const double hx = 0.5 * pl.d0, hy = 0.5 * pl.d1;
+  const bool in_x = (p.x > -hx) && (p.x < hx), in_y = (p.y > -hy) && (p.y < hy);
+  if (in_x && in_y) {
+    double fact = 1.0;
+    if (p.z < 0.0) fact = -1.0;
+    return fact * p.z;
+  }
+  d3 rim;
+  if (in_x) {
+    double fact = 1.0;
+    if (p.y < 0.0) fact = -1.0;
+    rim = mk3(p.x, fact * 0.5 * pl.d1, 0.0);
+  } else if (in_y) {
+    double fact = 1.0;
+    if (p.x < 0.0) fact = -1.0;
+    rim = mk3(fact * 0.5 * pl.d0, p.y, 0.0);
+  } else {
+    rim = mk3(0.5 * pl.d0, 0.5 * pl.d1, 0.0);
+    if (p.x < 0.0) rim.x = -rim.x;
+    if (p.y < 0.0) rim.y = -rim.y;
+  }
+  return norm_2(pose_to_parent(pl.pos, pl.q, rim) - pt);
+}
+
+// prox_plane_plane.cpp:98-183: the corners of plane 2 against plane 1, then those of plane 1 against plane 2
+RKH_DI double dist_plane_plane(const ShapeG& p1, const ShapeG& p2) {
+  double best = INFINITY;
+#pragma unroll 1
+  for (int side = 0; side < 2; ++side) {
+    const ShapeG& of = side == 0 ? p2 : p1;
+    const ShapeG& against = side == 0 ? p1 : p2;
+    d3 corner = mk3(0.5 * of.d0, 0.5 * of.d1, 0.0);
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      if (k == 1 || k == 3) corner.y = -corner.y;
+      if (k == 2) corner.x = -corner.x;
+      const double d = plane_point_distance(against, pose_to_parent(of.pos, of.q, corner));
+      if (d < best) best = d;
+    }
+  }
+  return best;
+}
+
+RKH_DI double dist_sphere_cyl(const ShapeG& sp, const ShapeG& cy) {  // prox_sphere_cylinder.cpp:43-92
+  const double L = cy.d0, R = cy.d1, sr = sp.d0;
+  const d3 sp_c = pose_to_parent(sp.pos, sp.q, mk3(0, 0, 0));
+  const d3 rel = pose_from_parent(cy.pos, cy.q, sp_c);
+  const double rel_rad = sqrt(rel.x * rel.x + rel.y * rel.y);
+  if (fabs(rel.z) <= 0.5 * L) return norm_2(mk3(rel.x, rel.y, 0.0)) - sr - R;
+  double fact = 1.0;
+  if (rel.z < 0.0) fact = -1.0;
+  if (rel_rad < R) return fact * rel.z - 0.5 * L - sr;
+  const d3 proj = mk3(rel.x, rel.y, 0.0);
+  const double proj_d = norm_2(proj);
+  const d3 rim = (R / proj_d) * proj + mk3(0.0, 0.0, fact * 0.5 * L);
+  const d3 p2 = pose_to_parent(cy.pos, cy.q, rim);
+  return norm_2(p2 - sp_c) - sr;
+}
+
 // (shape1, shape2) are already in the routine's own argument order
 RKH_DI double pair_distance(int routine, const ShapeG& s1, const ShapeG& s2) {
   switch (routine) {
@@ -155,6 +306,12 @@ RKH_DI double pair_distance(int routine, const ShapeG& s1, const ShapeG& s2) {
     case PR_SPHERE_BOX: return dist_sphere_box(s1, s2);
     case PR_CCYL_CCYL: return dist_ccyl_ccyl(s1, s2);
     case PR_CCYL_BOX: return dist_ccyl_box(s1, s2);
+    case PR_PLANE_PLANE: return dist_plane_plane(s1, s2);
+    case PR_PLANE_SPHERE: return dist_plane_sphere(s1, s2);
+    case PR_PLANE_CCYL: return dist_plane_ccyl(s1, s2);
+    case PR_PLANE_CYL: return dist_plane_cyl(s1, s2);
+    case PR_PLANE_BOX: return dist_plane_box(s1, s2);
+    case PR_SPHERE_CYL: return dist_sphere_cyl(s1, s2);
   }
   return INFINITY;
 }

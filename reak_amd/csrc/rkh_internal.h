@@ -146,6 +146,11 @@ struct SceneDev {
   // chain base, plus its bounding radius.  Pairs beyond that have a positive bounding-sphere gap in every configuration,
   // i.e. they are the pairs the cull of proxy_query_pair_3D::findMinimumDistance (proxy_query_model.cpp:384-389) drops.
   int32_t robot_n_reach[kMaxDof * 2];
+  // bit o of env_finder_mask[k][chunk]: the reference has a finder for (robot shape of kind k, environment shape o)
+  // (createProxFinderList, proxy_query_model.cpp:215-374: no finder for box-box, cylinder-cylinder, cylinder-box and
+  // capped cylinder-cylinder)
+  unsigned long long env_finder_mask[9][kMaxEnvShapes / 64];
+  int32_t has_ext_shapes;  // 1: the scene holds a plane or a cylinder (not handled by the first-generation lane kernel)
 };
 
 }  // namespace rkh
@@ -256,7 +261,8 @@ rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev*
                             const EdgeIO* tab_a = nullptr, const EdgeIO* tab_b = nullptr, uint32_t n_problems = 1,
                             double* d_lane_ws = nullptr, KernelGate gate = KernelGate());
 // the two-lanes-per-edge kernel handles one serial chain, with at most a tip-to-world beam
-inline bool scene_fits_lane_kernel(const SceneDev& S) {
+inline bool scene_fits_lane_kernel(const SceneDev& S, int variant = 2) {
+  if (variant == 1 && S.has_ext_shapes) return false;  // propagate_lane.hip knows spheres, boxes and capped cylinders
   return S.n_branches == 0 && (!S.beam_on || (S.beam_j1 == S.n_dof - 1 && S.beam_j2 < 0));
 }
 // one lane per edge (propagate_lane.hip); d_ws: propagate_lanes_workspace_bytes() of device memory

@@ -31,8 +31,50 @@ static double bounding_radius(const rkh_shape& s) {
       return std::sqrt(acc) * 0.5;
     }
     case RKH_SHAPE_CCYLINDER: return s.dims[0] * 0.5 + s.dims[1];
+    case RKH_SHAPE_PLANE: {  // plane.cpp:31-33
+      double acc = 0.0;
+      for (int i = 0; i < 2; ++i) acc += s.dims[i] * s.dims[i];
+      return std::sqrt(acc) * 0.5;
+    }
+    case RKH_SHAPE_CYLINDER: return std::sqrt(s.dims[1] * s.dims[1] + 0.25 * s.dims[0] * s.dims[0]);  // cylinder.cpp:33-35
   }
   return 0.0;
+}
+
+// createProxFinderList's cascade of kinds for one pair (the host twin of pair_routine() in proximity_device.h)
+static int host_pair_routine(int ka, int kb, bool* a_is_shape1) {
+  auto other = [&](int first_kind) { return (ka == first_kind) ? kb : ka; };
+  *a_is_shape1 = true;
+  if (ka == RKH_SHAPE_PLANE || kb == RKH_SHAPE_PLANE) {
+    *a_is_shape1 = (ka == RKH_SHAPE_PLANE);
+    switch (other(RKH_SHAPE_PLANE)) {
+      case RKH_SHAPE_PLANE: return 6;
+      case RKH_SHAPE_SPHERE: return 7;
+      case RKH_SHAPE_CCYLINDER: return 8;
+      case RKH_SHAPE_CYLINDER: return 9;
+      case RKH_SHAPE_BOX: return 10;
+    }
+    return 0;
+  }
+  if (ka == RKH_SHAPE_SPHERE || kb == RKH_SHAPE_SPHERE) {
+    *a_is_shape1 = (ka == RKH_SHAPE_SPHERE);
+    switch (other(RKH_SHAPE_SPHERE)) {
+      case RKH_SHAPE_SPHERE: return 1;
+      case RKH_SHAPE_CCYLINDER: return 2;
+      case RKH_SHAPE_CYLINDER: return 11;
+      case RKH_SHAPE_BOX: return 3;
+    }
+    return 0;
+  }
+  if (ka == RKH_SHAPE_CCYLINDER || kb == RKH_SHAPE_CCYLINDER) {
+    *a_is_shape1 = (ka == RKH_SHAPE_CCYLINDER);
+    switch (other(RKH_SHAPE_CCYLINDER)) {
+      case RKH_SHAPE_CCYLINDER: return 4;
+      case RKH_SHAPE_BOX: return 5;
+    }
+    return 0;
+  }
+  return 0;  // cylinder-cylinder, cylinder-box, box-box: no finder in the reference
 }
 
 // The time loops of the steer pattern and of runge_kutta4_integrate_impl depend only on (fraction, dt,
@@ -340,11 +382,14 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
   for (int oi = 0; oi < n_shapes; ++oi) {
     const int i = order[oi];
     const rkh_shape& s = shapes[i];
-    if (s.kind < RKH_SHAPE_SPHERE || s.kind > RKH_SHAPE_CCYLINDER) {
+    const bool kind_ok = (s.kind >= RKH_SHAPE_SPHERE && s.kind <= RKH_SHAPE_CCYLINDER) || s.kind == RKH_SHAPE_PLANE ||
+                         s.kind == RKH_SHAPE_CYLINDER;
+    if (!kind_ok) {
       delete sc;
       set_error("rkh_scene_create: unsupported shape kind");
       return RKH_ERR_UNSUPPORTED;
     }
+    if (s.kind == RKH_SHAPE_PLANE || s.kind == RKH_SHAPE_CYLINDER) S.has_ext_shapes = 1;
     ShapeDev d;
     std::memset(&d, 0, sizeof(d));
     d.kind = s.kind;
@@ -372,7 +417,12 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
       d.link = -1;
       for (int k = 0; k < 3; ++k) S.env_cull[S.n_env][k] = d.pos[k];
       S.env_cull[S.n_env][3] = d.brad;
-      S.env_kind_mask[d.kind == RKH_SHAPE_SPHERE ? 0 : (d.kind == RKH_SHAPE_BOX ? 1 : 2)][S.n_env / 64] |= 1ull << (S.n_env % 64);
+      if (d.kind <= RKH_SHAPE_CCYLINDER)
+        S.env_kind_mask[d.kind == RKH_SHAPE_SPHERE ? 0 : (d.kind == RKH_SHAPE_BOX ? 1 : 2)][S.n_env / 64] |= 1ull << (S.n_env % 64);
+      for (int k = RKH_SHAPE_SPHERE; k <= RKH_SHAPE_CYLINDER; ++k) {
+        bool first;
+        if (host_pair_routine(k, d.kind, &first) != 0) S.env_finder_mask[k][S.n_env / 64] |= 1ull << (S.n_env % 64);
+      }
       S.env[S.n_env++] = d;
       env_src.push_back(i);
       double d2 = 0.0;
@@ -398,6 +448,20 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
   // proxy_query_pair_3D::createProxFinderList (proxy_query_model.cpp:215-374), then grouped by routine so
   // that the lanes of a wave run the same closed form (the verdict does not depend on the pair order)
   std::vector<PairDev> pairs;
+  // reach of every robot shape's CENTRE from the chain base (over all configurations), for the plane rule below
+  std::vector<double> centre_reach(S.n_robot, 0.0);
+  for (int r = 0; r < S.n_robot; ++r) {
+    double reach = 0.0;
+    for (int i = 0; i < n; ++i) {  // serial chain: the links below the shape's joint; branching chains: all of them
+      if (S.n_branches == 0 && i >= S.robot[r].link) break;
+      const double* o = S.joints[i].off_pos;
+      reach += std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+      const double* mp = S.mount_pos[i];
+      reach += std::sqrt(mp[0] * mp[0] + mp[1] * mp[1] + mp[2] * mp[2]);
+    }
+    const double* lp = S.robot[r].pos;
+    centre_reach[r] = reach + std::sqrt(lp[0] * lp[0] + lp[1] * lp[1] + lp[2] * lp[2]);
+  }
   for (int i = 0; i < S.n_robot; ++i)
     for (int j = 0; j < S.n_env; ++j) {
       const int ki = S.robot[i].kind, kj = S.env[j].kind;
@@ -405,16 +469,24 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
       std::memset(&p, 0, sizeof(p));
       p.robot = uint16_t(i);
       p.env = uint16_t(j);
-      if (ki == RKH_SHAPE_SPHERE || kj == RKH_SHAPE_SPHERE) {
-        p.s1_is_robot = (ki == RKH_SHAPE_SPHERE) ? 1 : 0;  // the sphere is shape1
-        const int ko = p.s1_is_robot ? kj : ki;
-        p.routine = (ko == RKH_SHAPE_SPHERE) ? 1 : (ko == RKH_SHAPE_CCYLINDER ? 2 : 3);
-      } else if (ki == RKH_SHAPE_CCYLINDER || kj == RKH_SHAPE_CCYLINDER) {
-        p.s1_is_robot = (ki == RKH_SHAPE_CCYLINDER) ? 1 : 0;  // the capped cylinder is shape1
-        const int ko = p.s1_is_robot ? kj : ki;
-        p.routine = (ko == RKH_SHAPE_CCYLINDER) ? 4 : 5;
-      } else {
-        continue;  // box-box: no finder in the reference (proxy_query_model.cpp:367)
+      bool robot_first = true;
+      p.routine = uint8_t(host_pair_routine(ki, kj, &robot_first));
+      if (p.routine == 0) continue;  // no finder in the reference
+      p.s1_is_robot = robot_first ? 1 : 0;
+      if (ki == RKH_SHAPE_PLANE || kj == RKH_SHAPE_PLANE) {
+        // findMinimumDistance skips a finder whose bounding spheres are further apart than the running minimum
+        // (proxy_query_model.cpp:384-389).  For bounded shapes that cannot change the minimum; a plane's bounding radius
+        // (plane.cpp:31) is finite although the prox_plane_* routines treat it as infinite, so for a plane pair the skip
+        // could.  The kernels evaluate every plane pair; that is the reference's result exactly when the pair can never
+        // be skipped, i.e. the shapes' bounding spheres overlap in every configuration -- required here.
+        double d2 = 0.0;
+        for (int k = 0; k < 3; ++k) d2 += (S.env[j].pos[k] - S.base_pos[k]) * (S.env[j].pos[k] - S.base_pos[k]);
+        if (std::sqrt(d2) + centre_reach[i] - S.env[j].brad - S.robot[i].brad > 0.0) {
+          delete sc;
+          set_error("rkh_scene_create: a plane must be large enough that its bounding sphere (plane.cpp:31) always overlaps "
+                    "the robot shapes' (otherwise the reference's result depends on the finder order)");
+          return RKH_ERR_UNSUPPORTED;
+        }
       }
       pairs.push_back(p);
     }
@@ -545,7 +617,7 @@ rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const dou
   int lanes = 64;  // RKH_LANES_PER_EDGE = 64 | 16 | 2 | 1 selects the kernel mapping (identical results)
   if (const char* ev = getenv("RKH_LANES_PER_EDGE"))
     lanes = (atoi(ev) == 1) ? 1 : (atoi(ev) == 2 ? 2 : (atoi(ev) == 16 ? 16 : 64));
-  if ((lanes == 1 || lanes == 2) && !(n <= 7 && scene_fits_lane_kernel(scene->host))) lanes = 64;  // not a scene for that mapping
+  if ((lanes == 1 || lanes == 2) && !(n <= 7 && scene_fits_lane_kernel(scene->host, lanes))) lanes = 64;  // not a scene for that mapping
   if (lanes == 16 && 2 * n > 16) lanes = 64;
   DevBuf dws;
   if (lanes == 1) RKH_HIP(hipMalloc(&dws.p, propagate_lanes_workspace_bytes(n, B, 0, 1)));

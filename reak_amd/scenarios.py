@@ -120,10 +120,13 @@ def flexible_beam_op(anchor_frame, world_pose, rest_length, stiffness, torsion_s
     return op
 
 
-def make_c2(world_seed=1, n_obstacles=50, capsule_radius=0.05, steps_per_edge=20, dt=1e-3, tether=None):
+def make_c2(world_seed=1, n_obstacles=50, capsule_radius=0.05, steps_per_edge=20, dt=1e-3, tether=None, floor=None,
+            n_cylinders=0, tool_sphere=None):
     """BASELINE config C2: 6-DOF revolute KTE chain, RK4 dt=1e-3 x 20 steps/edge, 50 convex obstacles.
     tether = (rest_length, stiffness, torsion_stiffness): a flexible_beam_3D from the end effector to a world anchor
-    above the base (the beam parameters of BASELINE config C4: k = 1e4 N/m, k_theta = 1e2)."""
+    above the base (the beam parameters of BASELINE config C4: k = 1e4 N/m, k_theta = 1e2).
+    floor = z: an 8 m x 8 m `plane` at that height (normal +z); n_cylinders: flat-ended `cylinder` obstacles (the
+    reference only tests them against planes and spheres); tool_sphere = r: a `sphere` on the end effector."""
     rng = np.random.Generator(np.random.PCG64(world_seed))
     axes, lengths, offsets, masses, inertias, joint_inertias = crs_like_chain()
     n = len(axes)
@@ -165,6 +168,29 @@ def make_c2(world_seed=1, n_obstacles=50, capsule_radius=0.05, steps_per_edge=20
         s.dims[:] = [float(v) for v in dims]
         shapes.append(s)
         kinds.append(kind)
+
+    if tool_sphere is not None:  # a spherical tool at the tip of the last link (robot model)
+        s = T.Shape(kind=T.SHAPE_SPHERE, anchor=2 * (n - 1) + 1)
+        s.pose = T.make_pose((0.0, 0.0, lengths[n - 1] + tool_sphere))
+        s.dims[:] = [tool_sphere, 0.0, 0.0]
+        shapes.insert(n, s)
+    if floor is not None:
+        s = T.Shape(kind=T.SHAPE_PLANE, anchor=-1)
+        s.pose = T.make_pose((0.0, 0.0, float(floor)))
+        s.dims[:] = [8.0, 8.0, 0.0]
+        shapes.append(s)
+    erng = np.random.Generator(np.random.PCG64(7000 + world_seed))
+    placed = 0
+    while placed < n_cylinders:
+        c = erng.uniform([-0.9, -0.9, 0.0], [0.9, 0.9, 1.3])
+        L, r = erng.uniform(0.15, 0.4), erng.uniform(0.05, 0.15)
+        if _dist_point_segment(c, origin, reach_top) < float(np.hypot(r, 0.5 * L)) + capsule_radius + 0.25:
+            continue
+        s = T.Shape(kind=T.SHAPE_CYLINDER, anchor=-1)
+        s.pose = T.make_pose(c, _random_unit_quat(erng))
+        s.dims[:] = [L, r, 0.0]
+        shapes.append(s)
+        placed += 1
 
     dyn = T.DynSpace()
     dyn.n_dof = n

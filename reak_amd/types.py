@@ -24,6 +24,8 @@ SHAPE_CCYLINDER = 3
 SHAPE_CIRCLE = 4
 SHAPE_RECTANGLE = 5
 SHAPE_CRECT = 6
+SHAPE_PLANE = 7      # dims = (x extent, y extent); normal = local z
+SHAPE_CYLINDER = 8   # dims = (length, radius); flat ends, axis = local z
 
 
 class Pose(C.Structure):

@@ -326,6 +326,30 @@ def test_c1_stops_at_first_solution(L, ctx, oracle):
     assert np.array_equal(pl.tree()["parent"], rtree["parent"])
 
 
+def test_sample_stream_grows_past_its_first_capacity(L, ctx, oracle):
+    """generate_rrt has no iteration cap (rr_tree.hpp:192-196): a cluttered scene with a demanding steer tolerance accepts
+    ~9 % of its samples, so 2000 vertices take far more iterations than the first allocation of the device-resident
+    sample stream (16384); the planner must grow it and stay the sequential planner (the pool / solve loops used to
+    spin on empty rounds or return RKH_ERR_CAPACITY there)."""
+    c1 = scenarios.make_c1_planar(world_seed=1, n_obstacles=25)
+    sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    prm = c1.rrt_params(seed=4, max_vertices=2000, steer_tol=0.9)
+    rc, rout, rtree = osc.rrt_qs(lo, hi, mi, prm)
+    assert rout.iterations > 17000
+    for runner in ("solve", "pool"):
+        if runner == "solve":
+            pl = L.RrtPlanner(sc, prm, qs=L.make_qs_space(3, lo, hi, mi))
+        else:
+            pl = L.RrtPlannerPool(sc, [prm], groups=1, qs=L.make_qs_space(3, lo, hi, mi))
+        st = pl.solve_planning_query()
+        tree = pl.tree()
+        assert (st.num_vertices, st.iterations, st.edges_checked) == (rout.num_vertices, rout.iterations, rout.edges_checked)
+        assert np.array_equal(tree["nn_seq"], rtree["nn_seq"]) and np.array_equal(tree["accept"], rtree["accept"])
+        assert np.array_equal(tree["parent"], rtree["parent"]) and np.array_equal(tree["pos"], rtree["pos"])
+        pl.close()
+
+
 # ------------------------------------------------------------------ RRT* (a24)
 @pytest.mark.parametrize("seed", [1, 2])
 def test_rrtstar_graph_identical_to_sequential_planner(L, ctx, oracle, seed):
@@ -455,6 +479,51 @@ def test_every_robot_shape_is_tested_by_every_mapping(L, ctx, oracle, c2, monkey
                 for lanes in ("64", "16", "1", "2"):
                     monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
                     assert sc.steer_position_toward(x, t)[1][0] == 0, (k, kind, order, lanes)
+
+
+def test_c2_with_floor_plane_cylinders_and_a_spherical_tool(L, ctx, oracle, monkeypatch):
+    """The plane / cylinder finders (prox_plane_{sphere,ccylinder,box,..}, prox_sphere_cylinder): a C2 world with a floor
+    plane, flat-ended cylinders and a spherical tool on the end effector.  Distances to 1e-12, verdicts, free-step
+    counts of every steer mapping and a planner run against the oracle."""
+    scn = scenarios.make_c2(world_seed=2, floor=-0.12, n_cylinders=6, tool_sphere=0.06)
+    sc, osc = L.Scene(ctx, scn), oracle.OracleScene(scn)
+    rng = np.random.default_rng(17)
+    lo = np.array([scn.dyn.lower[i] for i in range(12)])
+    hi = np.array([scn.dyn.upper[i] for i in range(12)])
+    x = rng.uniform(lo, hi, size=(2048, 12))
+    rd, d = osc.min_distance(x), sc.min_distance(x)
+    assert np.allclose(d, rd, rtol=0, atol=1e-12)
+    sure = np.abs(rd) > 1e-12
+    assert np.array_equal((d < 0)[sure], (rd < 0)[sure])
+    # the floor is what stops many of them: without it the same configurations are mostly free
+    plain = oracle.OracleScene(scenarios.make_c2(world_seed=2, n_cylinders=6, tool_sphere=0.06))
+    assert ((rd < 0) & (plain.min_distance(x) > 0)).sum() > 200
+    a = x[:1024] * 0.6
+    b = rng.uniform(lo, hi, size=(a.shape[0], 12))
+    rc, rout, rsteps, _ = osc.steer(a, b)
+    assert (rsteps == 0).sum() > 20 and (rsteps == 20).sum() > 200
+    for lanes in ("64", "16", "2"):
+        monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
+        out, steps, _ = sc.steer_position_toward(a, b)
+        assert np.array_equal(steps, rsteps), lanes
+        assert np.allclose(out, rout, rtol=STATE_RTOL, atol=1e-12), lanes
+    monkeypatch.delenv("RKH_LANES_PER_EDGE")
+    prm = scn.rrt_params(seed=3, max_vertices=700)
+    rc, ro, rtree = osc.rrt_dyn(prm)
+    pl = L.RrtPlanner(sc, prm)
+    st = pl.solve_planning_query()
+    tree = pl.tree()
+    assert (st.num_vertices, st.iterations, st.edges_checked) == (ro.num_vertices, ro.iterations, ro.edges_checked)
+    assert np.array_equal(tree["parent"], rtree["parent"]) and np.array_equal(tree["accept"], rtree["accept"])
+
+
+def test_small_plane_is_refused(L, ctx):
+    """A plane whose bounding sphere (plane.cpp:31) does not always overlap the robot's makes the reference's result
+    depend on the finder order (proxy_query_model.cpp:384-389): refused instead of silently different."""
+    scn = scenarios.make_c2(world_seed=2, floor=-0.12)
+    scn.shapes[-1].dims[:] = [0.5, 0.5, 0.0]
+    with pytest.raises(Exception):
+        L.Scene(ctx, scn)
 
 
 def test_steer_from_colliding_and_free_starts_matches_oracle(L, ctx, oracle, c2, monkeypatch):

@@ -218,6 +218,54 @@ def test_proximity_closed_forms_analytic(oracle):
     assert math.isnan(pd(bx((0, 0, 0), (1, 1, 1)), bx((3, 0, 0), (1, 1, 1))))
 
 
+def test_plane_and_cylinder_finders_analytic(oracle):
+    """The six finders createProxFinderList enables beside the sphere / box / capped-cylinder ones
+    (proxy_query_model.cpp:226-300): hand-worked configurations, reference quirks included."""
+    lib = oracle.load()
+    pd = lambda a, b: lib.orc_pair_distance(C.byref(a), C.byref(b))
+    sp = lambda p, r: _shape(T.SHAPE_SPHERE, p, (r, 0, 0))
+    bx = lambda p, d, q=(1, 0, 0, 0): _shape(T.SHAPE_BOX, p, d, q)
+    cc = lambda p, L, r, q=(1, 0, 0, 0): _shape(T.SHAPE_CCYLINDER, p, (L, r, 0), q)
+    cy = lambda p, L, r, q=(1, 0, 0, 0): _shape(T.SHAPE_CYLINDER, p, (L, r, 0), q)
+    pl = lambda p, d, q=(1, 0, 0, 0): _shape(T.SHAPE_PLANE, p, (d[0], d[1], 0), q)
+    floor = pl((0, 0, -0.5), (4, 4))
+    qy90 = (math.cos(math.pi / 4), 0, math.sin(math.pi / 4), 0)   # local z -> global x
+    qy45 = (math.cos(math.pi / 8), 0, math.sin(math.pi / 8), 0)
+    # plane-sphere (prox_plane_sphere.cpp:106-122): signed height minus the radius; the plane is infinite -- a sphere
+    # far beside the 4 x 4 patch still sees it -- and one-sided (below it the distance is negative)
+    assert pd(floor, sp((0.3, -0.2, 1.0), 0.25)) == pytest.approx(1.25, rel=1e-15)
+    assert pd(sp((0.3, -0.2, 1.0), 0.25), floor) == pytest.approx(1.25, rel=1e-15)   # the plane is always shape1
+    assert pd(floor, sp((30.0, 0, 1.0), 0.25)) == pytest.approx(1.25, rel=1e-15)
+    assert pd(floor, sp((0, 0, -2.0), 0.25)) == pytest.approx(-1.75, rel=1e-15)
+    # plane-capped cylinder (prox_plane_ccylinder.cpp:43-74): upright, lying, tilted 45 degrees
+    assert pd(floor, cc((0, 0, 1.0), 1.0, 0.1)) == pytest.approx(1.5 - 0.5 - 0.1, rel=1e-15)
+    assert pd(floor, cc((0, 0, 1.0), 1.0, 0.1, qy90)) == pytest.approx(1.5 - 0.1, rel=1e-12)
+    assert pd(floor, cc((0, 0, 1.0), 1.0, 0.1, qy45)) == pytest.approx(1.5 - 0.5 * math.cos(math.pi / 4) - 0.1, rel=1e-12)
+    # plane-cylinder (prox_plane_cylinder.cpp:42-78): flat end down, on its side, tilted (lowest rim point)
+    assert pd(floor, cy((0, 0, 1.0), 1.0, 0.2)) == pytest.approx(1.5 - 0.5, rel=1e-15)
+    assert pd(floor, cy((0, 0, 1.0), 1.0, 0.2, qy90)) == pytest.approx(1.5 - 0.2, rel=1e-12)
+    c45 = math.cos(math.pi / 4)
+    assert pd(floor, cy((0, 0, 1.0), 1.0, 0.2, qy45)) == pytest.approx(1.5 - 0.5 * c45 - 0.2 * c45, rel=1e-12)
+    # plane-box (prox_plane_box.cpp:43-71): the reference takes ALL three box axes from the box's local x (:53-55), so
+    # an axis-aligned 1 x 2 x 4 box at height 1.5 reports 1.5 (its x axis lies in the plane: no extent along the
+    # normal), not the true 1.5 - 2; rotated so that x points down it reports 1.5 - (1 + 2 + 4) / 2.  Kept.
+    assert pd(floor, bx((0, 0, 1.0), (1, 2, 4))) == pytest.approx(1.5, rel=1e-15)
+    assert pd(floor, bx((0, 0, 1.0), (1, 2, 4), qy90)) == pytest.approx(1.5 - 3.5, rel=1e-12)
+    # sphere-cylinder (prox_sphere_cylinder.cpp:43-92): beside the round shell, above the flat end, off the rim
+    assert pd(sp((1.0, 0, 0.2), 0.1), cy((0, 0, 0), 1.0, 0.3)) == pytest.approx(1.0 - 0.1 - 0.3, rel=1e-15)
+    assert pd(sp((0.1, 0, 2.0), 0.1), cy((0, 0, 0), 1.0, 0.3)) == pytest.approx(2.0 - 0.5 - 0.1, rel=1e-15)
+    assert pd(sp((1.3, 0, 1.5), 0.1), cy((0, 0, 0), 1.0, 0.3)) == pytest.approx(math.sqrt(2.0) - 0.1, rel=1e-12)
+    assert pd(cy((0, 0, 0), 1.0, 0.3), sp((1.0, 0, 0.2), 0.1)) == pytest.approx(0.6, rel=1e-15)  # the sphere is shape1
+    # plane-plane (prox_plane_plane.cpp:98-183): corners of each patch against the other FINITE patch
+    assert pd(pl((0, 0, 0), (2, 2)), pl((0, 0, 1.5), (1, 1))) == pytest.approx(1.5, rel=1e-15)
+    assert pd(pl((0, 0, 0), (2, 2)), pl((3, 0, 0), (2, 2))) == pytest.approx(1.0, rel=1e-15)     # side by side
+    assert pd(pl((0, 0, 0), (2, 2)), pl((4, 5, 0), (2, 2))) == pytest.approx(math.hypot(2.0, 3.0), rel=1e-15)
+    # no finder: capped cylinder-cylinder, cylinder-cylinder, cylinder-box (proxy_query_model.cpp:317-320,341-349)
+    assert math.isnan(pd(cc((0, 0, 0), 1, 0.1), cy((3, 0, 0), 1, 0.1)))
+    assert math.isnan(pd(cy((0, 0, 0), 1, 0.1), cy((3, 0, 0), 1, 0.1)))
+    assert math.isnan(pd(cy((0, 0, 0), 1, 0.1), bx((3, 0, 0), (1, 1, 1))))
+
+
 def test_linear_nn_tie_rules(oracle):
     pts = np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 0.0], [-1.0, 0.0], [0.0, 1.0]])
     q = np.array([[2.0, 0.0], [0.0, 0.0], [0.0, 5.0]])
