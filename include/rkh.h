@@ -10,6 +10,9 @@
  * crosses the boundary; the caller owns every host buffer; one host thread per rkh_ctx; calls are
  * synchronous (they return after the device work finished) unless named *_async.
  * Pointers named d_* are device (HBM) pointers, all others are host pointers.
+ * Profiling and diagnostic entry points (kernel timing for bench.py, per-phase cycle counts) are NOT part of this
+ * boundary: they live in rkh_diag.h.  The C++ classes that model ReaK's concepts over these functions are in
+ * rkh_adaptors.hpp.
  */
 #ifndef RKH_H
 #define RKH_H
@@ -85,11 +88,6 @@ rkh_status rkh_nn_queryk_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32
  * fp64 test; results stay bit-identical.  bound = 0 (default) switches the pre-filters off. */
 rkh_status rkh_nn_set_coord_bound(rkh_nn* nn, double bound);
 rkh_status rkh_nn_fill_uniform(rkh_nn* nn, uint64_t n, uint64_t seed);
-/* One-shot: the next rkh_nn_query1_async records the two hipEvent_t (passed as void*) immediately before and after
- * its sweep kernel on the context stream (bench.py times the kernel itself, not the launch sequence). */
-rkh_status rkh_nn_set_events(rkh_nn* nn, void* ev_start, void* ev_stop);
-/* Name and grid of the sweep kernel the last query launched (for profile bookkeeping). */
-const char* rkh_nn_kernel_name(void);
 
 /* ---- scene: KTE chain + proximity environment ----------------------------------------------
  * rkh_scene_create flattens what the reference holds as kte_map_chain + mass_matrix_calc
@@ -125,12 +123,6 @@ rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const dou
 rkh_status rkh_edge_check(rkh_scene* scene, const double* lower, const double* upper, double min_interval,
                           const double* a, const double* b, uint32_t B, double fraction, double* out,
                           uint32_t* n_checked);
-
-/* Diagnostics (not on the product path): shader-clock cycles of `iters` back-to-back f-evals + proximity tests,
- * one wave per state; cycles[B][8] = {sincos, forward sweep, jacobian columns, force sweep, mass matrix, cholesky,
- * proximity, total}. */
-rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double* u, uint32_t B, int iters,
-                                 uint64_t* cycles);
 
 /* ---- planner: rrt_planner::solve_planning_query (LINEAR_SEARCH_KNN, UNIDIRECTIONAL) ----------
  * (ctrl/path_planning/rrt_path_planner.tpp:66-145 -> generate_rrt, ctrl/graph_alg/rr_tree.hpp:179-199)
@@ -247,13 +239,6 @@ rkh_status rkh_rrtstar_get_solution(rkh_rrtstar* p, uint32_t problem, uint32_t* 
                                     double* cost);
 rkh_status rkh_birrt_get_solution(rkh_birrt* p, uint32_t problem, uint32_t* path1, uint32_t* n_path1, uint32_t* path2,
                                   uint32_t* n_path2, uint32_t capacity, double* cost);
-/* With RKH_PROFILE_NN=1 in the environment at rkh_planner_create, every round brackets its NN sweep kernel with
- * HIP events on the planner stream: total kernel time, algorithmic bytes (n*D*8 per sweep) and launch count. */
-rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* total_bytes, uint64_t* launches);
-/* Same profile: (vertex, query) pairs the profiled sweeps evaluated = sum over rounds and problems of n * B. */
-rkh_status rkh_planner_nn_pairs(rkh_planner* p, uint64_t* pairs);
-/* Same switch: HIP events around the steer launches (both kernel mappings) of every round: total time, rounds. */
-rkh_status rkh_planner_steer_profile(rkh_planner* p, double* total_ms, uint64_t* launches);
 
 #ifdef __cplusplus
 }

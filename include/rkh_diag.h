@@ -1,0 +1,40 @@
+/* rkh_diag.h -- profiling and diagnostic entry points of librkh.so.
+ *
+ * NOT part of the drop-in boundary (rkh.h): nothing here replaces a reference interface.  bench.py uses them to time
+ * kernels with HIP events on the launch stream, the tests/diag_*.py scripts to read per-phase cycle counts.
+ */
+#ifndef RKH_DIAG_H
+#define RKH_DIAG_H
+
+#include "rkh.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One-shot: the next rkh_nn_query1_async records the two hipEvent_t (passed as void*) immediately before and after
+ * its sweep kernel on the context stream (bench.py times the kernel itself, not the launch sequence). */
+rkh_status rkh_nn_set_events(rkh_nn* nn, void* ev_start, void* ev_stop);
+/* Name of the sweep kernel the last query launched (for profile bookkeeping). */
+const char* rkh_nn_kernel_name(void);
+
+/* Shader-clock cycles of `iters` back-to-back f-evals + proximity tests.  One-wave-per-edge kernel: one wave per state,
+ * cycles[B][8] = {sincos, forward sweep, jacobian columns, force sweep, mass matrix, cholesky, proximity, total};
+ * two-lanes-per-edge kernels (RKH_LANES_PER_EDGE = 1 | 2 in the environment): one record per wave of 32 states,
+ * {frames + sincos, jacobian columns, mass matrix, force sweep, (assembly +) cholesky, proximity: joint frames, cull
+ * (+ queueing), closed forms}. */
+rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double* u, uint32_t B, int iters,
+                                 uint64_t* cycles);
+
+/* With RKH_PROFILE_NN=1 in the environment at rkh_planner_create, every round brackets its NN sweep kernel with
+ * HIP events on the planner stream: total kernel time, algorithmic bytes (n*D*8 per sweep) and launch count. */
+rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* total_bytes, uint64_t* launches);
+/* Same profile: (vertex, query) pairs the profiled sweeps evaluated = sum over rounds and problems of n * B. */
+rkh_status rkh_planner_nn_pairs(rkh_planner* p, uint64_t* pairs);
+/* Same switch: HIP events around the steer launches (both kernel mappings) of every round: total time, rounds. */
+rkh_status rkh_planner_steer_profile(rkh_planner* p, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

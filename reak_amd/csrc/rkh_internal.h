@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/rkh.h"
+#include "../../include/rkh_diag.h"
 
 namespace rkh {
 

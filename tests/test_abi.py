@@ -17,10 +17,13 @@ def lib():
     return L.load()
 
 
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "rkh.h")).read() + open(os.path.join(ROOT, "include", "rkh_diag.h")).read()
+    return set(re.findall(r"\b(rkh_[a-z0-9_]+)\s*\(", hdr)) - {"rkh_status"}
+
+
 def test_header_symbols_are_exported(lib):
-    hdr = open(os.path.join(ROOT, "include", "rkh.h")).read()
-    declared = set(re.findall(r"\b(rkh_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"rkh_status"}
+    declared = _declared()
     assert len(declared) >= 30
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, f"declared in include/rkh.h but not exported by librkh.so: {missing}"
@@ -29,9 +32,15 @@ def test_header_symbols_are_exported(lib):
 def test_python_binding_covers_the_header(lib):
     from reak_amd import lib as L
 
+    assert set(L.EXPORTS) == _declared()
+
+
+def test_diagnostics_stay_out_of_the_boundary_header():
+    """Profiling / diagnostic entry points live in rkh_diag.h; rkh.h declares only what replaces a reference interface."""
     hdr = open(os.path.join(ROOT, "include", "rkh.h")).read()
-    declared = set(re.findall(r"\b(rkh_[a-z0-9_]+)\s*\(", hdr)) - {"rkh_status"}
-    assert set(L.EXPORTS) == declared
+    for name in ("rkh_diag_feval_cycles", "rkh_nn_set_events", "rkh_nn_kernel_name", "rkh_planner_nn_profile",
+                 "rkh_planner_nn_pairs", "rkh_planner_steer_profile"):
+        assert name + "(" not in hdr
 
 
 def test_pod_layouts_match_the_header():
