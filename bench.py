@@ -249,6 +249,147 @@ def single_problem_rate(lib, scene, scn, P, max_vertices):
             "edges_collision_checked_per_s": edges / dt, "seconds": dt}
 
 
+def c3_rrtstar_rate(lib, ctx, events, P=16, max_vertices=20000, knn_n=1 << 20):
+    """BASELINE config C3 beside the headline: RRT* (quasi-static space of the same 6-DOF chain, star_neighborhood k-NN
+    rewiring) for P problems, and the k-NN sweep alone on a 1 Mi-vertex tree (k = 4 (floor(log2 n) + 1), star radius),
+    HIP-event timed, against the HBM peak by SURVEY 8(d): n * D * 8 algorithmic bytes per query batch."""
+    import torch
+
+    from reak_amd import scenarios
+
+    scn = scenarios.make_c3()
+    sc = lib.Scene(ctx, scn)
+    lo, hi, mi = scn.meta["lower"], scn.meta["upper"], scn.meta["min_interval"]
+    qs = lib.make_qs_space(6, lo, hi, mi)
+    pl = lib.RrtStarPlanner(sc, [scn.rrt_params(seed=9000 + i, max_vertices=max_vertices) for i in range(P)], qs)
+    t0 = time.perf_counter()
+    pl.solve_planning_query()
+    dt = time.perf_counter() - t0
+    it = sum(int(s.loop_iterations) for s in pl.all_stats)
+    ed = sum(int(s.edges_checked) for s in pl.all_stats)
+    rw = sum(int(s.rewires) for s in pl.all_stats)
+    pl.close()
+    D = 6
+    nn = lib.HipNeighborSearch(ctx, D, knn_n)
+    nn.fill_uniform(knn_n, seed=3)
+    logn = int(np.floor(np.log2(knn_n))) + 1
+    k, radius = 4 * logn, 3.0 * (logn / knn_n) ** (1.0 / D)
+    B = 8
+    q = torch.rand(B, D, dtype=torch.float64, device="cuda")
+    idx = torch.zeros(B, k, dtype=torch.int32, device="cuda")
+    dist = torch.zeros(B, k, dtype=torch.float64, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    call = lambda: lib._check(nn.lib.rkh_nn_queryk_async(nn.h, q.data_ptr(), B, k, float(radius), idx.data_ptr(),
+                                                         dist.data_ptr(), cnt.data_ptr()))
+    for _ in range(3):
+        call()
+    ctx.synchronize()
+    a, b = events.create(), events.create()
+    events.record(a, ctx.stream)
+    reps = 20
+    for _ in range(reps):
+        call()
+    events.record(b, ctx.stream)
+    ctx.synchronize()
+    ms = events.elapsed_ms(a, b) / reps
+    nn.close()
+    gbps = knn_n * D * 8 / (ms * 1e-3) / 1e9
+    return {"workload": "C3: 6-DOF chain, RRT* (quasi-static space), star_neighborhood k-NN rewiring", "problems": P,
+            "max_vertices": max_vertices, "iterations_per_s": it / dt, "edges_collision_checked_per_s": ed / dt,
+            "rewires": rw, "seconds": dt,
+            "knn_sweep": {"n": knn_n, "dims": D, "k": k, "queries_per_sweep": B, "us_per_batch": ms * 1e3,
+                          "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                          "note": "algorithmic bytes n * D * 8 per batch (the kernel makes two passes over the rows: bound "
+                                  "sweep + collect sweep; at 1 Mi x 6 the 48 MB tree is Infinity-Cache resident)"}}
+
+
+def c4_prm_rate(lib, ctx, P=16, max_vertices=1500):
+    """BASELINE config C4 as written: 12-DOF dual arm, PRM, 200 convex MESH obstacles (batched GJK)."""
+    from reak_amd import scenarios
+
+    scn = scenarios.make_c4(world_seed=1, meshes=True)
+    sc = lib.Scene(ctx, scn)
+    lo, hi, mi = scn.meta["lower"], scn.meta["upper"], scn.meta["min_interval"]
+    qs = lib.make_qs_space(12, lo, hi, mi)
+    prms = [scn.prm_params(seed=9100 + i, max_vertices=max_vertices, sampling_radius=1.5) for i in range(P)]
+    pl = lib.PrmPlanner(sc, prms, qs)
+    t0 = time.perf_counter()
+    pl.solve_planning_query()
+    dt = time.perf_counter() - t0
+    it = sum(int(s.loop_iterations) for s in pl.all_stats)
+    ed = sum(int(s.edges_checked) for s in pl.all_stats)
+    nv = sum(int(s.num_vertices) for s in pl.all_stats)
+    pl.close()
+    return {"workload": "C4: 12-DOF dual arm, PRM (quasi-static space), 200 convex mesh obstacles of 12-32 vertices, GJK",
+            "problems": P, "max_vertices": max_vertices, "iterations_per_s": it / dt,
+            "edges_collision_checked_per_s": ed / dt, "roadmap_vertices_per_s": nv / dt, "seconds": dt}
+
+
+def run_c5(args, rank, world, local_rank, dist, reduce_device, lib, scenarios, dist_utils, torch):
+    """BASELINE config C5: independent RRT* seeds (C3 world), --c5-problems per GPU, --c5-vertices each, sharded over the
+    ranks with no data-path collective; afterwards all-reduce(min) of the best solution cost and all-reduce(sum) of the
+    counters.  A step = one complete solve of the rank's seeds."""
+    ctx = lib.Context(local_rank)
+    scn = scenarios.make_c3()
+    scene = lib.Scene(ctx, scn)
+    lo, hi, mi = scn.meta["lower"], scn.meta["upper"], scn.meta["min_interval"]
+    qs = lib.make_qs_space(6, lo, hi, mi)
+    P = args.c5_problems
+
+    def run_step(step_index):
+        seeds = dist_utils.seeds_for_rank(step_index, rank, world, P)
+        pl = lib.RrtStarPlanner(scene, [scn.rrt_params(seed=s, max_vertices=args.c5_vertices) for s in seeds], qs)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        pl.solve_planning_query()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        r = {"seconds": dt, "nodes": sum(int(s.num_vertices) for s in pl.all_stats),
+             "edges": sum(int(s.edges_checked) for s in pl.all_stats),
+             "iters": sum(int(s.loop_iterations) for s in pl.all_stats),
+             "best": min(float(s.best_cost) for s in pl.all_stats)}
+        pl.close()
+        return r
+
+    for w in range(args.warmup):
+        run_step(1000 + w)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_begin = time.perf_counter()
+    tot = {"nodes": 0, "edges": 0, "iters": 0}
+    best = float("inf")
+    for k in range(args.steps):
+        r = run_step(k)
+        for key in tot:
+            tot[key] += r[key]
+        best = min(best, r["best"])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_begin
+    elapsed, nodes_all, edges_all, iters_all, best = dist_utils.reduce_results(dist, elapsed, tot["nodes"], tot["edges"],
+                                                                               tot["iters"], best, reduce_device)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "RRT* loop iterations/sec (+ edges-collision-checked/sec), config C5", "value": iters_all / elapsed,
+            "unit": "RRT* iterations/s", "edges_collision_checked_per_s": edges_all / elapsed,
+            "vertices_per_s": nodes_all / elapsed, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C5: 6-DOF chain, RRT* (quasi-static space, star_neighborhood k-NN rewiring), "
+                                   "independent seeds sharded one batch per GPU, best-cost all-reduce(min)",
+                       "vertices_per_seed": args.c5_vertices, "seeds_per_gpu": P,
+                       "parallelism": f"{world} x {P} independent RRT* planners"},
+            "best_solution_cost": None if best == float("inf") else best}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,6 +402,11 @@ def main():
                          "steer tail with the other's NN sweep, which paid before the steer waves were packed and the "
                          "batches fitted to whole passes of the machine; now one group is faster (DESIGN.md section 5)")
     ap.add_argument("--rounds-per-sync", type=int, default=16)
+    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
+                    help="c2 (default, BASELINE.json's metric): RRT with RK4 dynamics; c5: BASELINE config C5 -- independent "
+                         "RRT* seeds sharded over the ranks (one planner batch per GPU), best-cost all-reduce (min)")
+    ap.add_argument("--c5-vertices", type=int, default=1000000, help="vertices per RRT* seed of --workload c5")
+    ap.add_argument("--c5-problems", type=int, default=1, help="RRT* seeds per GPU of --workload c5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
     args = ap.parse_args()
@@ -303,6 +449,8 @@ def main():
 
     from reak_amd import dist_utils, lib, scenarios
 
+    if args.workload == "c5":
+        return run_c5(args, rank, world, local_rank, dist, reduce_device, lib, scenarios, dist_utils, torch)
     os.environ.setdefault("RKH_PROFILE_NN", "1")
     ctx = lib.Context(local_rank)
     events = HipEvents()
@@ -443,6 +591,8 @@ def main():
         if not args.no_microbench and world == 1:
             out["single_problem"] = [single_problem_rate(lib, scene, scn, 1, 20000),
                                      single_problem_rate(lib, scene, scn, 16, 20000)]
+            out["c3_rrtstar"] = c3_rrtstar_rate(lib, ctx, events)
+            out["c4_prm_meshes"] = c4_prm_rate(lib, ctx)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scn, args.max_vertices)
             nv_used = int(out["cpu_baseline"]["sample"].split("first ")[1].split(" ")[0])

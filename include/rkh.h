@@ -99,6 +99,14 @@ rkh_status rkh_nn_fill_uniform(rkh_nn* nn, uint64_t n, uint64_t seed);
  * RKH_ERR_UNSUPPORTED. */
 rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, const rkh_chain_base* base,
                             const rkh_shape* shapes, int n_shapes, rkh_scene** out);
+/* The same with convex vertex sets among the shapes (RKH_SHAPE_MESH): mesh_vertices = the pool [n_mesh_vertices][3] the
+ * mesh shapes index into.  Pairs with a mesh are evaluated by GJK over support maps (sphere = point + radius, capped
+ * cylinder = segment + radius, box, vertex set); the reference's closed forms stay in place for all other pairs.
+ * BASELINE config C4 ("200 mesh obstacles, batched GJK").  Meshes pair with spheres, capped cylinders, boxes and
+ * meshes; they have no finder against planes and cylinders. */
+rkh_status rkh_scene_create_with_meshes(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, const rkh_chain_base* base,
+                                        const rkh_shape* shapes, int n_shapes, const double* mesh_vertices,
+                                        uint32_t n_mesh_vertices, rkh_scene** out);
 rkh_status rkh_scene_destroy(rkh_scene* scene);
 int rkh_scene_num_dof(const rkh_scene* scene);
 int rkh_scene_num_pairs(const rkh_scene* scene);

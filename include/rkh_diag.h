@@ -26,6 +26,11 @@ const char* rkh_nn_kernel_name(void);
 rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double* u, uint32_t B, int iters,
                                  uint64_t* cycles);
 
+/* GJK distance of n world-anchored shape pairs (a[i], b[i]), any kinds GJK knows (sphere, capped cylinder, box, mesh):
+ * the check of the support-map query against the closed forms on primitive pairs. */
+rkh_status rkh_diag_gjk_distance(rkh_ctx* ctx, const rkh_shape* a, const rkh_shape* b, uint32_t n,
+                                 const double* mesh_vertices, uint32_t n_mesh_vertices, double* dist);
+
 /* With RKH_PROFILE_NN=1 in the environment at rkh_planner_create, every round brackets its NN sweep kernel with
  * HIP events on the planner stream: total kernel time, algorithmic bytes (n*D*8 per sweep) and launch count. */
 rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* total_bytes, uint64_t* launches);

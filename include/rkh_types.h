@@ -76,7 +76,11 @@ enum rkh_shape_kind {
   /* more shape_3D subclasses (geometry/shapes/{plane,cylinder}.hpp) */
   RKH_SHAPE_PLANE = 7,     /* dims[0..1] = mDimensions (x, y extents; they only enter the bounding radius of the cull:
                             * the enabled prox_plane_* routines treat the plane as infinite), normal = local z          */
-  RKH_SHAPE_CYLINDER = 8   /* dims[0] = length, dims[1] = radius (flat ends, axis = local z)                          */
+  RKH_SHAPE_CYLINDER = 8,  /* dims[0] = length, dims[1] = radius (flat ends, axis = local z)                          */
+  /* Convex vertex set ("mesh"): NOT a reference class (its proximity module has closed forms only, TODO_list.txt:230);
+   * BASELINE config C4's obstacles.  dims[0] = index of the shape's first vertex in the scene's vertex pool, dims[1] =
+   * number of vertices (the shape is their convex hull; local coordinates).  Distances through GJK (rkh.h). */
+  RKH_SHAPE_MESH = 9
 };
 
 typedef struct rkh_shape {

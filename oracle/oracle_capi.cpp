@@ -149,6 +149,24 @@ void* orc_scene_create(const rkh_kte_op* ops, int n_ops, const rkh_chain_base* b
   s->env = ProxyEnv(shapes, n_shapes);
   return s;
 }
+void* orc_scene_create_with_meshes(const rkh_kte_op* ops, int n_ops, const rkh_chain_base* base, const rkh_shape* shapes,
+                                   int n_shapes, const double* verts, int n_verts) {
+  Scene* s = new Scene();
+  s->chain = KteChain(ops, n_ops, *base);
+  s->env = ProxyEnv(shapes, n_shapes, verts, n_verts);
+  return s;
+}
+// GJK distance of n world-anchored pairs (the twin of rkh_diag_gjk_distance)
+void orc_gjk_distance(const rkh_shape* a, const rkh_shape* b, int n, const double* verts, double* out) {
+  for (int i = 0; i < n; ++i) {
+    ShapeG ga, gb;
+    ga.kind = a[i].kind; gb.kind = b[i].kind;
+    ga.g = to_pose(a[i].pose); gb.g = to_pose(b[i].pose);
+    ga.mesh_pool = verts; gb.mesh_pool = verts;
+    for (int k = 0; k < 3; ++k) { ga.dims[k] = a[i].dims[k]; gb.dims[k] = b[i].dims[k]; }
+    out[i] = gjk_distance(to_gjk(ga), to_gjk(gb));
+  }
+}
 void orc_scene_destroy(void* h) { delete static_cast<Scene*>(h); }
 int orc_scene_num_frames(void* h) { return static_cast<Scene*>(h)->chain.n_frames; }
 int orc_scene_num_finders(void* h) { return int(static_cast<Scene*>(h)->env.finders.size()); }

@@ -11,11 +11,13 @@
 #ifndef REAK_ORACLE_PROXIMITY_HPP
 #define REAK_ORACLE_PROXIMITY_HPP
 
+#include <algorithm>
 #include <cmath>
 #include <limits>
 #include <vector>
 
 #include "../include/rkh_types.h"
+#include "reak_gjk.hpp"
 #include "reak_kte.hpp"
 #include "reak_math.hpp"
 
@@ -32,6 +34,7 @@ struct ShapeG {
   int kind;
   Pose g;  // global pose
   double dims[3];
+  const double* mesh_pool = nullptr;  // RKH_SHAPE_MESH: the scene's vertex pool (dims[0] = first vertex, dims[1] = count)
   // shape_3D::getBoundingRadius: sphere.cpp:31, box.cpp:31, capped_cylinder.cpp:30
   double getBoundingRadius() const {
     switch (kind) {
@@ -49,6 +52,14 @@ struct ShapeG {
       }
       case RKH_SHAPE_CYLINDER:  // cylinder.cpp:33-35
         return std::sqrt(dims[1] * dims[1] + 0.25 * dims[0] * dims[0]);
+      case RKH_SHAPE_MESH: {  // the build's convex vertex set: radius about the local origin
+        double r2 = 0.0;
+        for (int i = 0; i < int(dims[1]); ++i) {
+          const double* v = mesh_pool + 3 * (std::size_t(dims[0]) + i);
+          r2 = std::max(r2, v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        }
+        return std::sqrt(r2);
+      }
     }
     return 0.0;
   }
@@ -435,7 +446,8 @@ inline ProxRecord prox_sphere_cylinder(const ShapeG& sp, const ShapeG& cy) {
 // finder's own argument order (createProxFinderList: proxy_query_model.cpp:215-374).
 struct ProxFinder {
   // 1 sphere-sphere, 2 sphere-ccyl, 3 sphere-box, 4 ccyl-ccyl, 5 ccyl-box,
-  // 6 plane-plane, 7 plane-sphere, 8 plane-ccyl, 9 plane-cylinder, 10 plane-box, 11 sphere-cylinder
+  // 6 plane-plane, 7 plane-sphere, 8 plane-ccyl, 9 plane-cylinder, 10 plane-box, 11 sphere-cylinder,
+  // 12 GJK (a convex vertex set against sphere / ccyl / box / vertex set: the build's query, reak_gjk.hpp)
   int routine;
   int s1, s2;   // indices into the combined shape table
 };
@@ -450,7 +462,11 @@ inline void createProxFinderList(const std::vector<rkh_shape>& shapes, const std
   for (int i : model1)
     for (int j : model2) {
       const int ki = shapes[i].kind, kj = shapes[j].kind;
-      if (ki == RKH_SHAPE_PLANE || kj == RKH_SHAPE_PLANE) {
+      if (ki == RKH_SHAPE_MESH || kj == RKH_SHAPE_MESH) {  // not a reference pair; shape1 = model 1's shape
+        const int ko = (ki == RKH_SHAPE_MESH) ? kj : ki;
+        if (ko == RKH_SHAPE_SPHERE || ko == RKH_SHAPE_CCYLINDER || ko == RKH_SHAPE_BOX || ko == RKH_SHAPE_MESH)
+          out.push_back({12, i, j});
+      } else if (ki == RKH_SHAPE_PLANE || kj == RKH_SHAPE_PLANE) {
         int pl = (ki == RKH_SHAPE_PLANE) ? i : j;
         int other = (ki == RKH_SHAPE_PLANE) ? j : i;
         int ko = shapes[other].kind;
@@ -478,7 +494,24 @@ inline void createProxFinderList(const std::vector<rkh_shape>& shapes, const std
     }
 }
 
+inline GjkShape to_gjk(const ShapeG& s) {
+  GjkShape r;
+  r.kind = s.kind;
+  r.g = s.g;
+  for (int k = 0; k < 3; ++k) r.dims[k] = s.dims[k];
+  if (s.kind == RKH_SHAPE_MESH) {
+    r.verts = s.mesh_pool + 3 * std::size_t(s.dims[0]);
+    r.nv = int(s.dims[1]);
+  }
+  return r;
+}
+
 inline ProxRecord computeProximity(const ProxFinder& f, const std::vector<ShapeG>& g) {
+  if (f.routine == 12) {
+    ProxRecord r;
+    r.mDistance = gjk_distance(to_gjk(g[f.s1]), to_gjk(g[f.s2]));
+    return r;
+  }
   switch (f.routine) {
     case 1: return prox_sphere_sphere(g[f.s1], g[f.s2]);
     case 2: return prox_sphere_ccylinder(g[f.s1], g[f.s2]);
@@ -521,6 +554,7 @@ inline double findMinimumDistance(const std::vector<ProxFinder>& finders, const 
 // (robot model = chain-anchored shapes, environment model = world shapes).
 struct ProxyEnv {
   std::vector<rkh_shape> shapes;
+  std::vector<double> mesh_pool;  // vertex pool of the RKH_SHAPE_MESH shapes
   std::vector<int> robot, env;
   std::vector<ProxFinder> finders;
   std::vector<ProxFinder2> finders2;  // planar scenes: proxy_query_pair_2D
@@ -528,7 +562,8 @@ struct ProxyEnv {
   long n_pair_tests = 0;
 
   ProxyEnv() {}
-  ProxyEnv(const rkh_shape* s, int n) : shapes(s, s + n) {
+  ProxyEnv(const rkh_shape* s, int n, const double* verts = nullptr, int n_verts = 0)
+      : shapes(s, s + n), mesh_pool(verts, verts + 3 * std::size_t(n_verts)) {
     for (int i = 0; i < n; ++i) (shapes[i].anchor >= 0 ? robot : env).push_back(i);
     for (int i = 0; i < n; ++i) planar = planar || (shapes[i].kind >= RKH_SHAPE_CIRCLE && shapes[i].kind <= RKH_SHAPE_CRECT);
     if (planar) createProxFinderList2D(shapes, robot, env, finders2);
@@ -548,6 +583,7 @@ struct ProxyEnv {
     g.resize(shapes.size());
     for (std::size_t i = 0; i < shapes.size(); ++i) {
       g[i].kind = shapes[i].kind;
+      g[i].mesh_pool = mesh_pool.data();
       for (int k = 0; k < 3; ++k) g[i].dims[k] = shapes[i].dims[k];
       Pose local = to_pose(shapes[i].pose);
       if (shapes[i].anchor >= 0) {

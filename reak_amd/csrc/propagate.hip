@@ -600,7 +600,7 @@ __device__ double proximity_min(const SceneDev* __restrict__ sc, const CPack<N>&
         const double r2 = pr.s1_is_robot ? es.brad : rs.brad;
         skip = (norm_2(c2p - c1) - r1 - r2 > 0.0);
       }
-      if (!skip) d = pr.s1_is_robot ? pair_distance(pr.routine, A, Bv) : pair_distance(pr.routine, Bv, A);
+      if (!skip) d = pr.s1_is_robot ? pair_distance(pr.routine, A, Bv, sc->mesh_verts) : pair_distance(pr.routine, Bv, A, sc->mesh_verts);
     }
     if (d < dmin) dmin = d;
     if (cull_positive) {

@@ -12,6 +12,8 @@
 #include "../../include/rkh_types.h"
 #include "device_math.h"
 
+#include "gjk_device.h"
+
 namespace rkh {
 
 struct ShapeG {  // shape with resolved global pose
@@ -24,13 +26,19 @@ struct ShapeG {  // shape with resolved global pose
 enum PairRoutine : int {
   PR_NONE = 0,  // the reference has no finder for the pair (proxy_query_model.cpp:317-320,341-349,366-369)
   PR_SPHERE_SPHERE = 1, PR_SPHERE_CCYL = 2, PR_SPHERE_BOX = 3, PR_CCYL_CCYL = 4, PR_CCYL_BOX = 5,
-  PR_PLANE_PLANE = 6, PR_PLANE_SPHERE = 7, PR_PLANE_CCYL = 8, PR_PLANE_CYL = 9, PR_PLANE_BOX = 10, PR_SPHERE_CYL = 11
+  PR_PLANE_PLANE = 6, PR_PLANE_SPHERE = 7, PR_PLANE_CCYL = 8, PR_PLANE_CYL = 9, PR_PLANE_BOX = 10, PR_SPHERE_CYL = 11,
+  PR_GJK = 12  // a convex vertex set against a sphere / capped cylinder / box / vertex set (gjk_device.h); shape1 = model 1's
 };
 
 // createProxFinderList's cascade of kinds (proxy_query_model.cpp:225-370) for one pair: the routine, and whether the
 // FIRST shape is the routine's shape1 (plane before sphere before capped cylinder; equal kinds: model 1's shape).
 RKH_DI int pair_routine(int ka, int kb, bool* a_is_shape1) {
   auto other = [&](int first_kind) { return (ka == first_kind) ? kb : ka; };
+  if (ka == RKH_SHAPE_MESH || kb == RKH_SHAPE_MESH) {  // not a reference pair: the build's GJK query
+    *a_is_shape1 = true;
+    const int ko = other(RKH_SHAPE_MESH);
+    return (ko == RKH_SHAPE_SPHERE || ko == RKH_SHAPE_CCYLINDER || ko == RKH_SHAPE_BOX || ko == RKH_SHAPE_MESH) ? PR_GJK : PR_NONE;
+  }
   if (ka == RKH_SHAPE_PLANE || kb == RKH_SHAPE_PLANE) {
     *a_is_shape1 = (ka == RKH_SHAPE_PLANE);
     switch (other(RKH_SHAPE_PLANE)) {
@@ -298,8 +306,24 @@ RKH_DI double dist_sphere_cyl(const ShapeG& sp, const ShapeG& cy) {  // prox_sph
   return norm_2(p2 - sp_c) - sr;
 }
 
-// (shape1, shape2) are already in the routine's own argument order
-RKH_DI double pair_distance(int routine, const ShapeG& s1, const ShapeG& s2) {
+RKH_DI GjkShape to_gjk(const ShapeG& s, const double* mesh_pool) {
+  GjkShape g;
+  g.kind = s.kind;
+  g.pos = s.pos;
+  g.R = rotmat(s.q);
+  g.d0 = s.d0; g.d1 = s.d1; g.d2 = s.d2;
+  g.verts = nullptr;
+  g.nv = 0;
+  if (s.kind == RKH_SHAPE_MESH) {
+    g.verts = mesh_pool + 3 * int(s.d0);
+    g.nv = int(s.d1);
+  }
+  return g;
+}
+
+// (shape1, shape2) are already in the routine's own argument order; mesh_pool: the scene's vertex pool (GJK pairs only)
+RKH_DI double pair_distance(int routine, const ShapeG& s1, const ShapeG& s2, const double* mesh_pool = nullptr) {
+  if (routine == PR_GJK) return gjk_distance(to_gjk(s1, mesh_pool), to_gjk(s2, mesh_pool));
   switch (routine) {
     case PR_SPHERE_SPHERE: return dist_sphere_sphere(s1, s2);
     case PR_SPHERE_CCYL: return dist_sphere_ccyl(s1, s2);

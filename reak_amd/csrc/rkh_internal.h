@@ -152,6 +152,8 @@ struct SceneDev {
   // capped cylinder-cylinder)
   unsigned long long env_finder_mask[9][kMaxEnvShapes / 64];
   int32_t has_ext_shapes;  // 1: the scene holds a plane or a cylinder (not handled by the first-generation lane kernel)
+  int32_t has_meshes;      // 1: convex vertex sets among the shapes (GJK pairs; wave-per-edge and quasi-static kernels)
+  const double* mesh_verts;  // device pointer: the vertex pool [n][3] the mesh shapes index into (dims[0], dims[1])
 };
 
 }  // namespace rkh
@@ -186,6 +188,7 @@ struct rkh_scene {
   rkh::SceneDev host;
   rkh::SceneDev* d_scene = nullptr;
   void* d_pairs = nullptr;  // PairDev[n_pairs], sorted by routine
+  double* d_mesh_verts = nullptr;  // vertex pool of the mesh shapes
   int* d_err = nullptr;
   int n_pairs = 0;
 };
@@ -264,6 +267,7 @@ rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev*
 // the two-lanes-per-edge kernel handles one serial chain, with at most a tip-to-world beam
 inline bool scene_fits_lane_kernel(const SceneDev& S, int variant = 2) {
   if (variant == 1 && S.has_ext_shapes) return false;  // propagate_lane.hip knows spheres, boxes and capped cylinders
+  if (S.has_meshes) return false;                       // GJK pairs run in the wave-per-edge / quasi-static kernels
   return S.n_branches == 0 && (!S.beam_on || (S.beam_j1 == S.n_dof - 1 && S.beam_j2 < 0));
 }
 // one lane per edge (propagate_lane.hip); d_ws: propagate_lanes_workspace_bytes() of device memory

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "proximity_device.h"
 #include "rkh_internal.h"
 
 using namespace rkh;
@@ -22,8 +23,25 @@ static void host_rotmat(const double* q, double* R) {
   std::memcpy(R, r, sizeof(r));
 }
 
+static thread_local const double* g_mesh_vertices = nullptr;
+static thread_local uint32_t g_n_mesh_vertices = 0;
+
+static bool mesh_range_ok(const rkh_shape& s) {
+  const double first = s.dims[0], cnt = s.dims[1];
+  return first >= 0.0 && cnt >= 1.0 && first == std::floor(first) && cnt == std::floor(cnt) &&
+         first + cnt <= double(g_n_mesh_vertices);
+}
+
 static double bounding_radius(const rkh_shape& s) {
   switch (s.kind) {
+    case RKH_SHAPE_MESH: {  // about the local origin, like the reference's shapes
+      double r2 = 0.0;
+      for (int i = 0; i < int(s.dims[1]); ++i) {
+        const double* v = g_mesh_vertices + 3 * (size_t(s.dims[0]) + i);
+        r2 = std::max(r2, v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      }
+      return std::sqrt(r2);
+    }
     case RKH_SHAPE_SPHERE: return s.dims[0];
     case RKH_SHAPE_BOX: {
       double acc = 0.0;
@@ -45,6 +63,10 @@ static double bounding_radius(const rkh_shape& s) {
 static int host_pair_routine(int ka, int kb, bool* a_is_shape1) {
   auto other = [&](int first_kind) { return (ka == first_kind) ? kb : ka; };
   *a_is_shape1 = true;
+  if (ka == RKH_SHAPE_MESH || kb == RKH_SHAPE_MESH) {  // the build's GJK query (no reference finder)
+    const int ko = other(RKH_SHAPE_MESH);
+    return (ko == RKH_SHAPE_SPHERE || ko == RKH_SHAPE_CCYLINDER || ko == RKH_SHAPE_BOX || ko == RKH_SHAPE_MESH) ? 12 : 0;
+  }
   if (ka == RKH_SHAPE_PLANE || kb == RKH_SHAPE_PLANE) {
     *a_is_shape1 = (ka == RKH_SHAPE_PLANE);
     switch (other(RKH_SHAPE_PLANE)) {
@@ -112,12 +134,33 @@ rkh_status build_dyn_dev(const rkh_dyn_space& sp, double fraction, DynDev* out) 
   return RKH_OK;
 }
 
+// diagnostic: GJK on n world-anchored pairs (rkh_diag_gjk_distance)
+__global__ void gjk_pairs_kernel(const rkh_shape* __restrict__ a, const rkh_shape* __restrict__ b, uint32_t n,
+                                 const double* __restrict__ pool, double* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  auto conv = [](const rkh_shape& s) {
+    ShapeG g;
+    g.kind = s.kind;
+    g.pos = mk3(s.pose.pos[0], s.pose.pos[1], s.pose.pos[2]);
+    g.q = d4{s.pose.quat[0], s.pose.quat[1], s.pose.quat[2], s.pose.quat[3]};
+    g.d0 = s.dims[0]; g.d1 = s.dims[1]; g.d2 = s.dims[2];
+    return g;
+  };
+  out[i] = gjk_distance(to_gjk(conv(a[i]), pool), to_gjk(conv(b[i]), pool));
+}
+
 }  // namespace rkh
 
 static rkh_status upload_scene(rkh_ctx* ctx, rkh_scene* sc, const std::vector<PairDev>& pairs, rkh_scene** out) {
-  const SceneDev& S = sc->host;
+  SceneDev& S = sc->host;
   sc->n_pairs = int(pairs.size());
   RKH_HIP(hipSetDevice(ctx->device));
+  if (S.has_meshes && g_n_mesh_vertices > 0) {
+    RKH_HIP(hipMalloc(&sc->d_mesh_verts, size_t(g_n_mesh_vertices) * 3 * sizeof(double)));
+    RKH_HIP(hipMemcpy(sc->d_mesh_verts, g_mesh_vertices, size_t(g_n_mesh_vertices) * 3 * sizeof(double), hipMemcpyHostToDevice));
+    S.mesh_verts = sc->d_mesh_verts;
+  }
   RKH_HIP(hipMalloc(&sc->d_scene, sizeof(SceneDev)));
   RKH_HIP(hipMemcpy(sc->d_scene, &S, sizeof(SceneDev), hipMemcpyHostToDevice));
   RKH_HIP(hipMalloc(&sc->d_pairs, std::max<size_t>(1, pairs.size()) * sizeof(PairDev)));
@@ -237,7 +280,16 @@ extern "C" {
 
 rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, const rkh_chain_base* base,
                             const rkh_shape* shapes, int n_shapes, rkh_scene** out) {
+  return rkh_scene_create_with_meshes(ctx, prog, n_ops, base, shapes, n_shapes, nullptr, 0, out);
+}
+
+rkh_status rkh_scene_create_with_meshes(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, const rkh_chain_base* base,
+                                        const rkh_shape* shapes, int n_shapes, const double* mesh_vertices,
+                                        uint32_t n_mesh_vertices, rkh_scene** out) {
   if (!ctx || !prog || !base || !out || n_ops < 1 || (n_shapes > 0 && !shapes)) return RKH_ERR_BAD_ARG;
+  if (n_mesh_vertices > 0 && !mesh_vertices) return RKH_ERR_BAD_ARG;
+  g_mesh_vertices = mesh_vertices;  // for bounding_radius() / validation while the scene is built (one host thread per ctx)
+  g_n_mesh_vertices = n_mesh_vertices;
   if (prog[0].kind == RKH_KTE_REVOLUTE_JOINT_2D) return create_planar_scene(ctx, prog, n_ops, base, shapes, n_shapes, out);
   const bool has_beam = n_ops > 1 && prog[n_ops - 1].kind == RKH_KTE_FLEXIBLE_BEAM_3D;
   if (has_beam) --n_ops;  // the beam is validated below, after the chain
@@ -383,13 +435,14 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
     const int i = order[oi];
     const rkh_shape& s = shapes[i];
     const bool kind_ok = (s.kind >= RKH_SHAPE_SPHERE && s.kind <= RKH_SHAPE_CCYLINDER) || s.kind == RKH_SHAPE_PLANE ||
-                         s.kind == RKH_SHAPE_CYLINDER;
+                         s.kind == RKH_SHAPE_CYLINDER || (s.kind == RKH_SHAPE_MESH && mesh_range_ok(s));
     if (!kind_ok) {
       delete sc;
       set_error("rkh_scene_create: unsupported shape kind");
       return RKH_ERR_UNSUPPORTED;
     }
     if (s.kind == RKH_SHAPE_PLANE || s.kind == RKH_SHAPE_CYLINDER) S.has_ext_shapes = 1;
+    if (s.kind == RKH_SHAPE_MESH) S.has_meshes = 1;
     ShapeDev d;
     std::memset(&d, 0, sizeof(d));
     d.kind = s.kind;
@@ -419,7 +472,7 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
       S.env_cull[S.n_env][3] = d.brad;
       if (d.kind <= RKH_SHAPE_CCYLINDER)
         S.env_kind_mask[d.kind == RKH_SHAPE_SPHERE ? 0 : (d.kind == RKH_SHAPE_BOX ? 1 : 2)][S.n_env / 64] |= 1ull << (S.n_env % 64);
-      for (int k = RKH_SHAPE_SPHERE; k <= RKH_SHAPE_CYLINDER; ++k) {
+      for (int k = RKH_SHAPE_SPHERE; k <= RKH_SHAPE_CYLINDER; ++k) {  // (meshes do not reach the kernel that reads this)
         bool first;
         if (host_pair_routine(k, d.kind, &first) != 0) S.env_finder_mask[k][S.n_env / 64] |= 1ull << (S.n_env % 64);
       }
@@ -494,10 +547,33 @@ rkh_status rkh_scene_create(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, con
   return upload_scene(ctx, sc, pairs, out);
 }
 
+rkh_status rkh_diag_gjk_distance(rkh_ctx* ctx, const rkh_shape* a, const rkh_shape* b, uint32_t n,
+                                 const double* mesh_vertices, uint32_t n_mesh_vertices, double* dist) {
+  if (!ctx || !a || !b || !dist) return RKH_ERR_BAD_ARG;
+  if (n == 0) return RKH_OK;
+  RKH_HIP(hipSetDevice(ctx->device));
+  rkh_shape *da = nullptr, *db = nullptr;
+  double *dv = nullptr, *dd = nullptr;
+  RKH_HIP(hipMalloc(&da, n * sizeof(rkh_shape)));
+  RKH_HIP(hipMalloc(&db, n * sizeof(rkh_shape)));
+  RKH_HIP(hipMalloc(&dd, n * sizeof(double)));
+  RKH_HIP(hipMalloc(&dv, std::max<size_t>(1, size_t(n_mesh_vertices) * 3) * sizeof(double)));
+  RKH_HIP(hipMemcpy(da, a, n * sizeof(rkh_shape), hipMemcpyHostToDevice));
+  RKH_HIP(hipMemcpy(db, b, n * sizeof(rkh_shape), hipMemcpyHostToDevice));
+  if (n_mesh_vertices) RKH_HIP(hipMemcpy(dv, mesh_vertices, size_t(n_mesh_vertices) * 3 * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(rkh::gjk_pairs_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, da, db, n, dv, dd);
+  RKH_HIP(hipGetLastError());
+  RKH_HIP(hipMemcpyAsync(dist, dd, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RKH_HIP(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dv); (void)hipFree(dd);
+  return RKH_OK;
+}
+
 rkh_status rkh_scene_destroy(rkh_scene* scene) {
   if (!scene) return RKH_OK;
   hipFree(scene->d_scene);
   hipFree(scene->d_pairs);
+  if (scene->d_mesh_verts) hipFree(scene->d_mesh_verts);
   hipFree(scene->d_err);
   delete scene;
   return RKH_OK;

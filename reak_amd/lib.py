@@ -69,7 +69,7 @@ EXPORTS = [
     "rkh_nn_create", "rkh_nn_destroy", "rkh_nn_clear", "rkh_nn_size", "rkh_nn_append", "rkh_nn_query1",
     "rkh_nn_queryk", "rkh_nn_query1_async", "rkh_nn_queryk_async", "rkh_nn_fill_uniform", "rkh_nn_kernel_name",
     "rkh_nn_set_coord_bound",
-    "rkh_scene_create", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
+    "rkh_scene_create", "rkh_scene_create_with_meshes", "rkh_diag_gjk_distance", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
     "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
@@ -119,6 +119,9 @@ def load():
     lib.rkh_nn_kernel_name.restype = C.c_char_p
     lib.rkh_scene_create.argtypes = [vp, C.POINTER(T.KteOp), C.c_int, C.POINTER(T.ChainBase), C.POINTER(T.Shape), C.c_int,
                                      C.POINTER(vp)]
+    lib.rkh_scene_create_with_meshes.argtypes = [vp, C.POINTER(T.KteOp), C.c_int, C.POINTER(T.ChainBase), C.POINTER(T.Shape),
+                                                 C.c_int, dp, u32, C.POINTER(vp)]
+    lib.rkh_diag_gjk_distance.argtypes = [vp, C.POINTER(T.Shape), C.POINTER(T.Shape), u32, dp, u32, dp]
     lib.rkh_scene_destroy.argtypes = [vp]
     lib.rkh_scene_num_dof.argtypes = [vp]
     lib.rkh_scene_num_pairs.argtypes = [vp]
@@ -256,6 +259,16 @@ class HipNeighborSearch:
             pass
 
 
+def gjk_distance(ctx, a, b, mesh_vertices=None):
+    """GJK distance of the world-anchored shape pairs (a[i], b[i]) (rkh_diag_gjk_distance)."""
+    n = len(a)
+    aa, bb = T.as_array(list(a), T.Shape), T.as_array(list(b), T.Shape)
+    verts = np.zeros((0, 3)) if mesh_vertices is None else np.ascontiguousarray(mesh_vertices, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros(n)
+    _check(ctx.lib.rkh_diag_gjk_distance(ctx.h, aa, bb, n, T.dptr(verts) if len(verts) else None, len(verts), T.dptr(out)))
+    return out
+
+
 class Scene:
     def __init__(self, ctx, scn):
         self.ctx, self.lib, self.scn = ctx, ctx.lib, scn
@@ -263,8 +276,15 @@ class Scene:
         self._ops = scn.ops_array()
         self._shapes = scn.shapes_array() if scn.shapes else (T.Shape * 1)()
         self.h = C.c_void_p()
-        _check(self.lib.rkh_scene_create(ctx.h, self._ops, len(scn.ops), C.byref(scn.base), self._shapes, len(scn.shapes),
-                                         C.byref(self.h)))
+        verts = getattr(scn, "mesh_vertices", None)
+        if verts is not None and len(verts):  # convex vertex sets among the shapes (RKH_SHAPE_MESH)
+            self._verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+            _check(self.lib.rkh_scene_create_with_meshes(ctx.h, self._ops, len(scn.ops), C.byref(scn.base), self._shapes,
+                                                         len(scn.shapes), T.dptr(self._verts), len(self._verts),
+                                                         C.byref(self.h)))
+        else:
+            _check(self.lib.rkh_scene_create(ctx.h, self._ops, len(scn.ops), C.byref(scn.base), self._shapes,
+                                             len(scn.shapes), C.byref(self.h)))
 
     @property
     def num_pairs(self):

@@ -24,6 +24,7 @@ class Scenario:
     start: np.ndarray
     goal: np.ndarray
     meta: dict = field(default_factory=dict)
+    mesh_vertices: np.ndarray = None  # [n][3] vertex pool of the SHAPE_MESH shapes (dims = first vertex, count)
 
     @property
     def D(self):
@@ -362,11 +363,30 @@ def make_c3(world_seed=1, min_interval=0.05):
     return scn
 
 
-def make_c4(world_seed=1, n_obstacles=200, capsule_radius=0.05, mount_y=0.35, min_interval=0.05, beam=None):
+def random_convex_mesh(rng, n_vertices, radius):
+    """A random convex vertex set: points on an ellipsoid (every point of an ellipsoid's surface is an extreme point of
+    the set) with semi-axes in [0.5, 1] x radius, so the bounding radius about the local origin is <= radius."""
+    axes = radius * rng.uniform(0.5, 1.0, size=3)
+    axes[int(rng.integers(0, 3))] = radius
+    u = rng.normal(size=(n_vertices, 3))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    return u * axes[None, :]
+
+
+def box_as_mesh(dims):
+    """The eight corners of a box (for checking the GJK mesh path against the reference's box routines)."""
+    hx, hy, hz = 0.5 * dims[0], 0.5 * dims[1], 0.5 * dims[2]
+    return np.array([[sx * hx, sy * hy, sz * hz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+
+
+def make_c4(world_seed=1, n_obstacles=200, capsule_radius=0.05, mount_y=0.35, min_interval=0.05, beam=None, meshes=False):
     """BASELINE config C4 (kinematic part): 12-DOF dual arm -- two CRS-like 6-R arms on fixed mounts (rigid links from
     the chain base) at y = -/+ mount_y -- and 200 convex obstacles, planned in the quasi-static joint space (PRM).
-    The reference's proximity module has closed-form pairs only (no meshes / GJK), so the obstacles are its spheres,
-    boxes and capped cylinders; the flexible beam of C4 is a force element and plays no role in a quasi-static space."""
+    meshes=False: the obstacles are the reference's own shapes (spheres, boxes, capped cylinders; closed forms).
+    meshes=True: C4 as BASELINE.json words it -- 200 convex MESH obstacles (random convex vertex sets of 12-32 vertices,
+    bounding radius 0.05-0.25 m) evaluated by batched GJK; the reference has no such shape, the build's
+    definition is in reak_amd/csrc/gjk_device.h.  The flexible beam of C4 is a force element and plays no role in a
+    quasi-static space."""
     rng = np.random.Generator(np.random.PCG64(4000 + world_seed))
     axes, lengths, offsets, masses, inertias, joint_inertias = crs_like_chain()
     n1 = len(axes)
@@ -418,6 +438,19 @@ def make_c4(world_seed=1, n_obstacles=200, capsule_radius=0.05, mount_y=0.35, mi
     tops = [np.array([0.0, -mount_y, sum(lengths)]), np.array([0.0, mount_y, sum(lengths)])]
     roots = [np.array([0.0, -mount_y, 0.0]), np.array([0.0, mount_y, 0.0])]
     kinds = []
+    pool = []
+    while meshes and len(kinds) < n_obstacles:
+        center = rng.uniform([-1.0, -1.4, 0.0], [1.0, 1.4, 1.4])
+        brad = rng.uniform(0.05, 0.25)
+        if min(_dist_point_segment(center, roots[a], tops[a]) for a in range(2)) < brad + capsule_radius + 0.12:
+            continue
+        verts = random_convex_mesh(rng, int(rng.integers(12, 33)), brad)
+        s = T.Shape(kind=T.SHAPE_MESH, anchor=-1)
+        s.dims[:] = [float(sum(len(v) for v in pool)), float(len(verts)), 0.0]
+        s.pose = T.make_pose(center, _random_unit_quat(rng))
+        pool.append(verts)
+        shapes.append(s)
+        kinds.append(T.SHAPE_MESH)
     while len(kinds) < n_obstacles:
         kind = [T.SHAPE_SPHERE, T.SHAPE_BOX, T.SHAPE_CCYLINDER][int(rng.integers(0, 3))]
         center = rng.uniform([-1.0, -1.4, 0.0], [1.0, 1.4, 1.4])
@@ -447,7 +480,8 @@ def make_c4(world_seed=1, n_obstacles=200, capsule_radius=0.05, mount_y=0.35, mi
     return Scenario(name="C4", ops=ops, base=base, shapes=shapes, dyn=dyn, n_dof=n, n_frames=frame,
                     start=np.zeros(n), goal=goal,
                     meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi), "min_interval": min_interval,
-                          "world_seed": world_seed, "n_obstacles": n_obstacles, "obstacle_kinds": kinds})
+                          "world_seed": world_seed, "n_obstacles": n_obstacles, "obstacle_kinds": kinds},
+                    mesh_vertices=(np.concatenate(pool) if pool else None))
 
 
 def make_random_chain(n, seed=1, n_obstacles=12):

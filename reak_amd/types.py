@@ -26,6 +26,7 @@ SHAPE_RECTANGLE = 5
 SHAPE_CRECT = 6
 SHAPE_PLANE = 7      # dims = (x extent, y extent); normal = local z
 SHAPE_CYLINDER = 8   # dims = (length, radius); flat ends, axis = local z
+SHAPE_MESH = 9       # convex vertex set: dims = (first vertex in the scene's pool, vertex count)
 
 
 class Pose(C.Structure):

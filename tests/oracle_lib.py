@@ -140,7 +140,16 @@ class OracleScene:
         self.scn = scn
         self._ops = scn.ops_array()
         self._shapes = scn.shapes_array() if scn.shapes else (T.Shape * 1)()
-        self.h = self.lib.orc_scene_create(self._ops, len(scn.ops), C.byref(scn.base), self._shapes, len(scn.shapes))
+        verts = getattr(scn, "mesh_vertices", None)
+        if verts is not None and len(verts):
+            self._verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+            self.lib.orc_scene_create_with_meshes.restype = C.c_void_p
+            self.lib.orc_scene_create_with_meshes.argtypes = [C.POINTER(T.KteOp), C.c_int, C.POINTER(T.ChainBase),
+                                                              C.POINTER(T.Shape), C.c_int, C.POINTER(C.c_double), C.c_int]
+            self.h = self.lib.orc_scene_create_with_meshes(self._ops, len(scn.ops), C.byref(scn.base), self._shapes,
+                                                           len(scn.shapes), T.dptr(self._verts), len(self._verts))
+        else:
+            self.h = self.lib.orc_scene_create(self._ops, len(scn.ops), C.byref(scn.base), self._shapes, len(scn.shapes))
         self.n = scn.n_dof
         self.D = 2 * scn.n_dof
 
@@ -266,6 +275,25 @@ class OracleScene:
         self.lib.orc_rrt_copy(T.dptr(pos), T.u32ptr(parent), T.u32ptr(nn_seq),
                               accept.ctypes.data_as(C.POINTER(C.c_uint8)), T.dptr(goal_dist))
         return {"pos": pos, "parent": parent, "nn_seq": nn_seq[:it], "accept": accept[:it], "goal_dist": goal_dist[: nv - 1]}
+
+
+def gjk_distance(a, b, mesh_vertices=None):
+    """The oracle's GJK on world-anchored shape pairs (a[i], b[i])."""
+    lib = load()
+    n = len(a)
+    aa, bb = T.as_array(list(a), T.Shape), T.as_array(list(b), T.Shape)
+    verts = np.zeros((1, 3)) if mesh_vertices is None else np.ascontiguousarray(mesh_vertices, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros(n)
+    lib.orc_gjk_distance.argtypes = [C.POINTER(T.Shape), C.POINTER(T.Shape), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.orc_gjk_distance(aa, bb, n, T.dptr(verts), T.dptr(out))
+    return out
+
+
+def pair_distance(a, b):
+    """The restated reference's closed form for one world-anchored pair (NaN: no finder)."""
+    lib = load()
+    lib.orc_pair_distance.restype = C.c_double
+    return lib.orc_pair_distance(C.byref(a), C.byref(b))
 
 
 def nn1(q, pts, fast=False):

@@ -38,6 +38,8 @@ def test_oracle_reproduces_golden(oracle, gold, c2):
     assert np.array_equal(steps, gold["steer_steps"]) and np.allclose(xo, gold["steer_x"], rtol=1e-11, atol=1e-12)
     idx, dist = oracle.nn1(gold["nn_q"], gold["nn_pts"])
     assert np.array_equal(idx, gold["nn_idx"]) and np.array_equal(dist, gold["nn_dist"])
+    kidx, kdist, kcnt = oracle.knn(gold["nn_q"], gold["nn_pts"], 52, radius=4.0)
+    assert np.array_equal(kidx, gold["knn_idx"]) and np.array_equal(kdist, gold["knn_dist"]) and np.array_equal(kcnt, gold["knn_cnt"])
     prm = c2.rrt_params(seed=2, max_vertices=1500)
     rc, o, tree = osc.rrt_dyn(prm)
     assert list(gold["rrt2_counts"]) == [o.num_vertices, o.iterations, o.edges_checked, o.num_solutions]
@@ -65,6 +67,16 @@ def test_hip_reproduces_golden(gold, c2):
     nn.added_vertices(gold["nn_pts"])
     idx, dist = nn.nearest(gold["nn_q"])
     assert np.array_equal(idx, gold["nn_idx"]) and np.array_equal(dist, gold["nn_dist"])
+    # k-NN + radius (k = 52 = 4 (floor(log2 5000) + 1), the C1 neighbourhood): counts and distances bit for bit; the
+    # indices too wherever the distances are distinct (among exact ties the reference's order is std::heap-defined)
+    kidx, kdist, kcnt = nn.k_nearest(gold["nn_q"], 52, radius=4.0)
+    assert np.array_equal(kcnt, gold["knn_cnt"]) and np.array_equal(kdist, gold["knn_dist"])
+    for b in range(len(kcnt)):
+        c = int(kcnt[b])
+        d = kdist[b, :c]
+        distinct = np.r_[True, d[1:] != d[:-1]] & np.r_[d[:-1] != d[1:], True]
+        assert np.array_equal(kidx[b, :c][distinct], gold["knn_idx"][b, :c][distinct])
+        assert set(kidx[b, :c]) == set(gold["knn_idx"][b, :c])
     # planner level: three seeds in ONE batch (one launch per kernel per round for all of them)
     pl = L.RrtPlanner(sc, [c2.rrt_params(seed=s, max_vertices=1500) for s in (1, 2, 3)])
     pl.solve_planning_query()

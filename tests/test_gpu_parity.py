@@ -686,6 +686,85 @@ def test_c4_dual_arm_quasi_static(L, ctx, oracle):
     _prm_same(st, pm.graph(), ro, rg)
 
 
+# ------------------------------------------------------------------ GJK / convex meshes (north_star N1, config C4)
+def test_gjk_on_the_device_matches_the_oracle_and_the_closed_forms(L, ctx, oracle):
+    """10 000 random poses per primitive pair type: device GJK against the oracle's twin (1e-12) and, while the cores are
+    apart, against the restated closed forms (1e-10; capped cylinder / box: within the reference's own golden-section
+    tolerance).  Then boxes given as eight-corner meshes, and mesh / mesh pairs."""
+    from test_oracle_kat import _rand_quat, _shape, gjk_pair_sets
+
+    rng = np.random.default_rng(123)
+    for (ka, kb), (A, B) in gjk_pair_sets(rng, 10000).items():
+        g = L.gjk_distance(ctx, A, B)
+        og = oracle.gjk_distance(A, B)
+        assert np.max(np.abs(g - og)) <= 1e-12, (ka, kb)
+        c = np.array([oracle.pair_distance(a, b) for a, b in zip(A[:2000], B[:2000])])
+        rad = lambda s: s.dims[0] if s.kind == T.SHAPE_SPHERE else (s.dims[1] if s.kind == T.SHAPE_CCYLINDER else 0.0)
+        rsum = np.array([rad(a) + rad(b) for a, b in zip(A[:2000], B[:2000])])
+        apart = g[:2000] > -rsum - 1e-10
+        assert np.all(c[~apart] < 0.0)
+        if (ka, kb) == ("ccyl", "box"):
+            tol = 1e-3 * 0.5 * np.array([a.dims[0] for a in A[:2000]])
+            assert np.all(g[:2000][apart] <= c[apart] + 1e-10) and np.all(c[apart] - g[:2000][apart] <= tol[apart] + 1e-10)
+        else:
+            assert np.max(np.abs(g[:2000][apart] - c[apart])) <= 1e-10, (ka, kb)
+    rng = np.random.default_rng(9)
+    pool, m1, m2 = [], [], []
+    for i in range(2000):
+        for lst in (m1, m2):
+            v = scenarios.random_convex_mesh(rng, int(rng.integers(12, 33)), rng.uniform(0.05, 0.25))
+            lst.append(_shape(T.SHAPE_MESH, rng.uniform(-0.6, 0.6, 3), (float(sum(len(x) for x in pool)), float(len(v)), 0.0),
+                              _rand_quat(rng)))
+            pool.append(v)
+    pool = np.concatenate(pool)
+    g, og = L.gjk_distance(ctx, m1, m2, pool), oracle.gjk_distance(m1, m2, pool)
+    assert np.max(np.abs(g - og)) <= 1e-12 and (g > 0).sum() > 1000 and (g < 0).sum() > 20
+    caps = [_shape(T.SHAPE_CCYLINDER, rng.uniform(-0.6, 0.6, 3), (rng.uniform(0.1, 0.5), 0.05, 0), _rand_quat(rng)) for _ in m1]
+    g, og = L.gjk_distance(ctx, caps, m2, pool), oracle.gjk_distance(caps, m2, pool)
+    assert np.max(np.abs(g - og)) <= 1e-12
+
+
+def test_c4_with_200_convex_mesh_obstacles(L, ctx, oracle):
+    """BASELINE config C4 as written: the 12-DOF dual arm among 200 convex MESH obstacles (12-32 vertices each),
+    proximity through batched GJK.  Distance queries, edge walks, RRT, bidirectional RRT and the PRM roadmap against
+    the oracle."""
+    c4 = scenarios.make_c4(world_seed=1, meshes=True)
+    assert sum(1 for s in c4.shapes if s.kind == T.SHAPE_MESH) == 200 and 12 * 200 <= len(c4.mesh_vertices) <= 32 * 200
+    sc, osc = L.Scene(ctx, c4), oracle.OracleScene(c4)
+    lo, hi, mi = c4.meta["lower"], c4.meta["upper"], c4.meta["min_interval"]
+    rng = np.random.default_rng(45)
+    q = rng.uniform(lo, hi, size=(400, 12))
+    x = np.zeros((400, 24)); x[:, 0::2] = q
+    d, rd = sc.min_distance(x), osc.min_distance(x)
+    assert np.allclose(d, rd, rtol=0, atol=1e-10)
+    far = np.abs(rd) > 1e-10
+    assert np.array_equal((d < 0)[far], (rd < 0)[far]) and 0.05 < (rd < 0).mean() < 0.95
+    a = q[rd > 0.0][:96]
+    b = rng.uniform(lo, hi, size=(a.shape[0], 12))
+    out, nchk = sc.move_position_toward(lo, hi, mi, a, b, fraction=1.0)
+    rout, rnchk = osc.qs_move(lo, hi, mi, a, b, fraction=1.0)
+    assert np.array_equal(nchk, rnchk) and np.array_equal(out, rout)
+    qs = L.make_qs_space(12, lo, hi, mi)
+    prm = c4.rrt_params(seed=1, max_vertices=300)
+    rc, ro, rtree = osc.rrt_qs(lo, hi, mi, prm)
+    pl = L.RrtPlanner(sc, prm, qs=qs)
+    st = pl.solve_planning_query()
+    assert (st.num_vertices, st.iterations, st.edges_checked) == (ro.num_vertices, ro.iterations, ro.edges_checked)
+    assert np.array_equal(pl.tree()["parent"], rtree["parent"]) and np.array_equal(pl.tree()["pos"], rtree["pos"])
+    pp = c4.prm_params(seed=2, max_vertices=200, sampling_radius=1.5)
+    rc, ro, rg = osc.prm_qs(lo, hi, mi, pp)
+    pm = L.PrmPlanner(sc, pp, qs)
+    st = pm.solve_planning_query()
+    _prm_same(st, pm.graph(), ro, rg)
+    bp = c4.rrt_params(seed=3, max_vertices=150, max_results=2)
+    rc, ro, rt = osc.birrt_qs(lo, hi, mi, bp)
+    bl = L.BiRrtPlanner(sc, bp, qs)
+    st = bl.solve_planning_query()
+    assert (st.num_vertices_1, st.num_vertices_2, st.loop_iterations, st.num_solutions) == (ro.n1, ro.n2, ro.loop_iterations,
+                                                                                              ro.num_solutions)
+    assert np.array_equal(bl.trees()["parent1"], rt["parent1"]) and np.array_equal(bl.trees()["parent2"], rt["parent2"])
+
+
 # ------------------------------------------------------------------ bidirectional RRT (a7, rr_tree.hpp:256-317)
 @pytest.mark.parametrize("seed,max_results", [(1, 3), (2, 1 << 30)])
 def test_bidirectional_rrt_identical_to_sequential_planner(L, ctx, oracle, seed, max_results):

@@ -76,6 +76,60 @@ def test_quaternion_known_answers(oracle):
     assert np.linalg.norm(t2 - t3) < 2e-12
 
 
+def test_more_rotation_known_answers(oracle):
+    """Further cases the reference's own unit test holds (core/kinetostatics/unit_test_rotations.cpp): rot_mat * v and
+    v * rot_mat (:325-326), the quaternion of a rotation matrix and its repeated products / inverses (:328-362), trace
+    and determinant of the 45-degree rotation (:310-311,375-376), M * invert(M) = identity (:319-320)."""
+    lib = oracle.load()
+    rel = 1e-14
+    q45 = np.zeros(4)
+    lib.orc_axis_angle_quat(0.25 * math.pi, T.dptr(_arr([0, 0, 1])), T.dptr(q45))
+    R = np.zeros(9)
+    lib.orc_quat_rotmat(T.dptr(q45), T.dptr(R))
+    R = R.reshape(3, 3)
+    v1 = np.array([1.0, 1.0, 2.0])
+    assert np.linalg.norm(R @ v1 - np.array([0.0, math.sqrt(2.0), 2.0])) < 10 * rel        # r_45z * v1
+    assert np.linalg.norm(v1 @ R - np.array([math.sqrt(2.0), 0.0, 2.0])) < 10 * rel        # v1 * r_45z
+    assert np.trace(R) == pytest.approx(math.sqrt(2.0) + 1.0, rel=rel) and np.linalg.det(R) == pytest.approx(1.0, rel=rel)
+    assert np.allclose(R.T @ R, np.eye(3), atol=rel) and np.linalg.norm(R.T @ R) == pytest.approx(math.sqrt(3.0), rel=rel)
+    # q * q * invert(q) * invert(q) walks 45 -> 90 -> 45 -> 0 degrees (:349-362)
+    conj = q45 * np.array([1.0, -1.0, -1.0, -1.0])
+    q = np.zeros(4)
+    lib.orc_quat_mul(T.dptr(q45), T.dptr(q45), T.dptr(q))
+    back = np.zeros(4)
+    lib.orc_quat_mul(T.dptr(q), T.dptr(conj), T.dptr(back))
+    assert back[0] == pytest.approx(math.cos(0.125 * math.pi), rel=10 * rel) and back[3] == pytest.approx(math.sin(0.125 * math.pi), rel=10 * rel)
+    ident = np.zeros(4)
+    lib.orc_quat_mul(T.dptr(back), T.dptr(conj), T.dptr(ident))
+    assert ident[0] == pytest.approx(1.0, rel=100 * rel) and np.max(np.abs(ident[1:])) < rel
+    # quaternion::quaternion(Vector) normalises (:916-920); (q * invert(q))[0] == 1 (:379)
+    qn = np.zeros(4)
+    lib.orc_quat_from_vector(T.dptr(_arr([2.0, 0.0, 0.0, 2.0])), T.dptr(qn))
+    assert np.allclose(qn, [math.sqrt(0.5), 0, 0, math.sqrt(0.5)], atol=rel)
+    one = np.zeros(4)
+    lib.orc_quat_mul(T.dptr(q45), T.dptr(conj), T.dptr(one))
+    assert one[0] == pytest.approx(1.0, rel=rel)
+
+
+def test_cholesky_diagonal_and_inverse_cases(oracle):
+    """unit_test_mat_num.cpp:81-103: invert_Cholesky of m_gauss (tolerance 2 eps, M * M^-1 = I within 4 eps) and of the
+    diagonal matrix diag(2, 1, 0.5) (exact inverse diag(0.5, 1, 2) within eps)."""
+    lib = oracle.load()
+    eps = np.finfo(float).eps
+    A = _arr([[2, -1, 0], [-1, 2, -1], [0, -1, 2]])
+    inv = np.zeros((3, 3))
+    for j in range(3):
+        b = np.zeros(3); b[j] = 1.0
+        assert lib.orc_cholesky_solve(T.dptr(A), T.dptr(b), 3, 1e-15) == 0
+        inv[:, j] = b
+    assert np.max(np.abs(A @ inv - np.eye(3))) <= 4.0 * eps
+    Dg = np.diag([2.0, 1.0, 0.5])
+    for j in range(3):
+        b = np.zeros(3); b[j] = 1.0
+        assert lib.orc_cholesky_solve(T.dptr(_arr(Dg)), T.dptr(b), 3, 1e-15) == 0
+        assert np.max(np.abs(b - np.diag([0.5, 1.0, 2.0])[:, j])) <= eps
+
+
 def test_cholesky_known_answers(oracle):
     lib = oracle.load()
     # m_gauss (unit_test_mat_num.cpp:52-59): [[2,-1,0],[-1,2,-1],[0,-1,2]], true inverse [[.75,.5,.25],[.5,1,.5],[.25,.5,.75]]
@@ -264,6 +318,129 @@ def test_plane_and_cylinder_finders_analytic(oracle):
     assert math.isnan(pd(cc((0, 0, 0), 1, 0.1), cy((3, 0, 0), 1, 0.1)))
     assert math.isnan(pd(cy((0, 0, 0), 1, 0.1), cy((3, 0, 0), 1, 0.1)))
     assert math.isnan(pd(cy((0, 0, 0), 1, 0.1), bx((3, 0, 0), (1, 1, 1))))
+
+
+def _rand_quat(rng):
+    q = rng.normal(size=4)
+    return tuple(q / np.linalg.norm(q))
+
+
+def gjk_pair_sets(rng, n):
+    """Random world-anchored pairs per pair type, for the GJK-vs-closed-form checks (used by the GPU test too)."""
+    sets = {}
+    mk = {"sphere": lambda: _shape(T.SHAPE_SPHERE, rng.uniform(-1, 1, 3), (rng.uniform(0.05, 0.3), 0, 0)),
+          "ccyl": lambda: _shape(T.SHAPE_CCYLINDER, rng.uniform(-1, 1, 3), (rng.uniform(0.1, 0.8), rng.uniform(0.03, 0.2), 0),
+                                 _rand_quat(rng)),
+          "box": lambda: _shape(T.SHAPE_BOX, rng.uniform(-1, 1, 3), tuple(rng.uniform(0.1, 0.6, 3)), _rand_quat(rng))}
+    for ka, kb in (("sphere", "sphere"), ("sphere", "ccyl"), ("sphere", "box"), ("ccyl", "ccyl"), ("ccyl", "box")):
+        sets[(ka, kb)] = ([mk[ka]() for _ in range(n)], [mk[kb]() for _ in range(n)])
+    return sets
+
+
+def test_gjk_reproduces_the_closed_forms(oracle):
+    """The support-map distance query (oracle twin of reak_amd/csrc/gjk_device.h) against the restated reference closed
+    forms, 10 000 random poses per pair type.  Exact pairs agree to 1e-10 while the cores are apart (radii are handled
+    analytically, so overlapping spheres / capsules still agree); intersecting cores give a negative value on both
+    sides.  Capped cylinder against box: the reference itself is a golden-section search with tolerance 1e-3 * L/2
+    (prox_fundamentals_3D.cpp:113), so GJK -- the exact distance -- must lie within that of it, never above."""
+    rng = np.random.default_rng(123)
+    for (ka, kb), (A, B) in gjk_pair_sets(rng, 10000).items():
+        g = oracle.gjk_distance(A, B)
+        c = np.array([oracle.pair_distance(a, b) for a, b in zip(A, B)])
+        ra = np.array([a.dims[0] if a.kind == T.SHAPE_SPHERE else (a.dims[1] if a.kind == T.SHAPE_CCYLINDER else 0.0) for a in A])
+        rb = np.array([b.dims[0] if b.kind == T.SHAPE_SPHERE else (b.dims[1] if b.kind == T.SHAPE_CCYLINDER else 0.0) for b in B])
+        apart = g > -(ra + rb) - 1e-10        # cores apart: GJK computed a core distance
+        assert apart.sum() > 9000, (ka, kb)
+        assert np.all(c[~apart] < 0.0), (ka, kb)   # cores intersect: both say collision
+        if (ka, kb) == ("ccyl", "box"):
+            tol = 1e-3 * 0.5 * np.array([a.dims[0] for a in A])
+            assert np.all(g[apart] <= c[apart] + 1e-10) and np.all(c[apart] - g[apart] <= tol[apart] + 1e-10)
+        elif (ka, kb) == ("ccyl", "ccyl"):
+            # the reference's parallel branch (prox_ccylinder_ccylinder.cpp:61-62) is a quirk; random poses are not parallel
+            assert np.max(np.abs(g[apart] - c[apart])) <= 1e-10
+        else:
+            assert np.max(np.abs(g[apart] - c[apart])) <= 1e-10, (ka, kb)
+
+
+def test_gjk_mesh_is_the_convex_hull_of_its_vertices(oracle):
+    """A box handed over as the mesh of its eight corners behaves like the box; a mesh pair is symmetric and invariant
+    under a common rigid motion; a point deep inside a mesh is a collision."""
+    from reak_amd import scenarios
+
+    rng = np.random.default_rng(7)
+    n = 2000
+    boxes = [_shape(T.SHAPE_BOX, rng.uniform(-1, 1, 3), tuple(rng.uniform(0.1, 0.6, 3)), _rand_quat(rng)) for _ in range(n)]
+    pool, meshes = [], []
+    for bx in boxes:
+        m = _shape(T.SHAPE_MESH, bx.pose.pos, (8.0 * len(pool), 8.0, 0.0), tuple(bx.pose.quat))
+        pool.append(scenarios.box_as_mesh(bx.dims))
+        meshes.append(m)
+    pool = np.concatenate(pool)
+    others = [_shape(T.SHAPE_SPHERE, rng.uniform(-1, 1, 3), (rng.uniform(0.05, 0.3), 0, 0)) if i % 2 else
+              _shape(T.SHAPE_CCYLINDER, rng.uniform(-1, 1, 3), (rng.uniform(0.1, 0.8), rng.uniform(0.03, 0.2), 0), _rand_quat(rng))
+              for i in range(n)]
+    gb = oracle.gjk_distance(others, boxes)
+    gm = oracle.gjk_distance(others, meshes, pool)
+    assert np.max(np.abs(gb - gm)) <= 1e-12
+    sb = np.array([oracle.pair_distance(o, b) for o, b in zip(others, boxes)])[1::2]   # sphere-box closed form (exact)
+    apart = gm[1::2] > -np.array([o.dims[0] for o in others[1::2]]) - 1e-10
+    assert np.max(np.abs(gm[1::2][apart] - sb[apart])) <= 1e-10
+    # mesh against mesh
+    p2, m1, m2 = [], [], []
+    for i in range(500):
+        for lst in (m1, m2):
+            v = scenarios.random_convex_mesh(rng, int(rng.integers(12, 33)), rng.uniform(0.05, 0.25))
+            lst.append(_shape(T.SHAPE_MESH, rng.uniform(-0.6, 0.6, 3), (float(sum(len(x) for x in p2)), float(len(v)), 0.0), _rand_quat(rng)))
+            p2.append(v)
+    p2 = np.concatenate(p2)
+    d12, d21 = oracle.gjk_distance(m1, m2, p2), oracle.gjk_distance(m2, m1, p2)
+    assert np.max(np.abs(d12 - d21)) <= 1e-12 and (d12 > 0).sum() > 300 and (d12 < 0).sum() > 5
+    # brute force upper bound: the distance between the hulls is at most the closest vertex pair, and at least that minus
+    # both bounding diameters' worth of slack is meaningless -- check the vertex-pair bound and a sampled lower bound
+    def world(s):
+        q = np.array(list(s.pose.quat)); w, x, y, z = q
+        R = np.array([[1-2*(y*y+z*z), 2*(x*y-w*z), 2*(x*z+w*y)], [2*(x*y+w*z), 1-2*(x*x+z*z), 2*(y*z-w*x)], [2*(x*z-w*y), 2*(y*z+w*x), 1-2*(x*x+y*y)]])
+        v = p2[int(s.dims[0]):int(s.dims[0]) + int(s.dims[1])]
+        return v @ R.T + np.array(list(s.pose.pos))
+    for i in range(0, 500, 25):
+        a, b = world(m1[i]), world(m2[i])
+        vv = np.min(np.linalg.norm(a[:, None, :] - b[None, :, :], axis=2))
+        assert d12[i] <= vv + 1e-12
+        if d12[i] > 0:  # separating direction = the closest-point difference: every vertex pair is at least that far along it
+            from scipy.optimize import minimize
+            na, nb = len(a), len(b)
+            f = lambda w: np.sum((w[:na] @ a - w[na:] @ b) ** 2)
+            cons = [{"type": "eq", "fun": lambda w: np.sum(w[:na]) - 1}, {"type": "eq", "fun": lambda w: np.sum(w[na:]) - 1}]
+            r = minimize(f, np.r_[np.full(na, 1 / na), np.full(nb, 1 / nb)], bounds=[(0, 1)] * (na + nb), constraints=cons,
+                         method="SLSQP", options={"maxiter": 500, "ftol": 1e-16})
+            assert abs(np.sqrt(r.fun) - d12[i]) <= 1e-5 * max(1.0, d12[i])  # the QP's own accuracy
+
+
+def test_planar_3r_jacobian_against_the_reference_closed_form(oracle):
+    """manip_3R_2D_kinematics::getJacobianMatrix (ctrl/kte_models/manip_3R_arm.cpp:223-236) writes the end-effector
+    Jacobian of the planar 3R arm in closed form: column i = (1 % (R_1..i (L_i, 0)), 1) -- the velocity the tip gets
+    from link i turning alone, `s % v` = (-s v_y, s v_x).  The derivative of the tip w.r.t. JOINT j (every link from j on
+    turns) is the sum of columns j..3.  The oracle's revolute_joint_2D / rigid_link_2D chain (the same chain,
+    manip_3R_arm.cpp:75-150, link lengths 0.5, 0.5, 0.3) must reproduce it: central differences of its forward
+    kinematics against the reference's formula."""
+    from reak_amd import scenarios
+
+    scn = scenarios.make_c1_planar(world_seed=1)
+    osc = oracle.OracleScene(scn)
+    L = [0.5, 0.5, 0.3]
+    rng = np.random.default_rng(2)
+    tip = lambda q: osc.fk(np.c_[q, np.zeros(3)].reshape(1, 6))[0, -1]      # last frame: (x, y, 0, cos, sin, 0, 0)
+    for q in rng.uniform(-np.pi, np.pi, size=(20, 3)):
+        cum = np.cumsum(q)
+        ref_cols = np.array([[-L[i] * np.sin(cum[i]), L[i] * np.cos(cum[i]), 1.0] for i in range(3)]).T   # the reference's Jac
+        h = 1e-6
+        for j in range(3):
+            dq = np.zeros(3); dq[j] = h
+            fp, fm = tip(q + dq), tip(q - dq)
+            dpos = (fp[:2] - fm[:2]) / (2 * h)
+            dang = (np.arctan2(fp[4], fp[3]) - np.arctan2(fm[4], fm[3])) / (2 * h)
+            assert np.allclose(dpos, ref_cols[:2, j:].sum(axis=1), rtol=0, atol=1e-8)
+            assert abs((dang + np.pi) % (2 * np.pi) - np.pi - ref_cols[2, j]) < 1e-8
 
 
 def test_linear_nn_tie_rules(oracle):
