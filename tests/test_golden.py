@@ -73,6 +73,8 @@ def test_hip_reproduces_golden(gold, c2):
     assert np.array_equal(kcnt, gold["knn_cnt"]) and np.array_equal(kdist, gold["knn_dist"])
     for b in range(len(kcnt)):
         c = int(kcnt[b])
+        if c == 0:
+            continue
         d = kdist[b, :c]
         distinct = np.r_[True, d[1:] != d[:-1]] & np.r_[d[:-1] != d[1:], True]
         assert np.array_equal(kidx[b, :c][distinct], gold["knn_idx"][b, :c][distinct])
