@@ -10,6 +10,7 @@
 #include "reak_kte.hpp"
 #include "reak_math.hpp"
 #include "reak_planning.hpp"
+#include "dvp_tree.hpp"
 #include "vp_tree.hpp"
 #include "reak_proximity.hpp"
 
@@ -22,6 +23,41 @@ struct Scene {
 };
 Quat mkq(const double* q) { return Quat(q[0], q[1], q[2], q[3]); }
 }  // namespace
+
+// helper of orc_dvptree (below)
+template <int Arity>
+static int dvptree_run(const double* q, uint32_t B, const double* pts, uint64_t n, int D, int incremental, uint32_t seed,
+                       uint32_t k, double radius, uint32_t* idx, double* dist, uint32_t* cnt, double* build_seconds,
+                       double* query_seconds, uint64_t* dist_evals) {
+  std::mt19937 rng(seed);
+  DvpTree<Arity> tree(pts, D, &rng);
+  auto t0 = std::chrono::steady_clock::now();
+  if (incremental) {
+    for (uint64_t i = 0; i < n; ++i) tree.insert(uint32_t(i));
+  } else {
+    tree.build(std::size_t(n));
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  const uint64_t evals_build = tree.distance_evaluations();
+  for (uint32_t b = 0; b < B; ++b) {
+    if (k <= 1) {
+      auto r = tree.find_nearest(q + std::size_t(b) * D);
+      idx[b] = r.first;
+      dist[b] = r.second;
+    } else {
+      for (uint32_t j = 0; j < k; ++j) {
+        idx[std::size_t(b) * k + j] = 0xFFFFFFFFu;
+        dist[std::size_t(b) * k + j] = std::numeric_limits<double>::infinity();
+      }
+      cnt[b] = uint32_t(tree.find_nearest(q + std::size_t(b) * D, k, radius, idx + std::size_t(b) * k, dist + std::size_t(b) * k));
+    }
+  }
+  auto t2 = std::chrono::steady_clock::now();
+  if (build_seconds) *build_seconds = std::chrono::duration<double>(t1 - t0).count();
+  if (query_seconds) *query_seconds = std::chrono::duration<double>(t2 - t1).count();
+  if (dist_evals) *dist_evals = tree.distance_evaluations() - evals_build;
+  return int(tree.size() == n ? 0 : 1);
+}
 
 extern "C" {
 
@@ -498,6 +534,16 @@ int orc_vptree_nn1(const double* q, uint32_t B, const double* pts, uint64_t n, i
   return 0;
 }
 
+// ---- the reference's DVP-tree (dvp_tree.hpp): 1-NN / k-NN of B queries over n points.  incremental = 0: the tree is
+// built from all points at once (dvp_tree_impl's range constructor); 1: points are inserted one by one (the planners'
+// use).  arity 2 or 4 (DVP_BF2 / DVP_BF4).  k = 1: idx/dist [B]; k > 1: [B][k] padded with 0xFFFFFFFF / +inf, cnt[B].
+int orc_dvptree(const double* q, uint32_t B, const double* pts, uint64_t n, int D, int arity, int incremental, uint32_t seed,
+                uint32_t k, double radius, uint32_t* idx, double* dist, uint32_t* cnt, double* build_seconds,
+                double* query_seconds, uint64_t* dist_evals) {
+  if (arity == 4)
+    return dvptree_run<4>(q, B, pts, n, D, incremental, seed, k, radius, idx, dist, cnt, build_seconds, query_seconds, dist_evals);
+  return dvptree_run<2>(q, B, pts, n, D, incremental, seed, k, radius, idx, dist, cnt, build_seconds, query_seconds, dist_evals);
+}
 
 // ---- report text through a real iostream (pins reak_amd/reports.py):
 // any_mg_vertex_printer::operator() R/ctrl/path_planning/any_motion_graphs.hpp:666-700 and the file name of

@@ -320,6 +320,27 @@ def vptree_nn1(q, pts, fast=False):
     return idx, dist, tb.value, tq.value
 
 
+def dvptree(q, pts, arity=2, incremental=False, seed=1, k=1, radius=np.inf, fast=False):
+    """The restated DVP-tree of the reference (oracle/dvp_tree.hpp): k = 1 -> (idx, dist, info); k > 1 -> (idx, dist, cnt,
+    info); info = {build_s, query_s, dist_evals (distance evaluations of the queries)}."""
+    lib = load(fast)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    B, D = q.shape
+    idx = np.zeros((B, k) if k > 1 else B, dtype=np.uint32)
+    dist = np.zeros((B, k) if k > 1 else B)
+    cnt = np.zeros(B, dtype=np.uint32)
+    tb, tq, ev = C.c_double(), C.c_double(), C.c_uint64()
+    lib.orc_dvptree.argtypes = [C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_double), C.c_uint64, C.c_int, C.c_int, C.c_int,
+                                C.c_uint32, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_double),
+                                C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    rc = lib.orc_dvptree(T.dptr(q), B, T.dptr(pts), pts.shape[0], D, arity, 1 if incremental else 0, seed, k, float(radius),
+                         T.u32ptr(idx), T.dptr(dist), T.u32ptr(cnt), C.byref(tb), C.byref(tq), C.byref(ev))
+    assert rc == 0
+    info = {"build_s": tb.value, "query_s": tq.value, "dist_evals": int(ev.value)}
+    return (idx, dist, info) if k <= 1 else (idx, dist, cnt, info)
+
+
 def knn(q, pts, k, radius=np.inf, fast=False):
     lib = load(fast)
     q = np.ascontiguousarray(q, dtype=np.float64)

@@ -504,6 +504,27 @@ def test_vantage_point_tree_equals_linear_search(oracle):
         assert np.array_equal(li, ti) and np.array_equal(ld, td)
 
 
+def test_dvp_tree_restatement_is_exact(oracle):
+    """The reference's DVP-tree (dvp_tree_detail.hpp, arity 2 and 4; built at once and grown by insert()) returns the
+    linear search's nearest neighbours -- distances bit for bit, the same vertices wherever the distances are distinct --
+    and prunes: far fewer distance evaluations than n per query."""
+    rng = np.random.default_rng(8)
+    for D, n in ((3, 600), (6, 5000), (12, 3000)):
+        pts = rng.uniform(-1, 1, size=(n, D))
+        q = rng.uniform(-1, 1, size=(200, D))
+        li, ld = oracle.nn1(q, pts)
+        kidx, kdist, kcnt = oracle.knn(q, pts, 12, radius=0.9)
+        for arity in (2, 4):
+            for incremental in (False, True):
+                ti, td, info = oracle.dvptree(q, pts, arity=arity, incremental=incremental, seed=5)
+                assert np.array_equal(li, ti) and np.array_equal(ld, td), (D, arity, incremental)
+                if D <= 6:
+                    assert info["dist_evals"] < 0.5 * n * len(q)
+                di, dd, dc, _ = oracle.dvptree(q, pts, arity=arity, incremental=incremental, seed=5, k=12, radius=0.9)
+                assert np.array_equal(dc, kcnt) and np.array_equal(dd, kdist)
+                assert np.array_equal(di, kidx)  # no ties in random data
+
+
 def _shape2(kind, pos, dims, angle=0.0):
     s = T.Shape(kind=kind, anchor=-1)
     s.pose = T.make_pose_2d(pos, angle)
