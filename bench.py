@@ -136,6 +136,51 @@ def nn_mfma_microbench(lib, ctx, events, n_rows=1 << 20, B=1024, reps=10):
             "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}
 
 
+def nn_published_config(lib, ctx, events, n_rows=25000, D=6, B=1000, reps=20):
+    """the reference's NN-search table is quoted at 6-D, N = 25 000 vertices, in us per query per vertex
+    (linear search 8.2e-3, DVP-tree 1.6e-4 on the authors' 2012 desktop).  The same figure for the GPU sweep, and for the
+    oracle's linear search and its restated DVP-tree (oracle/dvp_tree.hpp) on THIS host's CPU, same points and queries."""
+    import torch
+    import oracle_lib
+
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-1.0, 1.0, size=(n_rows, D))
+    q = rng.uniform(-1.0, 1.0, size=(B, D))
+    nn = lib.HipNeighborSearch(ctx, D, n_rows)
+    nn.added_vertices(pts)
+    dq = torch.from_numpy(q).cuda()
+    idx = torch.zeros(B, dtype=torch.int32, device="cuda")
+    dist = torch.zeros(B, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        nn.nearest_async(dq.data_ptr(), B, idx.data_ptr(), dist.data_ptr())
+    ctx.synchronize()
+    pairs = [(events.create(), events.create()) for _ in range(reps)]
+    for a, b in pairs:
+        nn.nearest_async(dq.data_ptr(), B, idx.data_ptr(), dist.data_ptr(), events=(a, b))
+    ctx.synchronize()
+    ms = sum(events.elapsed_ms(a, b) for a, b in pairs) / reps
+    name = nn.kernel_name()
+    gpu_idx = idx.cpu().numpy().astype(np.int64)
+    nn.close()
+    per = lambda seconds: seconds * 1e6 / B / n_rows
+    t0 = time.perf_counter()
+    lin_idx, _ = oracle_lib.nn1(q, pts, fast=True)
+    t_lin = time.perf_counter() - t0
+    out = {"n": n_rows, "dims": D, "queries": B, "unit": "us per query per vertex",
+           "gpu_sweep": {"kernel": name, "value": per(ms * 1e-3), "us_per_batch": ms * 1e3},
+           "cpu_linear_search": {"value": per(t_lin)},
+           "reference_2012_desktop": {"linear_search": 8.2e-3, "dvp_tree": 1.6e-4, "source": "BASELINE.md 1"},
+           "same_answers": bool(np.array_equal(gpu_idx, lin_idx.astype(np.int64))), "host": host_description()}
+    for arity in (2, 4):
+        for inc in (False, True):
+            t_idx, _, info = oracle_lib.dvptree(q, pts, arity=arity, incremental=inc, seed=1, fast=True)
+            out[f"cpu_dvp_tree_arity{arity}_{'incremental' if inc else 'bulk'}"] = {
+                "value": per(info["query_s"]), "build_s": info["build_s"],
+                "distance_evaluations_per_query": info["dist_evals"] / B,
+                "same_answers": bool(np.array_equal(t_idx.astype(np.int64), lin_idx.astype(np.int64)))}
+    return out
+
+
 def host_description():
     model = "unknown"
     try:
@@ -597,6 +642,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(scn, args.max_vertices)
             nv_used = int(out["cpu_baseline"]["sample"].split("first ")[1].split(" ")[0])
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(nv_used)
+            out["nn_published_config"] = nn_published_config(lib, ctx, events)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

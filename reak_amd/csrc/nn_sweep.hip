@@ -151,6 +151,148 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_kernel(NnArgs single, cons
   }
 }
 
+// The HBM-bound regime (at most 8 queries per sweep, D equal to its padded width): rows go straight from HBM into the
+// registers of ONE lane each (Dp/2 16-byte loads per lane; the wave's Dp/2 loads together cover whole cache lines) --
+// no LDS tile, no block barrier in the loop.  The queries are uniform across the block, so they are never held in
+// vector registers: they are re-read every row through the scalar cache (constant address space => s_load) and enter
+// the fp64 operations as scalar operands.  A lane keeps (best distance, index, threshold) of every query for its own
+// rows; lanes and waves are merged once at the end.  Same operation sequence per (row, query) as nn1_sweep_kernel.
+typedef const __attribute__((address_space(4))) double* nn_cdouble_p;
+typedef double nn_d2 __attribute__((ext_vector_type(2)));
+
+template <int DP, int QB>
+__global__ __launch_bounds__(kThreads, 2) void nn1_stream_kernel(NnArgs single, const NnArgs* __restrict__ table,
+                                                                  uint32_t Bpad) {
+  constexpr int H = DP / 2;
+  __shared__ double red_d[kThreads / 64][QB];
+  __shared__ uint32_t red_i[kThreads / 64][QB];
+
+  // everything read from the table entry is block-uniform by construction; the compiler has to be told (the entry
+  // arrives through vector loads), so that the row addresses get a scalar base and the queries scalar loads
+  auto uniform64 = [](uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v)), hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+    return (uint64_t(hi) << 32) | lo;
+  };
+  const NnArgs a = table ? table[blockIdx.z] : single;
+  typedef const __attribute__((address_space(1))) nn_d2* nn_grow_p;  // global, not flat: flat loads would share
+  const uint64_t pos = uniform64(reinterpret_cast<uint64_t>(a.pos));   // the queries' scalar-load counter
+  const uint64_t n = uniform64(a.d_n ? uint64_t(*a.d_n) : a.n);
+  const uint32_t B = __builtin_amdgcn_readfirstlane(a.d_B ? *a.d_B : a.B);
+  if (B == 0) return;
+  const int tid = threadIdx.x;
+  nn_cdouble_p qc =
+      (nn_cdouble_p)uniform64(reinterpret_cast<uint64_t>(a.q + (a.d_qoff ? uint64_t(*a.d_qoff) : 0ull) * DP));
+
+  const uint64_t tiles_total = (n + kTileRows - 1) / kTileRows;
+  const uint64_t tiles_per_block = (tiles_total + gridDim.x - 1) / gridDim.x;
+  const uint64_t tile0 = uint64_t(blockIdx.x) * tiles_per_block;
+  uint64_t tile1 = tile0 + tiles_per_block;
+  if (tile1 > tiles_total) tile1 = tiles_total;
+
+  double best_d[QB], best_thr[QB];
+  uint32_t best_i[QB];
+#pragma unroll
+  for (int k = 0; k < QB; ++k) {
+    best_d[k] = INFINITY;
+    best_thr[k] = INFINITY;
+    best_i[k] = 0xFFFFFFFFu;
+  }
+
+  auto fetch = [&](uint64_t t, nn_d2* dst) {
+    uint64_t row = t * kTileRows + tid;
+    if (row >= n) row = n - 1;  // re-reads the last row; the result is discarded below
+    nn_grow_p src = (nn_grow_p)(pos + row * (DP * sizeof(double)));
+#pragma unroll
+    for (int j = 0; j < H; ++j) dst[j] = src[j];
+  };
+  auto scan = [&](uint64_t t, const nn_d2* cur) {
+    const uint64_t row = t * kTileRows + tid;
+    const bool valid = row < n;
+    asm volatile("" : "+s"(qc));  // keep the query loads inside the loop (hoisted, they would not fit the scalar file)
+#pragma unroll
+    for (int k = 0; k < QB; ++k) {
+      nn_cdouble_p qk = qc + uint32_t(uint32_t(k) < B ? k : B - 1) * DP;
+      double s;
+      {
+        const double df = qk[0] - cur[0].x;
+        s = df * df;
+      }
+#pragma unroll
+      for (int d = 1; d < DP; ++d) {
+        const double df = qk[d] - ((d & 1) ? cur[d >> 1].y : cur[d >> 1].x);
+        s = s + df * df;
+      }
+      if (valid && s <= best_thr[k]) {
+        const double dd = sqrt(s);
+        if (dd < best_d[k]) {
+          best_d[k] = dd;
+          best_i[k] = uint32_t(row);
+          best_thr[k] = s * (1.0 + 4.0 * DBL_EPSILON);
+        }
+      }
+    }
+  };
+  // Three row buffers in turn: the loads of tiles t + 1 and t + 2 are in flight while tile t is scanned (a wave then
+  // keeps 2 x 64 rows on the way to it; with one tile ahead the sweep was bound by the load latency, not by HBM).  The
+  // prefetches inside the loop are unconditional (past the slice they re-read its last tile): behind a branch the
+  // compiler's wait-count bookkeeping has to assume the shorter queue and waits for the loads it has just issued.
+  nn_d2 ra[H], rb[H], rc[H];
+  if (tile0 < tile1) {
+    const uint64_t last = tile1 - 1;
+    auto clamp = [&](uint64_t t) { return t < last ? t : last; };
+    fetch(tile0, ra);
+    fetch(clamp(tile0 + 1), rb);
+    uint64_t t = tile0;
+    for (; t + 3 <= tile1; t += 3) {
+      fetch(clamp(t + 2), rc);
+      scan(t, ra);
+      fetch(clamp(t + 3), ra);
+      scan(t + 1, rb);
+      fetch(clamp(t + 4), rb);
+      scan(t + 2, rc);
+    }
+    if (t < tile1) {
+      scan(t, ra);
+    }
+    if (t + 1 < tile1) {
+      scan(t + 1, rb);
+    }
+  }
+
+  // lanes -> wave (minimum distance first, then the lowest index among the lanes that hold it), waves -> block
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < QB; ++k) {
+    double bd = best_d[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bd = fmin(bd, __shfl_xor(bd, off, 64));
+    uint32_t bi = best_d[k] == bd ? best_i[k] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t oi = __shfl_xor(bi, off, 64);
+      bi = oi < bi ? oi : bi;
+    }
+    if (lane == 0) {
+      red_d[wave][k] = bd;
+      red_i[wave][k] = bi;
+    }
+  }
+  __syncthreads();
+  if (tid < QB && uint32_t(tid) < B) {
+    double bd = red_d[0][tid];
+    uint32_t bi = red_i[0][tid];
+#pragma unroll
+    for (int w = 1; w < kThreads / 64; ++w) {
+      if (lex_less(red_d[w][tid], red_i[w][tid], bd, bi)) {
+        bd = red_d[w][tid];
+        bi = red_i[w][tid];
+      }
+    }
+    a.part_dist[uint64_t(blockIdx.x) * Bpad + tid] = bd;
+    a.part_idx[uint64_t(blockIdx.x) * Bpad + tid] = bi;
+  }
+}
+
 // The same sweep with a single-precision pre-filter, for the compute-bound regime (many queries per sweep, as in the
 // planner's speculative rounds).  Per (row, query) the exact test costs 3*Dp-1 fp64 VALU operations; here a packed fp32
 // estimate of the squared distance (Dp/2 v_pk_add_f32 + Dp/2 v_pk_fma_f32 on a float copy of the tile) rejects every
@@ -305,14 +447,23 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_f32_kernel(NnArgs single, 
 // l & 31) and 16 rows per slab (the C/D map of the 32x32 shapes: row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)); the two
 // lane halves hold different rows of the same queries and are merged at the end.
 // No exact arithmetic inside the sweep: with E >= |c_r - (s_r - |q^|^2)| for every row r, the true nearest row r*
-// satisfies c_{r*} <= c_min + 2 E, and the running minimum is never below the final one, so the rows with
+// satisfies c_{r*} <= c_min + 2 E, and a running minimum over ANY rows of the tree is never below the final one, so the
+// rows with
 //   c_r <= (running min of c, including r's slab) + 2 E
-// are a superset of the candidates; they are appended, (row, c), to a short per-lane list in LDS, a handful per sweep.
-// After the sweep the list is cut down with the final minimum (typically to one or two rows) and those rows are
-// evaluated with the exact fp64 sequence of nn1_sweep_kernel straight from HBM; the lexicographic minimum of
-// (distance, index) over them is the reference's "first minimum wins".  Bit-identical results.
-// (Keeping whole slabs as candidates -- one compare per slab -- was measured: resolving a slab's 16 rows from HBM at
-// the end costs far more than the per-row checks it saves.)
+// are a superset of the candidates.  A half-slab (16 rows of one lane) that holds such a row is recorded as ONE entry
+// (slab, 16-bit row mask, its minimum) in a short per-lane list in LDS -- straight-line code, a compare per row, no
+// nested divergent loops.  After the sweep the list is cut down with the final minimum (typically to one entry, one
+// bit) and those rows are evaluated with the exact fp64 sequence of nn1_sweep_kernel straight from HBM; the
+// lexicographic minimum of (distance, index) over them is the reference's "first minimum wins".  Bit-identical results.
+// Seeding: every recorded entry stalls its whole wave, and a block that starts from +inf meets ~ln(rows) new minima per
+// lane.  A first pass (SEED = true: same tiles, same instructions, minimum only) over every s-th tile of the tree leaves
+// min c of that sample in NnArgs::seed (ordered-integer atomicMin); the sweep proper starts from it -- same rows, same
+// bits, so it is a running minimum in the sense above -- and records ~(rows / sample) entries per query over the whole
+// tree instead of ~ln(slice) per block.
+// Slabs are software-pipelined: the MFMA chain of slab g + 1 is issued before the minimum tree / compare of slab g, so
+// the matrix pipe has work while the wave's VALU settles the previous slab.
+// (Tried and measured slower: whole slabs as candidates -- resolving 16 rows per entry from HBM costs more than the
+// per-row compares save; an exact fp64 recheck inside the sweep.)
 // Error bound (u = 2^-24, M = coord_bound, M' = M (1 + u), x^, q^ = the float-rounded coordinates): the MFMA is a
 // k-ordered fmaf chain starting from C, so |c - (|x^|^2 - 2 x^.q^)| <= (Dp + 1) u (|x^|^2 + 2 sum|x^ q^|) plus the
 // (Dp + 1) u |x^|^2 of the float evaluation of |x^|^2 itself, <= 4 (Dp + 1) u Dp M'^2; and |sum (x^ - q^)^2 - s| <=
@@ -321,59 +472,105 @@ typedef float rkh_f16v __attribute__((ext_vector_type(16)));
 typedef float rkh_f4v __attribute__((ext_vector_type(4)));
 static constexpr int kMfmaThreads = 256;
 static constexpr int kMfmaQueries = 128;  // 4 waves x 32 queries (8 waves x 32 per block measured 25 % slower)
-static constexpr int kCandCap = 8;  // per-lane candidate list (compacted, then resolved exactly, when it fills)
+static constexpr int kCandCap = 8;        // per-lane entry list (compacted, then resolved exactly, when it fills)
+// Seeding pays when the sample is a small fraction of the tree: the sample is kSeedSample tiles (32 Ki rows), and trees
+// of fewer than kSeedMinTiles tiles (sample stride below 16, i.e. a seeding pass of more than 1/16 of the sweep's matrix
+// work) are swept unseeded -- measured on the planner's trees (<= 100 k rows) a stride-8 pass cost 125 us and saved 76.
+static constexpr int kSeedSample = 128;
+static constexpr int kSeedMinTiles = 16 * kSeedSample;
 
-template <int DP>
+// order-preserving map float -> uint32 (atomicMin on the image = min on the floats); 0xFFFFFFFF decodes to NaN = "none"
+__device__ __forceinline__ uint32_t seed_encode(float c) {
+  const uint32_t u = __float_as_uint(c);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float seed_decode(uint32_t e) {
+  return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e);
+}
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// minimum over the two lane halves (lanes l and l ^ 32), one VALU swap instead of an LDS round trip
+__device__ __forceinline__ float min_over_halves(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float lo = __uint_as_float(r[0]), hi = __uint_as_float(r[1]);
+  return min3_raw(lo, hi, hi);
+}
+
+// Grid: 1-D, 8 * ceil(W / 8) blocks for W = gx * (query blocks of all problems) work items (row slice, query block,
+// problem).  Hardware deals consecutive blocks round-robin to the 8 XCDs, so block L runs on XCD L % 8 as that XCD's
+// (L / 8)-th block: XCD x takes the items [x Wc, (x + 1) Wc) in order, and items are numbered with the query block
+// fastest -- the query blocks that sweep the same row slice run back to back on one XCD and share its L2.
+template <int DP, bool SEED>
 __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs single, const NnArgs* __restrict__ table,
                                                                       int D, uint32_t Bpad, double coord_bound,
                                                                       const uint32_t* __restrict__ yblock_base,
-                                                                      uint32_t n_problems) {
+                                                                      uint32_t n_problems, uint32_t gx, uint32_t gy) {
   constexpr int H = DP / 2;
   constexpr int TS = kTileRows + 4;  // float stride of one coordinate's row of the transposed copy
+  constexpr int kSlabs = kTileRows / 32;
   __shared__ __attribute__((aligned(16))) float tileT[DP * TS];
   __shared__ __attribute__((aligned(16))) float xn[kTileRows];
-  __shared__ uint32_t cand_row[kCandCap][kMfmaThreads];
-  __shared__ float cand_c[kCandCap][kMfmaThreads];
+  __shared__ uint32_t cand_key[SEED ? 1 : kCandCap][kMfmaThreads];
+  __shared__ uint32_t cand_mask[SEED ? 1 : kCandCap][kMfmaThreads];
+  __shared__ float cand_m[SEED ? 1 : kCandCap][kMfmaThreads];
 
-  // (row slice, query block, problem) of this block.  With a prefix of the query blocks per problem (yblock_base, written
-  // by the planner's round_begin_kernel) the grid's blocks, in dispatch order, take the working (slice, query block)
-  // pairs one after the other: no holes for problems with fewer queries than the grid was sized for, and an even spread
-  // over the XCDs.
-  uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (yblock_base) {
-    const uint32_t L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const uint32_t yy = L / gridDim.x;
-    if (yy >= yblock_base[n_problems]) return;
-    uint32_t lo = 0, hi = n_problems;  // yblock_base[lo] <= yy < yblock_base[hi]
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (yblock_base[mid] <= yy) lo = mid;
-      else hi = mid;
+  uint32_t bx, by, bz;
+  {
+    const uint32_t L = blockIdx.x;
+    const uint32_t ytot = yblock_base ? yblock_base[n_problems] : gy * n_problems;
+    const uint32_t W = ytot * gx, Wc = (W + 7) >> 3;
+    const uint32_t slot = L >> 3, w = (L & 7) * Wc + slot;
+    if (slot >= Wc || w >= W) return;
+    const uint32_t yy = w / gx;
+    uint32_t p = 0, y0, cnt;
+    if (yblock_base) {
+      uint32_t hi_p = n_problems;  // yblock_base[p] <= yy < yblock_base[hi_p]
+      while (hi_p - p > 1) {
+        const uint32_t mid = (p + hi_p) >> 1;
+        if (yblock_base[mid] <= yy) p = mid;
+        else hi_p = mid;
+      }
+      y0 = yblock_base[p];
+      cnt = yblock_base[p + 1] - y0;
+    } else {
+      p = yy / gy;
+      y0 = p * gy;
+      cnt = gy;
     }
-    bx = L - yy * gridDim.x;
-    by = yy - yblock_base[lo];
-    bz = lo;
+    const uint32_t r = w - y0 * gx;
+    bx = r / cnt;
+    by = r - bx * cnt;
+    bz = p;
   }
+  // everything read from the table entry is block-uniform; said explicitly, it lives in scalar registers
+  auto uniform64 = [](uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v)), hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+    return (uint64_t(hi) << 32) | lo;
+  };
   const NnArgs a = table ? table[bz] : single;
-  const double* __restrict__ pos = a.pos;
-  const double* __restrict__ q = a.q;
-  const uint32_t* __restrict__ d_qoff = a.d_qoff;
-  double* __restrict__ part_dist = a.part_dist;
-  uint32_t* __restrict__ part_idx = a.part_idx;
-  const uint64_t n = a.d_n ? uint64_t(*a.d_n) : a.n;
-  const uint32_t B = a.d_B ? *a.d_B : a.B;
+  const double* __restrict__ pos = reinterpret_cast<const double*>(uniform64(reinterpret_cast<uint64_t>(a.pos)));
+  const uint64_t n = uniform64(a.d_n ? uint64_t(*a.d_n) : a.n);
+  const uint32_t B = __builtin_amdgcn_readfirstlane(a.d_B ? *a.d_B : a.B);
+  const double* __restrict__ q = reinterpret_cast<const double*>(
+      uniform64(reinterpret_cast<uint64_t>(a.q + (a.d_qoff ? uint64_t(*a.d_qoff) : 0ull) * D)));
+  uint32_t* __restrict__ seed = reinterpret_cast<uint32_t*>(uniform64(reinterpret_cast<uint64_t>(a.seed)));
+  double* __restrict__ part_dist = reinterpret_cast<double*>(uniform64(reinterpret_cast<uint64_t>(a.part_dist)));
+  uint32_t* __restrict__ part_idx = reinterpret_cast<uint32_t*>(uniform64(reinterpret_cast<uint64_t>(a.part_idx)));
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, hi = lane >> 5;
   const uint32_t qi = by * kMfmaQueries + wave * 32 + col;
   if (by * kMfmaQueries >= B) return;
-  const uint64_t qsrc = uint64_t(qi < B ? qi : (B - 1)) + (d_qoff ? uint64_t(*d_qoff) : 0ull);
+  const uint32_t qsrc = qi < B ? qi : (B - 1);
 
   float bop[H];  // B operand of step j: -2 q^[2 j + hi]
 #pragma unroll
   for (int j = 0; j < H; ++j) {
     const int d = 2 * j + hi;
-    bop[j] = -2.0f * float(d < D ? q[qsrc * D + d] : 0.0);
+    bop[j] = -2.0f * float(d < D ? q[uint64_t(qsrc) * D + d] : 0.0);
   }
   const double u32 = 5.9604644775390625e-08;  // 2^-24
   const double Mb = coord_bound * (1.0 + u32);
@@ -382,22 +579,37 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
   // 2 E, plus the rounding of the float sum (running min + band) at the magnitude of the estimates (<= 3 Dp M'^2)
   const float band = __double2float_ru(2.0 * e_one + 8.0 * u32 * 3.0 * double(DP) * Mb * Mb);
 
+  // the tiles of this block: its contiguous slice of the tree, or (SEED) every stride-th tile of the whole tree dealt
+  // round-robin to the gx seed blocks
   const uint64_t tiles_total = (n + kTileRows - 1) / kTileRows;
-  const uint64_t tiles_per_block = (tiles_total + gridDim.x - 1) / gridDim.x;
-  const uint64_t tile0 = uint64_t(bx) * tiles_per_block;
-  uint64_t tile1 = tile0 + tiles_per_block;
-  if (tile1 > tiles_total) tile1 = tiles_total;
+  uint64_t t_first, t_step, t_count;
+  if (SEED) {
+    if (tiles_total < uint64_t(kSeedMinTiles)) return;
+    const uint64_t stride = tiles_total / kSeedSample;
+    const uint64_t ns = (tiles_total + stride - 1) / stride;
+    t_first = uint64_t(bx) * stride;
+    t_step = uint64_t(gx) * stride;
+    t_count = ns > bx ? (ns - bx + gx - 1) / gx : 0;
+  } else {
+    const uint64_t tiles_per_block = (tiles_total + gx - 1) / gx;
+    t_first = uint64_t(bx) * tiles_per_block;
+    uint64_t t_end = t_first + tiles_per_block;
+    if (t_end > tiles_total) t_end = tiles_total;
+    t_step = 1;
+    t_count = t_end > t_first ? t_end - t_first : 0;
+  }
 
-  double best_d = INFINITY;         // champion of the candidates resolved so far (list overflow only)
+  double best_d = INFINITY;         // champion of the entries resolved so far (list overflow only)
   uint32_t best_i = 0xFFFFFFFFu;
-  float cmin = INFINITY;            // running minimum of the estimates of this lane's query
-  int cnt = 0;                      // candidates in the list
+  // running minimum of the estimates of this lane's query; NaN ("no seed") is dropped by fminf
+  float cmin = (!SEED && seed) ? fminf(INFINITY, seed_decode(seed[qsrc])) : INFINITY;
+  int cnt = 0;                      // entries in the list
 
   // exact fp64 distance of vertex `row` (global index): the operation sequence of nn1_sweep_kernel
   auto resolve = [&](uint32_t row) {
-    if (uint64_t(row) >= n) return;  // padding rows of the last tile (a half-wave that has seen nothing else)
+    if (uint64_t(row) >= n) return;  // padding rows of the last tile
     const double* p = pos + uint64_t(row) * DP;
-    const double* qq = q + qsrc * D;
+    const double* qq = q + uint64_t(qsrc) * D;
     double s;
     {
       const double df = qq[0] - p[0];
@@ -414,24 +626,35 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
       best_i = row;
     }
   };
-  // drop the candidates the current minimum rules out; if the list is still full, resolve it
-  auto compact = [&]() {
-    const float lim = cmin + band;
+  // every flagged row of entry k: key = slab index counted from the block's first tile
+  auto resolve_entry = [&](int k) {
+    uint32_t mask = cand_mask[k][tid];
+    const uint32_t base = uint32_t(t_first) * uint32_t(kTileRows) + cand_key[k][tid] * 32u + 4u * uint32_t(hi);
+#pragma unroll 1
+    while (mask) {
+      const uint32_t i = uint32_t(__builtin_ctz(mask));
+      mask &= mask - 1;
+      resolve(base + 8u * (i >> 2) + (i & 3u));
+    }
+  };
+  // drop the entries the current minimum rules out; if the list is still full, resolve it
+  auto compact = [&](float lim) {
     int w = 0;
 #pragma unroll 1
     for (int k = 0; k < cnt; ++k) {
-      const float cc = cand_c[k][tid];
-      const uint32_t rr = cand_row[k][tid];
-      if (cc <= lim) {
-        cand_c[w][tid] = cc;
-        cand_row[w][tid] = rr;
+      const float mm = cand_m[k][tid];
+      if (mm <= lim) {
+        const uint32_t kk = cand_key[k][tid], mk = cand_mask[k][tid];
+        cand_m[w][tid] = mm;
+        cand_key[w][tid] = kk;
+        cand_mask[w][tid] = mk;
         ++w;
       }
     }
     cnt = w;
     if (cnt == kCandCap) {
 #pragma unroll 1
-      for (int k = 0; k < cnt; ++k) resolve(cand_row[k][tid]);
+      for (int k = 0; k < cnt; ++k) resolve_entry(k);
       cnt = 0;
     }
   };
@@ -449,9 +672,10 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
       pf[j] = (uint64_t(i) < valid2 && i < N2) ? src[i] : make_double2(INFINITY, INFINITY);
     }
   };
-  if (tile0 < tile1) fetch(tile0);
-  for (uint64_t t = tile0; t < tile1; ++t) {
-    const uint32_t row_base = uint32_t(t * kTileRows);
+  // a wave whose 32 query slots all lie past the batch only helps staging the tiles
+  const bool sweeping = by * kMfmaQueries + wave * 32 < B;
+  if (t_count > 0) fetch(t_first);
+  for (uint64_t it = 0; it < t_count; ++it) {
     {
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
@@ -464,7 +688,7 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
         tileT[(2 * dp + 1) * TS + row] = pad ? 1e18f : float(pf[j].y);
       }
     }
-    if (t + 1 < tile1) fetch(t + 1);
+    if (it + 1 < t_count) fetch(t_first + (it + 1) * t_step);
     __syncthreads();
     if (tid < kTileRows) {  // |x^|^2 of row tid, a float fmaf chain over the coordinates
       float acc = 0.0f;
@@ -476,72 +700,74 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
       xn[tid] = acc;
     }
     __syncthreads();
-    cmin = fminf(cmin, __shfl_xor(cmin, 32, 64));  // the other half's minimum bounds the final one just as well
-    // a wave whose 32 query slots all lie past the batch only helps staging the tiles
-    const int n_slabs = (by * kMfmaQueries + wave * 32 < B) ? kTileRows / 32 : 0;
-#pragma unroll 2
-    for (int g = 0; g < n_slabs; ++g) {
-      rkh_f16v c;
-      {
+    if (sweeping) {
+      // operands of slab g: C = |x^|^2 of the lane's 16 rows, A = the slab's column of coordinate 2 j + hi
+      auto load_ops = [&](int g, float (&aop)[H], rkh_f16v& c) {
         const rkh_f4v* x4 = reinterpret_cast<const rkh_f4v*>(xn + 32 * g + 4 * hi);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const rkh_f4v v = x4[2 * k];  // rows 32 g + 8 k + 4 hi .. +3
           c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
         }
-      }
 #pragma unroll
-      for (int j = 0; j < H; ++j) {
-        const float aop = tileT[(2 * j + hi) * TS + 32 * g + col];
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bop[j], c, 0, 0, 0);
-      }
-      // minima of the four 4-row groups, then of the slab
-      float gm[4];
+        for (int j = 0; j < H; ++j) aop[j] = tileT[(2 * j + hi) * TS + 32 * g + col];
+      };
+      auto chain = [&](const float (&aop)[H], rkh_f16v& c) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) gm[k] = fminf(fminf(c[4 * k], c[4 * k + 1]), fminf(c[4 * k + 2], c[4 * k + 3]));
-      const float m = fminf(fminf(gm[0], gm[1]), fminf(gm[2], gm[3]));
-      // running minimum of the query, over both lane halves: the pair then meets a new minimum as often as ONE sequence
-      // of twice the length would (ln 2 more often), not twice as often -- and every such event stalls the whole wave
-      cmin = fminf(cmin, m);
-      cmin = fminf(cmin, __shfl_xor(cmin, 32, 64));
-      const float lim = cmin + band;
-      if (m <= lim) {  // a new minimum, or a row within the band of the old one
-        if (cnt > kCandCap - 3) compact();
-        bool overflow = false;
+        for (int j = 0; j < H; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[j], bop[j], c, 0, 0, 0);
+      };
+      // the estimates of slab g are complete: running minimum, and (sweep proper) one entry if a row is within the band
+      auto settle = [&](int g, const rkh_f16v& c) {
+        // (v_min3 spelled out: fminf would first quiet every operand, one more VALU operation per estimate; the
+        // estimates are finite by construction)
+        float m = min3_raw(min3_raw(c[0], c[1], c[2]), min3_raw(c[3], c[4], c[5]), min3_raw(c[6], c[7], c[8]));
+        m = min3_raw(m, min3_raw(c[9], c[10], c[11]), min3_raw(c[12], c[13], c[14]));
+        m = min3_raw(m, c[15], m);
+        cmin = min3_raw(cmin, m, m);
+        if (SEED) return;
+        // over both lane halves: the pair then meets a new minimum as often as ONE sequence of twice the length would
+        cmin = min_over_halves(cmin);
+        const float lim = cmin + band;
+        if (m <= lim) {
+          if (cnt == kCandCap) compact(lim);
+          uint32_t mask = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (gm[k] <= lim) {  // usually one group, one row
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int i = 4 * k + j;
-              if (c[i] <= lim) {
-                if (cnt < kCandCap) {
-                  cand_c[cnt][tid] = c[i];
-                  cand_row[cnt][tid] = row_base + uint32_t(32 * g + 8 * (i >> 2) + 4 * hi + (i & 3));
-                  ++cnt;
-                } else {
-                  overflow = true;
-                }
-              }
-            }
-          }
+          for (int i = 0; i < 16; ++i) mask |= (c[i] <= lim) ? (1u << i) : 0u;
+          cand_key[cnt][tid] = uint32_t(it) * uint32_t(kSlabs) + uint32_t(g);
+          cand_mask[cnt][tid] = mask;
+          cand_m[cnt][tid] = m;
+          ++cnt;
         }
-        // more candidates in one slab than the list takes (many coincident vertices): settle this slab exactly
-        if (overflow) {
-#pragma unroll 1
-          for (int i = 0; i < 16; ++i) resolve(row_base + uint32_t(32 * g + 8 * (i >> 2) + 4 * hi + (i & 3)));
+      };
+      rkh_f16v c0, c1;
+      float a0[H], a1[H];
+      load_ops(0, a0, c0);
+      chain(a0, c0);
+#pragma unroll
+      for (int g = 0; g < kSlabs; g += 2) {
+        load_ops(g + 1, a1, c1);
+        chain(a1, c1);
+        settle(g, c0);
+        if (g + 2 < kSlabs) {
+          load_ops(g + 2, a0, c0);
+          chain(a0, c0);
         }
+        settle(g + 1, c1);
       }
     }
     __syncthreads();
   }
+  cmin = min_over_halves(cmin);
+  if (SEED) {
+    if (hi == 0 && qi < B && t_count > 0) atomicMin(seed + qi, seed_encode(cmin));
+    return;
+  }
   // resolve what the final minimum (of both halves) leaves of the list
-  cmin = fminf(cmin, __shfl_xor(cmin, 32, 64));
   {
     const float lim = cmin + band;
 #pragma unroll 1
     for (int k = 0; k < cnt; ++k)
-      if (cand_c[k][tid] <= lim) resolve(cand_row[k][tid]);
+      if (cand_m[k][tid] <= lim) resolve_entry(k);
   }
   {  // the two halves of the wave hold different rows of the same 32 queries
     const double od = __shfl_xor(best_d, 32, 64);
@@ -591,6 +817,7 @@ __global__ __launch_bounds__(256) void nn1_reduce_kernel(NnArgs single, const Nn
   if (lane == 0) {
     idx[qi] = bi;
     dist[qi] = bd;
+    if (a.seed) a.seed[qi] = 0xFFFFFFFFu;  // consumed: "no seed" again for the next sweep
   }
 }
 
@@ -638,10 +865,41 @@ static uint32_t pick_gx(uint64_t n_upper, uint32_t gy) {
   return uint32_t(tiles < want ? tiles : want);
 }
 
+// the register-direct sweep: exactly one resident set of blocks (`resident` = what the occupancy of the instantiation
+// allows on the whole device; a partial second round of blocks would run at a fraction of the machine); a thread's
+// fixed costs (the merge of the lanes at the end) are worth at least 4 rows
+static constexpr uint32_t kStreamBlocksMax = 2048;  // 8 blocks of 256 threads on each of 256 CUs
+static uint32_t pick_gx_stream(uint64_t n_upper, uint32_t n_problems, uint32_t resident) {
+  uint64_t tiles = (n_upper + kTileRows - 1) / kTileRows;
+  if (tiles < 1) tiles = 1;
+  if (resident > kStreamBlocksMax) resident = kStreamBlocksMax;
+  uint64_t want = resident / (n_problems ? n_problems : 1);
+  if (want < 1) want = 1;
+  const uint64_t most = tiles >= 4 ? tiles / 4 : 1;
+  if (want > most) want = most;
+  return uint32_t(want);
+}
+template <int DP, int QB>
+static uint32_t stream_resident_blocks() {
+  static const uint32_t v = [] {
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1024u;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 1024u;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nn1_stream_kernel<DP, QB>, kThreads, 0) != hipSuccess ||
+        per_cu <= 0)
+      return 1024u;
+    return uint32_t(per_cu) * uint32_t(cus);
+  }();
+  return v;
+}
+
 uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B, uint32_t n_problems) {
   const uint32_t qb = pick_qb(B);
   const uint32_t gy = (B + qb - 1) / qb;
-  return pick_gx(n_upper, gy * (n_problems ? n_problems : 1));
+  const uint32_t np = n_problems ? n_problems : 1;
+  const uint32_t a = pick_gx(n_upper, gy * np);
+  const uint32_t b = B <= 8 ? pick_gx_stream(n_upper, np, kStreamBlocksMax) : 0;
+  return a > b ? a : b;
 }
 
 uint32_t nn1_mfma_queries() { return uint32_t(kMfmaQueries); }
@@ -652,10 +910,17 @@ const char* nn_last_kernel_name() { return g_last_kernel; }
 template <int DP>
 static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
                                 uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0,
-                                hipEvent_t ev1, double coord_bound, const uint32_t* d_yblock_base) {
+                                hipEvent_t ev1, double coord_bound, const uint32_t* d_yblock_base, bool table_has_seed) {
   const uint32_t qb = pick_qb(B);
   const uint32_t gy = (B + qb - 1) / qb;
+  const bool stream = B <= 8 && D == DP;  // HBM-bound regime: rows straight into registers
   uint32_t gx = pick_gx(n_upper, gy * n_problems);
+  if (stream) {
+    const uint32_t resident = B <= 1 ? stream_resident_blocks<DP, 1>()
+                                     : (B <= 2 ? stream_resident_blocks<DP, 2>()
+                                               : (B <= 4 ? stream_resident_blocks<DP, 4>() : stream_resident_blocks<DP, 8>()));
+    gx = pick_gx_stream(n_upper, n_problems, resident);
+  }
   if (gx > part_capacity_blocks) gx = part_capacity_blocks;
   const uint32_t Bpad = B;
   dim3 grid(gx, gy, n_problems), block(kThreads);
@@ -665,11 +930,30 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
   if (ev0) (void)hipEventRecord(ev0, s);
   const bool f32 = coord_bound > 0.0 && qb >= 32;  // compute-bound regime with known coordinate bounds
   const bool mfma = f32 && qb == kMfmaQueries && mfma_enabled() && DP <= 16;
-  g_last_kernel = mfma ? "nn1_sweep_mfma_kernel" : (f32 ? "nn1_sweep_f32_kernel" : "nn1_sweep_kernel");
-  if (mfma) {
-    if constexpr (DP <= 16)
-      hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP>), grid, dim3(kMfmaThreads), 0, s, single, d_table, D, Bpad, coord_bound,
-                         d_table ? d_yblock_base : nullptr, n_problems);
+  g_last_kernel = stream ? "nn1_stream_kernel"
+                         : (mfma ? "nn1_sweep_mfma_kernel" : (f32 ? "nn1_sweep_f32_kernel" : "nn1_sweep_kernel"));
+  if (stream) {
+#define RKH_STREAM(QB) hipLaunchKernelGGL((nn1_stream_kernel<DP, QB>), grid, block, 0, s, single, d_table, Bpad)
+    if (B <= 1) { RKH_STREAM(1); }
+    else if (B <= 2) { RKH_STREAM(2); }
+    else if (B <= 4) { RKH_STREAM(4); }
+    else { RKH_STREAM(8); }
+#undef RKH_STREAM
+  } else if (mfma) {
+    if constexpr (DP <= 16) {
+      const uint32_t* yb = d_table ? d_yblock_base : nullptr;
+      auto blocks_for = [&](uint32_t slices) { return dim3((slices * gy * n_problems + 7) / 8 * 8); };
+      // the sampled-minimum pass (trees of at least kSeedMinTiles tiles; smaller ones leave "no seed" behind)
+      const uint64_t tiles_upper = (n_upper + kTileRows - 1) / kTileRows;
+      const bool seeded = (d_table ? table_has_seed : single.seed != nullptr) && tiles_upper >= uint64_t(kSeedMinTiles);
+      if (seeded) {  // kSeedSample sample tiles, four per seed block
+        const uint32_t gxs = kSeedSample / 4;
+        hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP, true>), blocks_for(gxs), dim3(kMfmaThreads), 0, s, single, d_table, D,
+                           Bpad, coord_bound, yb, n_problems, gxs, gy);
+      }
+      hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP, false>), blocks_for(gx), dim3(kMfmaThreads), 0, s, single, d_table, D,
+                         Bpad, coord_bound, yb, n_problems, gx, gy);
+    }
   } else
   switch (qb) {
     case 8: RKH_NN1_LAUNCH(8); break;
@@ -691,12 +975,12 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
 // n_upper (host bound on the vertex count) and B (host bound on the query count) only size the grid.
 rkh_status launch_nn1(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
                       uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0, hipEvent_t ev1,
-                      double coord_bound, const uint32_t* d_yblock_base) {
+                      double coord_bound, const uint32_t* d_yblock_base, bool table_has_seed) {
   if (B == 0 || n_problems == 0) return RKH_OK;
   switch (padded_dims(D)) {
 #define RKH_CASE(DP) \
   case DP: return launch_nn1_dp<DP>(s, D, single, d_table, n_problems, n_upper, B, part_capacity_blocks, ev0, ev1, coord_bound, \
-                                    d_yblock_base)
+                                    d_yblock_base, table_has_seed)
     RKH_CASE(2);
     RKH_CASE(4);
     RKH_CASE(6);

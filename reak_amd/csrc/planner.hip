@@ -649,7 +649,7 @@ rkh_status enqueue_round(rkh_planner* p) {
                      p->d_wave_base ? p->d_wave_base + (2 * p->P + 1) : nullptr, lane_kernel_edges_per_wave());
   // 1. NN sweep of every problem's samples over its snapshot
   rkh_status st = launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, batch_ub, p->part_blocks, ev0, ev1,
-                             p->coord_bound, p->d_nn_base);
+                             p->coord_bound, p->d_nn_base, true);
   if (st != RKH_OK) return st;
   // 2. speculative steer of all candidates + the goal probes of the vertices the previous round committed
   if (ev0) (void)hipEventRecord(p->ev_steer[2 * slot], s);
@@ -887,7 +887,9 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     RKH_HIP(hipMalloc(&q.d_probe_steps, p->b_max * sizeof(uint32_t)));
     RKH_HIP(hipMalloc(&q.d_goal, D * sizeof(double)));
     RKH_HIP(hipMalloc(&q.d_part_dist, uint64_t(p->part_blocks) * p->b_max * sizeof(double)));
-    RKH_HIP(hipMalloc(&q.d_part_idx, uint64_t(p->part_blocks) * p->b_max * sizeof(uint32_t)));
+    // one more row than the partials need: NnArgs::seed (sampled minima of the matrix-core sweep, "none" = all ones)
+    RKH_HIP(hipMalloc(&q.d_part_idx, uint64_t(p->part_blocks + 1) * p->b_max * sizeof(uint32_t)));
+    RKH_HIP(hipMemset(q.d_part_idx + uint64_t(p->part_blocks) * p->b_max, 0xFF, uint64_t(p->b_max) * sizeof(uint32_t)));
     if (p->profile_nn) RKH_HIP(hipMalloc(&q.d_round_n, 2 * rkh_planner::kProfMax * sizeof(uint32_t)));
     // root vertex = query start (create_root, rrt_path_planner.tpp:131-133)
     std::vector<double> row(DP, 0.0);
@@ -930,6 +932,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     na.d_B = &dst->B;
     na.part_dist = q.d_part_dist;
     na.part_idx = q.d_part_idx;
+    na.seed = q.d_part_idx + uint64_t(p->part_blocks) * p->b_max;
     na.idx = q.d_nn_idx;
     na.dist = q.d_nn_dist;
     EdgeIO& io = hio[i];

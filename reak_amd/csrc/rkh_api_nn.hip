@@ -1,6 +1,7 @@
 // rkh_api_nn.hip -- C-ABI: context + nearest-neighbour store (include/rkh.h).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 #include <mutex>
 
@@ -74,6 +75,7 @@ rkh_status rkh_nn_destroy(rkh_nn* nn) {
   hipFree(nn->d_count);
   hipFree(nn->d_part_dist);
   hipFree(nn->d_part_idx);
+  hipFree(nn->d_seed);
   hipFree(nn->d_knn_ws);
   delete nn;
   return RKH_OK;
@@ -81,6 +83,7 @@ rkh_status rkh_nn_destroy(rkh_nn* nn) {
 rkh_status rkh_nn_clear(rkh_nn* nn) {
   if (!nn) return RKH_ERR_BAD_ARG;
   nn->n = 0;
+  nn->max_abs_coord = 0.0;
   return RKH_OK;
 }
 uint64_t rkh_nn_size(const rkh_nn* nn) { return nn ? nn->n : 0; }
@@ -93,6 +96,17 @@ rkh_status rkh_nn_append(rkh_nn* nn, const double* pts, uint64_t n) {
   }
   if (n == 0) return RKH_OK;
   const int D = nn->st.D, DP = nn_padded_dims(D);
+  // the single-precision pre-filters are exact only if every |coordinate| <= coord_bound
+  double amax = 0.0;
+  for (uint64_t i = 0; i < n * uint64_t(D); ++i) {
+    const double v = std::fabs(pts[i]);
+    if (!(v <= amax)) amax = v;  // NaN ends up in amax
+  }
+  if (nn->coord_bound > 0.0 && !(amax <= nn->coord_bound)) {
+    set_error("rkh_nn_append: a coordinate exceeds the bound given to rkh_nn_set_coord_bound");
+    return RKH_ERR_BAD_ARG;
+  }
+  if (!(amax <= nn->max_abs_coord)) nn->max_abs_coord = amax;
   hipStream_t s = nn->ctx->stream;
   if (DP == D) {
     RKH_HIP(hipMemcpyAsync(nn->st.d_pos + nn->n * DP, pts, n * D * sizeof(double), hipMemcpyHostToDevice, s));
@@ -120,6 +134,13 @@ static rkh_status ensure_partials(rkh_nn* nn, uint32_t B) {
     nn->part_cap = need;
   }
   nn->part_blocks = blocks;
+  if (B > nn->seed_cap) {
+    hipFree(nn->d_seed);
+    nn->d_seed = nullptr;
+    RKH_HIP(hipMalloc(&nn->d_seed, uint64_t(B) * sizeof(uint32_t)));
+    RKH_HIP(hipMemsetAsync(nn->d_seed, 0xFF, uint64_t(B) * sizeof(uint32_t), nn->ctx->stream));
+    nn->seed_cap = B;
+  }
   return RKH_OK;
 }
 
@@ -147,6 +168,10 @@ static rkh_status ensure_scratch(rkh_nn* nn, uint64_t q_elems, uint64_t res_elem
 
 rkh_status rkh_nn_set_coord_bound(rkh_nn* nn, double bound) {
   if (!nn || !(bound >= 0.0)) return RKH_ERR_BAD_ARG;
+  if (bound > 0.0 && !(nn->max_abs_coord <= bound)) {
+    set_error("rkh_nn_set_coord_bound: rows already appended exceed the bound");
+    return RKH_ERR_BAD_ARG;
+  }
   nn->coord_bound = bound;
   return RKH_OK;
 }
@@ -165,6 +190,7 @@ rkh_status rkh_nn_query1_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32
   a.part_idx = nn->d_part_idx;
   a.idx = d_idx;
   a.dist = d_dist;
+  a.seed = nn->d_seed;
   hipEvent_t e0 = nn->ev0, e1 = nn->ev1;
   nn->ev0 = nn->ev1 = nullptr;
   return launch_nn1(nn->ctx->stream, nn->st.D, a, nullptr, 1, nn->n, B, nn->part_blocks, e0, e1, nn->coord_bound);
@@ -173,6 +199,13 @@ rkh_status rkh_nn_query1_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32
 rkh_status rkh_nn_query1(rkh_nn* nn, const double* q, uint32_t B, uint32_t* idx, double* dist) {
   if (!nn || !q || !idx || !dist) return RKH_ERR_BAD_ARG;
   if (B == 0) return RKH_OK;
+  if (nn->coord_bound > 0.0) {
+    for (uint64_t i = 0; i < uint64_t(B) * nn->st.D; ++i)
+      if (!(std::fabs(q[i]) <= nn->coord_bound)) {
+        set_error("rkh_nn_query1: a query coordinate exceeds the bound given to rkh_nn_set_coord_bound");
+        return RKH_ERR_BAD_ARG;
+      }
+  }
   rkh_status st = ensure_scratch(nn, uint64_t(B) * nn->st.D, B);
   if (st != RKH_OK) return st;
   hipStream_t s = nn->ctx->stream;
@@ -238,6 +271,7 @@ rkh_status rkh_nn_fill_uniform(rkh_nn* nn, uint64_t n, uint64_t seed) {
   if (st != RKH_OK) return st;
   RKH_HIP(hipStreamSynchronize(nn->ctx->stream));
   nn->n = n;
+  if (nn->max_abs_coord < 1.0) nn->max_abs_coord = 1.0;  // the unit hypercube
   return RKH_OK;
 }
 

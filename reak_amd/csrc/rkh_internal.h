@@ -48,10 +48,12 @@ struct NnArgs {  // one 1-NN problem: tree rows, queries, outputs (device pointe
   uint32_t* part_idx = nullptr;
   uint32_t* idx = nullptr;             // [B] results
   double* dist = nullptr;
+  uint32_t* seed = nullptr;            // [B] optional: matrix-core sweeps start from a sampled minimum (all 0xFF between sweeps)
 };
 rkh_status launch_nn1(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
                       uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0 = nullptr,
-                      hipEvent_t ev1 = nullptr, double coord_bound = 0.0, const uint32_t* d_yblock_base = nullptr);
+                      hipEvent_t ev1 = nullptr, double coord_bound = 0.0, const uint32_t* d_yblock_base = nullptr,
+                      bool table_has_seed = false);
 // d_yblock_base (table launches, matrix-core kernel): [n_problems + 1] exclusive prefix of ceil(B_p / nn1_mfma_queries())
 // over the problems; the grid's blocks then take the working (row slice, query block) pairs in dispatch order.
 uint32_t nn1_mfma_queries();
@@ -176,6 +178,9 @@ struct rkh_nn {
   double* d_part_dist = nullptr;
   uint32_t* d_part_idx = nullptr;
   uint64_t part_cap = 0;
+  uint32_t* d_seed = nullptr;  // NnArgs::seed
+  uint32_t seed_cap = 0;
+  double max_abs_coord = 0.0;  // over the rows appended from the host (checked against coord_bound)
   uint32_t part_blocks = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // one-shot: bracket the next sweep kernel
   void* d_knn_ws = nullptr;  // k-NN workspace

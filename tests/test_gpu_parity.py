@@ -48,6 +48,7 @@ def test_nn1_bit_exact(L, ctx, oracle, D, n, B):
 @pytest.mark.parametrize("D,n,B,expect", [(12, 30000, 300, "nn1_sweep_mfma_kernel"), (12, 777, 129, "nn1_sweep_mfma_kernel"),
                                            (6, 20000, 200, "nn1_sweep_mfma_kernel"), (3, 5000, 1000, "nn1_sweep_mfma_kernel"),
                                            (16, 9000, 130, "nn1_sweep_mfma_kernel"), (12, 30000, 48, "nn1_sweep_f32_kernel"),
+                                           (12, 600000, 200, "nn1_sweep_mfma_kernel"), (6, 8192, 1000, "nn1_sweep_mfma_kernel"),
                                            (24, 4000, 200, "nn1_sweep_f32_kernel")])
 def test_nn1_single_precision_prefilters_are_bit_exact(L, ctx, oracle, D, n, B, expect):
     """Sweeps with a coordinate bound run a float pre-filter (fp32 matrix cores above 64 queries, packed fp32 VALU below)
@@ -75,6 +76,29 @@ def test_nn1_single_precision_prefilters_are_bit_exact(L, ctx, oracle, D, n, B, 
     ridx, rdist = oracle.nn1(q, pts)
     assert np.array_equal(idx, ridx)
     assert np.array_equal(dist, rdist)
+
+
+def test_coordinate_bound_is_checked_where_the_library_holds_the_data(L, ctx):
+    """rkh_nn_set_coord_bound is a promise the pre-filters' exactness rests on: rows and host queries beyond it are refused."""
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-1, 1, size=(1000, 6))
+    nn = L.HipNeighborSearch(ctx, 6, 2000)
+    nn.added_vertices(pts)
+    with pytest.raises(L.RkhError):
+        nn.set_coord_bound(0.5)          # rows already stored exceed it
+    nn.set_coord_bound(1.0)
+    bad = pts[:10].copy()
+    bad[3, 2] = 1.5
+    with pytest.raises(L.RkhError):
+        nn.added_vertices(bad)
+    assert len(nn) == 1000
+    q = rng.uniform(-1, 1, size=(100, 6))
+    q[50, 0] = -1.0001
+    with pytest.raises(L.RkhError):
+        nn.nearest(q)
+    q[50, 0] = -1.0
+    idx, _ = nn.nearest(q)
+    assert np.all(idx < 1000)
 
 
 def test_nn1_ties_first_minimum_wins(L, ctx, oracle):
