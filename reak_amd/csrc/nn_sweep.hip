@@ -159,6 +159,8 @@ __global__ __launch_bounds__(kThreads) void nn1_sweep_kernel(NnArgs single, cons
 // rows; lanes and waves are merged once at the end.  Same operation sequence per (row, query) as nn1_sweep_kernel.
 typedef const __attribute__((address_space(4))) double* nn_cdouble_p;
 typedef double nn_d2 __attribute__((ext_vector_type(2)));
+// queries per basic block of the register-direct sweep (1, 2 and 4 measured within 2 % of one another)
+static constexpr int kStreamGroup = 1;
 
 template <int DP, int QB>
 __global__ __launch_bounds__(kThreads, 2) void nn1_stream_kernel(NnArgs single, const NnArgs* __restrict__ table,
@@ -209,25 +211,43 @@ __global__ __launch_bounds__(kThreads, 2) void nn1_stream_kernel(NnArgs single, 
     const uint64_t row = t * kTileRows + tid;
     const bool valid = row < n;
     asm volatile("" : "+s"(qc));  // keep the query loads inside the loop (hoisted, they would not fit the scalar file)
+    // queries in groups of G: the squared distances of a group are computed in one basic block (the scalar loads of its
+    // later queries can then be issued under the arithmetic of the earlier ones), then tested together
+    constexpr int G = QB < kStreamGroup ? QB : kStreamGroup;
 #pragma unroll
-    for (int k = 0; k < QB; ++k) {
-      nn_cdouble_p qk = qc + uint32_t(uint32_t(k) < B ? k : B - 1) * DP;
-      double s;
-      {
-        const double df = qk[0] - cur[0].x;
-        s = df * df;
-      }
+    for (int g = 0; g < QB; g += G) {
+      double sq[G];
 #pragma unroll
-      for (int d = 1; d < DP; ++d) {
-        const double df = qk[d] - ((d & 1) ? cur[d >> 1].y : cur[d >> 1].x);
-        s = s + df * df;
+      for (int j = 0; j < G; ++j) {
+        const int k = g + j;
+        nn_cdouble_p qk = qc + uint32_t(uint32_t(k) < B ? k : B - 1) * DP;
+        double s;
+        {
+          const double df = qk[0] - cur[0].x;
+          s = df * df;
+        }
+#pragma unroll
+        for (int d = 1; d < DP; ++d) {
+          const double df = qk[d] - ((d & 1) ? cur[d >> 1].y : cur[d >> 1].x);
+          s = s + df * df;
+        }
+        sq[j] = s;
       }
-      if (valid && s <= best_thr[k]) {
-        const double dd = sqrt(s);
-        if (dd < best_d[k]) {
-          best_d[k] = dd;
-          best_i[k] = uint32_t(row);
-          best_thr[k] = s * (1.0 + 4.0 * DBL_EPSILON);
+      bool hit = false;
+#pragma unroll
+      for (int j = 0; j < G; ++j) hit = hit || (sq[j] <= best_thr[g + j]);
+      if (valid && hit) {  // rare after the first few rows
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const int k = g + j;
+          if (sq[j] <= best_thr[k]) {
+            const double dd = sqrt(sq[j]);
+            if (dd < best_d[k]) {
+              best_d[k] = dd;
+              best_i[k] = uint32_t(row);
+              best_thr[k] = sq[j] * (1.0 + 4.0 * DBL_EPSILON);
+            }
+          }
         }
       }
     }
@@ -676,10 +696,14 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
   const bool sweeping = by * kMfmaQueries + wave * 32 < B;
   if (t_count > 0) fetch(t_first);
   for (uint64_t it = 0; it < t_count; ++it) {
+    // the staging indices are recomputed every tile (an opaque copy of the thread id): hoisted out of the loop they
+    // stay live across the slab loop and push its registers into scratch
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
     {
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
-        const int i = tid + j * kMfmaThreads;
+        const int i = tl + j * kMfmaThreads;
         if (i >= N2) continue;
         const int row = i / H, dp = i - row * H;
         // rows past the end of the tree: a large finite float (estimate ~1e36: never a candidate)
@@ -690,14 +714,14 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
     }
     if (it + 1 < t_count) fetch(t_first + (it + 1) * t_step);
     __syncthreads();
-    if (tid < kTileRows) {  // |x^|^2 of row tid, a float fmaf chain over the coordinates
+    if (tl < kTileRows) {  // |x^|^2 of row tl, a float fmaf chain over the coordinates
       float acc = 0.0f;
 #pragma unroll
       for (int d = 0; d < DP; ++d) {
-        const float v = tileT[d * TS + tid];
+        const float v = tileT[d * TS + tl];
         acc = __builtin_fmaf(v, v, acc);
       }
-      xn[tid] = acc;
+      xn[tl] = acc;
     }
     __syncthreads();
     if (sweeping) {
