@@ -191,6 +191,17 @@ typedef struct rkh_rrtstar_stats {
 } rkh_rrtstar_stats;
 rkh_status rkh_rrtstar_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_rrt_params* prms,
                                        uint32_t n_problems, rkh_rrtstar** out);
+/* The same planner over the steerable dynamic free space (rkh_dyn_space: vertices are states (q, qd), every candidate
+ * edge -- expand_to_nearest, can_be_connected in each direction -- is an RK4 propagation with collision checks, as in
+ * rkh_planner_*).  For a space with an asymmetric metric the reference builds a directed motion graph
+ * (motion_graph_structures.hpp:73-74) and runs rrg_node_generator's directed overload (node_generators.hpp:176-206) and
+ * lazy_node_connector's (lazy_connector.hpp:418-460: connect_best_predecessor over the predecessor neighbourhood,
+ * connect_successors :277-325 over the successor neighbourhood; both from min_dist_linear_search
+ * topological_search.hpp:296-345).  This space's metric is the symmetric Euclidean state distance, under which the two
+ * neighbourhoods coincide (one k-NN sweep serves both); what is directional is every can_be_connected call, and those
+ * are evaluated per direction. */
+rkh_status rkh_rrtstar_create_batch(rkh_scene* scene, const rkh_dyn_space* space, const rkh_rrt_params* prms,
+                                    uint32_t n_problems, rkh_rrtstar** out);
 rkh_status rkh_rrtstar_destroy(rkh_rrtstar* p);
 /* stats: array of n_problems entries.  max_loop_iterations < 0: run until keep_going() is false. */
 rkh_status rkh_rrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_rrtstar_stats* stats);
@@ -214,6 +225,12 @@ typedef struct rkh_prm_stats {
 } rkh_prm_stats;
 rkh_status rkh_prm_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_prm_params* prms,
                                    uint32_t n_problems, rkh_prm** out);
+/* The same planner over the steerable dynamic free space: vertices are states (q, qd); the rejection sampling tests
+ * is_free(state), every random-walk attempt is steer_position_toward(v, target_dist / dist, p_rnd) -- an RK4 propagation
+ * over that fraction of the edge time -- and every connection a full propagation judged by can_be_connected.  A walk
+ * whose fraction asks for more RK4 steps than an edge's budget (64) is refused with RKH_ERR_UNSUPPORTED. */
+rkh_status rkh_prm_create_batch(rkh_scene* scene, const rkh_dyn_space* space, const rkh_prm_params* prms, uint32_t n_problems,
+                                rkh_prm** out);
 rkh_status rkh_prm_destroy(rkh_prm* p);
 /* stats: array of n_problems entries.  max_loop_iterations < 0: run until keep_going() is false. */
 rkh_status rkh_prm_solve(rkh_prm* p, int64_t max_loop_iterations, rkh_prm_stats* stats);

@@ -282,6 +282,8 @@ static DynSpace make_dyn(Scene* s, const rkh_dyn_space* P) {
   DynSpace sp;
   sp.P = *P;
   sp.D = 2 * P->n_dof;
+  sp.lower.assign(P->lower, P->lower + sp.D);
+  sp.upper.assign(P->upper, P->upper + sp.D);
   sp.chain = s->chain;
   sp.env = s->env;
   return sp;
@@ -425,6 +427,34 @@ int orc_rrtstar_qs(void* h, int D, const double* lower, const double* upper, dou
   out->best_cost = g_last_star.best_cost;
   return 0;
 }
+// RRT* over the steerable dynamic free space (vertices = states).  The reference picks a directed motion graph when the
+// space's metric is not symmetric (motion_graph_structures.hpp:73-74) and then runs the directed branches
+// (rrg_node_generator node_generators.hpp:176-206, lazy_node_connector lazy_connector.hpp:418-460 with the
+// predecessor / successor neighbourhoods of topological_search.hpp:296-345).  This space's metric is the symmetric
+// Euclidean state distance, for which the two neighbourhoods hold the same vertices in the same order and the directed
+// branch performs exactly the steps of the undirected one (connect_best_predecessor over Pred, connect_successors
+// over Succ, both with direction-specific can_be_connected calls): generate_rrt_star<DynSpace> is both.
+int orc_rrtstar_dyn(void* h, const rkh_dyn_space* P, const rkh_rrt_params* prm, int64_t max_loop_iterations,
+                    OrcRrtStarOut* out) {
+  Scene* s = static_cast<Scene*>(h);
+  DynSpace sp = make_dyn(s, P);
+  auto t0 = std::chrono::steady_clock::now();
+  try {
+    generate_rrt_star(sp, *prm, long(max_loop_iterations), g_last_star);
+  } catch (const singularity_error&) {
+    return -3;
+  }
+  out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  out->num_vertices = g_last_star.pred.size();
+  out->samples = g_last_star.samples;
+  out->loop_iterations = g_last_star.loop_iterations;
+  out->num_solutions = g_last_star.num_solutions;
+  out->rewires = g_last_star.rewires;
+  out->edges_checked = g_last_star.cnt.edges_checked;
+  out->states_checked = g_last_star.cnt.states_checked;
+  out->best_cost = g_last_star.best_cost;
+  return 0;
+}
 void orc_rrtstar_copy(double* pos, uint32_t* pred, double* dist, uint32_t* near_seq) {
   if (pos) std::memcpy(pos, g_last_star.pos.data(), g_last_star.pos.size() * sizeof(double));
   if (pred) std::memcpy(pred, g_last_star.pred.data(), g_last_star.pred.size() * sizeof(uint32_t));
@@ -452,6 +482,29 @@ int orc_prm_qs(void* h, int D, const double* lower, const double* upper, double 
   sp.env = s->env;
   auto t0 = std::chrono::steady_clock::now();
   generate_prm(sp, *prm, long(max_loop_iterations), g_last_prm);
+  out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  out->num_vertices = g_last_prm.density.size();
+  out->num_edges = g_last_prm.edge_w.size();
+  out->samples = g_last_prm.samples;
+  out->rejected = g_last_prm.rejected;
+  out->loop_iterations = g_last_prm.loop_iterations;
+  out->num_components = g_last_prm.num_components;
+  out->publish_calls = g_last_prm.publish_calls;
+  out->merged_at_vertex = g_last_prm.merged_at_vertex;
+  out->edges_checked = g_last_prm.cnt.edges_checked;
+  out->states_checked = g_last_prm.cnt.states_checked;
+  return 0;
+}
+// PRM over the steerable dynamic free space (vertices = states; every walk / connection is an RK4 propagation)
+int orc_prm_dyn(void* h, const rkh_dyn_space* P, const rkh_prm_params* prm, int64_t max_loop_iterations, OrcPrmOut* out) {
+  Scene* s = static_cast<Scene*>(h);
+  DynSpace sp = make_dyn(s, P);
+  auto t0 = std::chrono::steady_clock::now();
+  try {
+    generate_prm(sp, *prm, long(max_loop_iterations), g_last_prm);
+  } catch (const singularity_error&) {
+    return -3;
+  }
   out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   out->num_vertices = g_last_prm.density.size();
   out->num_edges = g_last_prm.edge_w.size();

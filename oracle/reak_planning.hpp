@@ -239,6 +239,7 @@ int runge_kutta4_integrate(F get_state_derivative, int D, const double* start_po
 struct DynSpace {
   rkh_dyn_space P;
   int D = 0;
+  std::vector<double> lower, upper;  // the state hyperbox (copies of P.lower / P.upper for the planners that read them)
   KteChain chain;
   ProxyEnv env;
   SpaceCounters cnt;

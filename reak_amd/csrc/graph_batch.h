@@ -135,6 +135,8 @@ struct GraphBatch {
   rkh_scene* scene = nullptr;
   hipStream_t stream = nullptr;
   QsDev qs;
+  bool dynamic = false;  // edges are RK4 propagations through the steerable dynamic space (D = 2 n_dof states)
+  DynDev dyn;
   int n_dof = 0, D = 0, DP = 0;
   uint32_t P = 0, kmax = 0, emax = 0;
   std::vector<GbProblem> prob;
@@ -154,22 +156,38 @@ struct GraphBatch {
   bool any_knn = false, any_edges = false, any_append = false, any_stage_a = false;
   uint64_t steps = 0;
 
+  // the steerable dynamic free space: vertices are states (q, qd), edges steer_position_toward (planner.hip's space)
+  rkh_status init_dynamic(rkh_scene* sc, const rkh_dyn_space* space, uint32_t n_problems, const uint64_t* capacities,
+                          uint32_t kmax_) {
+    if (2 * space->n_dof > RKH_MAX_DOF) {
+      set_error("graph batch: state dimension exceeds RKH_MAX_DOF");
+      return RKH_ERR_UNSUPPORTED;
+    }
+    rkh_status st = build_dyn_dev(*space, 1.0, &dyn);
+    if (st != RKH_OK) return st;
+    dynamic = true;
+    std::memset(&qs, 0, sizeof(qs));
+    return init_common(sc, space->n_dof, 2 * space->n_dof, n_problems, capacities, kmax_);
+  }
   rkh_status init(rkh_scene* sc, const rkh_qs_space* space, uint32_t n_problems, const uint64_t* capacities,
                   uint32_t kmax_) {
+    std::memset(&qs, 0, sizeof(qs));
+    qs.min_interval = space->min_interval;
+    qs.fraction = 1.0;
+    for (int d = 0; d < space->n_dof; ++d) {
+      qs.lower[d] = space->lower[d];
+      qs.upper[d] = space->upper[d];
+    }
+    return init_common(sc, space->n_dof, space->n_dof, n_problems, capacities, kmax_);
+  }
+  rkh_status init_common(rkh_scene* sc, int n_dof_, int D_, uint32_t n_problems, const uint64_t* capacities, uint32_t kmax_) {
     scene = sc;
-    n_dof = space->n_dof;
-    D = space->n_dof;
+    n_dof = n_dof_;
+    D = D_;
     DP = nn_padded_dims(D);
     P = n_problems;
     kmax = kmax_;
     emax = 2 * kmax_;
-    std::memset(&qs, 0, sizeof(qs));
-    qs.min_interval = space->min_interval;
-    qs.fraction = 1.0;
-    for (int d = 0; d < D; ++d) {
-      qs.lower[d] = space->lower[d];
-      qs.upper[d] = space->upper[d];
-    }
     RKH_HIP(hipSetDevice(sc->ctx->device));
     RKH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     cmd_bytes = size_t(P) * (sizeof(KnnArgs) + 2 * sizeof(EdgeIO) + sizeof(GbAux));
@@ -297,6 +315,12 @@ struct GraphBatch {
     if (select_mode == GB_SELECT_POINT) {
       io.mode = EDGE_POINT;
     } else {
+      if (dynamic)  // a walk's travel time is its fraction of the edge time; the kernel's step budget is kMaxSteps
+        for (uint32_t c = 0; c < count; ++c)
+          if (!(a.frac[c] * dyn.full_time <= kMaxSteps * dyn.dt)) {
+            set_error("graph batch: a random walk over the dynamic space asks for more than the step budget of an edge");
+            return RKH_ERR_UNSUPPORTED;
+          }
       io.mode = EDGE_WALK_ACCEPT;
       io.frac = d_aux[i].frac;
       io.best_case = d_aux[i].target_dist;
@@ -389,8 +413,10 @@ struct GraphBatch {
     RKH_HIP(hipMemcpyAsync(d_cmd, h_cmd, cmd_bytes, hipMemcpyHostToDevice, s));
     if (any_append) hipLaunchKernelGGL(gb_prep_kernel, dim3(P), dim3(64), 0, s, d_aux, DP);
     if (any_stage_a) {
-      rkh_status st = launch_edge_check(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, qs,
-                                        EdgeIO(), kGbStageA, nullptr, 0, d_ioa, nullptr, P);
+      rkh_status st = dynamic ? launch_propagate(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs,
+                                                 dyn, EdgeIO(), kGbStageA, nullptr, 0, 64, d_ioa, nullptr, P)
+                              : launch_edge_check(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs,
+                                                  scene->n_pairs, qs, EdgeIO(), kGbStageA, nullptr, 0, d_ioa, nullptr, P);
       if (st != RKH_OK) return st;
       hipLaunchKernelGGL(gb_select_kernel, dim3(P), dim3(64), 0, s, d_aux, D, DP);
     }
@@ -400,8 +426,11 @@ struct GraphBatch {
     }
     hipLaunchKernelGGL(gb_list_kernel, dim3(P), dim3(64), 0, s, d_aux);
     if (any_edges) {
-      rkh_status st = launch_edge_check(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, qs,
-                                        EdgeIO(), emax, nullptr, 0, d_io, nullptr, P);
+      // one wave per edge: a step holds at most 2 k candidates per problem, far from filling the two-lanes mappings
+      rkh_status st = dynamic ? launch_propagate(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs,
+                                                 dyn, EdgeIO(), emax, nullptr, 0, 64, d_io, nullptr, P)
+                              : launch_edge_check(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs,
+                                                  scene->n_pairs, qs, EdgeIO(), emax, nullptr, 0, d_io, nullptr, P);
       if (st != RKH_OK) return st;
     }
     RKH_HIP(hipMemcpyAsync(h_res, d_res, res_stride * P, hipMemcpyDeviceToHost, s));

@@ -322,25 +322,24 @@ void connect_vertex(rkh_prm* p, uint32_t i, const double* pt, uint32_t x_near, d
 
 extern "C" {
 
-rkh_status rkh_prm_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_prm_params* prms,
-                                   uint32_t n_problems, rkh_prm** out) {
-  if (!scene || !space || !prms || !out || n_problems < 1) return RKH_ERR_BAD_ARG;
-  if (space->n_dof != scene->host.n_dof || !(space->min_interval > 0.0)) {
-    set_error("rkh_prm_create: n_dof mismatch or min_interval <= 0");
-    return RKH_ERR_BAD_ARG;
-  }
+}  // extern "C"
+
+namespace {
+// qs != nullptr: quasi-static free space; dyn != nullptr: steerable dynamic free space (vertices = states, D = 2 n_dof)
+rkh_status prm_create(rkh_scene* scene, const rkh_qs_space* space, const rkh_dyn_space* dyn, const rkh_prm_params* prms,
+                      uint32_t n_problems, rkh_prm** out) {
   for (uint32_t i = 0; i < n_problems; ++i)
     if (!(prms[i].sampling_radius > 0.0)) {
       set_error("rkh_prm_create: sampling_radius must be positive");
       return RKH_ERR_BAD_ARG;
     }
   rkh_prm* p = new rkh_prm();
-  p->D = space->n_dof;
+  p->D = space ? space->n_dof : 2 * dyn->n_dof;
   p->P = n_problems;
   const int D = p->D;
   for (int d = 0; d < D; ++d) {
-    p->lower[d] = space->lower[d];
-    p->upper[d] = space->upper[d];
+    p->lower[d] = space ? space->lower[d] : dyn->lower[d];
+    p->upper[d] = space ? space->upper[d] : dyn->upper[d];
   }
   uint32_t max_v = 0;
   std::vector<uint64_t> caps(n_problems);
@@ -349,7 +348,8 @@ rkh_status rkh_prm_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, 
     caps[i] = uint64_t(prms[i].base.max_vertices) + 2;
   }
   const uint32_t kmax = uint32_t(4 * (highest_set_bit(size_t(max_v) + 2) + 1));
-  rkh_status st = p->gb.init(scene, space, n_problems, caps.data(), kmax);
+  rkh_status st = space ? p->gb.init(scene, space, n_problems, caps.data(), kmax)
+                        : p->gb.init_dynamic(scene, dyn, n_problems, caps.data(), kmax);
   if (st != RKH_OK) {
     p->gb.destroy();
     delete p;
@@ -385,6 +385,29 @@ rkh_status rkh_prm_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, 
   }
   *out = p;
   return RKH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+rkh_status rkh_prm_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_prm_params* prms,
+                                   uint32_t n_problems, rkh_prm** out) {
+  if (!scene || !space || !prms || !out || n_problems < 1) return RKH_ERR_BAD_ARG;
+  if (space->n_dof != scene->host.n_dof || !(space->min_interval > 0.0)) {
+    set_error("rkh_prm_create: n_dof mismatch or min_interval <= 0");
+    return RKH_ERR_BAD_ARG;
+  }
+  return prm_create(scene, space, nullptr, prms, n_problems, out);
+}
+
+rkh_status rkh_prm_create_batch(rkh_scene* scene, const rkh_dyn_space* space, const rkh_prm_params* prms, uint32_t n_problems,
+                                rkh_prm** out) {
+  if (!scene || !space || !prms || !out || n_problems < 1) return RKH_ERR_BAD_ARG;
+  if (space->n_dof != scene->host.n_dof) {
+    set_error("rkh_prm_create: n_dof mismatch");
+    return RKH_ERR_BAD_ARG;
+  }
+  return prm_create(scene, nullptr, space, prms, n_problems, out);
 }
 
 rkh_status rkh_prm_destroy(rkh_prm* p) {

@@ -692,7 +692,7 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
   stage_env(sc, env_lds, lane);
   GroupWs<N>& ws = lds.g[g];
   const uint32_t si = io.src_idx ? io.src_idx[ec] : ((io.d_src_first ? *io.d_src_first : 0u) + ec);
-  const uint64_t trow = (io.d_tgt_off ? uint64_t(*io.d_tgt_off) : 0ull) + ec;
+  const uint64_t trow = io.tgt_idx ? uint64_t(io.tgt_idx[ec]) : (io.d_tgt_off ? uint64_t(*io.d_tgt_off) : 0ull) + ec;
   const double a_d = (gl < D) ? io.src[uint64_t(si) * io.src_stride + gl] : 0.0;
   const double b_d = (gl < D) ? io.tgt[trow * io.tgt_stride + gl] : 0.0;
   const double lo = (gl < D) ? dyn.lower[gl] : 0.0;
@@ -709,7 +709,37 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
   bool alive = true;       // this edge is still stepping
   if (record && gl < D) record[(uint64_t(e) * record_stride + 0) * D + gl] = x;
 
-  for (int k = 0; k < dyn.n_steps; ++k) {
+  // steps of this edge: the launch's schedule, or (EdgeIO::frac) the edge's own travel fraction cut with the comparison
+  // of the steer loop, current_time < fraction * (steps_per_edge * dt), current_time accumulated step by step
+  int n_steps = dyn.n_steps;
+  if (io.frac) {
+    const double T_goal = io.frac[ec] * dyn.full_time;
+    double current_time = 0.0;
+    n_steps = 0;
+    while (current_time < T_goal && n_steps < kMaxSteps) {
+      current_time += dyn.dt;
+      ++n_steps;
+    }
+  }
+  if (io.mode == EDGE_POINT) {  // is_free(target): bounds, then proximity; no propagation
+    n_steps = 0;
+    x = b_d;
+    bool oob = false;
+    if (gl < D) {
+      if (lo < hi) oob = (x < lo) || (x > hi);
+      else oob = (x > lo) || (x < hi);
+    }
+    const unsigned long long m = __ballot(oob);
+    const unsigned long long gm = (GL == 64) ? m : ((m >> gb) & ((1ull << (GL & 63)) - 1ull));
+    bool free_pt = gm == 0ull;
+    if (gl < D) ws.x[gl] = x;
+    __syncthreads();
+    const double dmin = proximity_min<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true, !free_pt);
+    if (dmin < 0.0) free_pt = false;
+    if (edge_valid && gl == 0) io.accept[e] = free_pt ? 1 : 0;
+  }
+
+  for (int k = 0; k < n_steps; ++k) {
     // distance(x_current, x_goal) > goal_proximity_threshold
     const double dist = group_norm<N>(ws, x - b_d, gl);
     if (!(dist > dyn.goal_tol)) alive = false;
@@ -794,7 +824,15 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
       const double best_case = io.best_case ? io.best_case[ec] : n_ab;
       const bool ok = (!isinf(traveled)) && (traveled < 2.0 * best_case) && (traveled > io.steer_tol * best_case);
       if (edge_valid && gl == 0) io.accept[e] = ok ? 1 : 0;
-    } else {
+    } else if (io.mode == EDGE_CONNECT) {
+      // planning_visitor_base::can_be_connected (planning_visitors.hpp:385-395); steer_tol carries the connection tolerance
+      const bool ok = (!isinf(n_ar)) && (n_rb < io.steer_tol * n_ar);
+      if (edge_valid && gl == 0) io.accept[e] = ok ? 1 : 0;
+    } else if (io.mode == EDGE_WALK_ACCEPT) {
+      // planning_visitor_base::random_walk (planning_visitors.hpp:418-421)
+      const bool ok = (!isinf(n_ar)) && (n_ar > io.steer_tol * io.best_case[ec]);
+      if (edge_valid && gl == 0) io.accept[e] = ok ? 1 : 0;
+    } else if (io.mode == EDGE_GOAL_PROBE) {
       // C_free distance used by the goal probe (MEAQR_topology.hpp:995-1003)
       if (edge_valid && gl == 0) io.goal_dist[si - 1] = (n_ab * 0.05 > n_rb) ? n_ab : INFINITY;
     }

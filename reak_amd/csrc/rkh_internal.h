@@ -211,8 +211,9 @@ struct PairDev {
 struct DynDev {  // rkh_dyn_space on the device (passed by value)
   double dt, kp, kd, u_max, goal_tol;
   double lower[2 * kMaxDof], upper[2 * kMaxDof];
+  double full_time;         // steps_per_edge * dt (the travel time of fraction 1)
   int n_steps;              // RK4 steps for this fraction
-  int8_t inner[kMaxSteps];  // runge_kutta4_integrate_impl loop iterations of step k (normally 1)
+  int8_t inner[kMaxSteps];  // runge_kutta4_integrate_impl loop iterations of step k (normally 1), whole step budget
 };
 
 enum EdgeMode : int {
@@ -221,7 +222,7 @@ enum EdgeMode : int {
   EDGE_GOAL_PROBE = 2,
   EDGE_CONNECT = 3,
   EDGE_WALK_ACCEPT = 4,  // random_walk: traveled > steer_tol * best_case[e] (best_case carries the target distance)
-  EDGE_POINT = 5,        // quasi-static kernel only: accept = is_free(target point), no walk
+  EDGE_POINT = 5,        // accept = is_free(target point), no walk (quasi-static kernel, one-wave-per-edge dynamics kernel)
 };
 
 struct QsDev {  // manip_quasi_static_env on the device (passed by value)

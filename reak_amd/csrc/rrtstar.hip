@@ -195,19 +195,19 @@ void connect_vertex(rkh_rrtstar* p, uint32_t i) {
 
 extern "C" {
 
-rkh_status rkh_rrtstar_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_rrt_params* prms,
-                                       uint32_t n_problems, rkh_rrtstar** out) {
-  if (!scene || !space || !prms || !out || n_problems < 1) return RKH_ERR_BAD_ARG;
-  if (space->n_dof != scene->host.n_dof || !(space->min_interval > 0.0)) {
-    set_error("rkh_rrtstar_create: n_dof mismatch or min_interval <= 0");
-    return RKH_ERR_BAD_ARG;
-  }
+}  // extern "C"
+
+namespace {
+// qs != nullptr: quasi-static free space (vertices = joint positions); dyn != nullptr: steerable dynamic free space
+// (vertices = states (q, qd), D = 2 n_dof; edges are RK4 propagations)
+rkh_status rrtstar_create(rkh_scene* scene, const rkh_qs_space* qs, const rkh_dyn_space* dyn, const rkh_rrt_params* prms,
+                          uint32_t n_problems, rkh_rrtstar** out) {
   rkh_rrtstar* p = new rkh_rrtstar();
-  p->D = space->n_dof;
+  p->D = qs ? qs->n_dof : 2 * dyn->n_dof;
   p->P = n_problems;
   for (int d = 0; d < p->D; ++d) {
-    p->lower[d] = space->lower[d];
-    p->upper[d] = space->upper[d];
+    p->lower[d] = qs ? qs->lower[d] : dyn->lower[d];
+    p->upper[d] = qs ? qs->upper[d] : dyn->upper[d];
   }
   uint32_t max_v = 0;
   std::vector<uint64_t> caps(n_problems);
@@ -216,7 +216,8 @@ rkh_status rkh_rrtstar_create_qs_batch(rkh_scene* scene, const rkh_qs_space* spa
     caps[i] = uint64_t(prms[i].max_vertices) + 2;
   }
   const uint32_t kmax = uint32_t(4 * (highest_set_bit(size_t(max_v) + 2) + 1));
-  rkh_status st = p->gb.init(scene, space, n_problems, caps.data(), kmax);
+  rkh_status st = qs ? p->gb.init(scene, qs, n_problems, caps.data(), kmax)
+                     : p->gb.init_dynamic(scene, dyn, n_problems, caps.data(), kmax);
   if (st != RKH_OK) {
     p->gb.destroy();
     delete p;
@@ -251,6 +252,29 @@ rkh_status rkh_rrtstar_create_qs_batch(rkh_scene* scene, const rkh_qs_space* spa
   }
   *out = p;
   return RKH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+rkh_status rkh_rrtstar_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_rrt_params* prms,
+                                       uint32_t n_problems, rkh_rrtstar** out) {
+  if (!scene || !space || !prms || !out || n_problems < 1) return RKH_ERR_BAD_ARG;
+  if (space->n_dof != scene->host.n_dof || !(space->min_interval > 0.0)) {
+    set_error("rkh_rrtstar_create: n_dof mismatch or min_interval <= 0");
+    return RKH_ERR_BAD_ARG;
+  }
+  return rrtstar_create(scene, space, nullptr, prms, n_problems, out);
+}
+
+rkh_status rkh_rrtstar_create_batch(rkh_scene* scene, const rkh_dyn_space* space, const rkh_rrt_params* prms,
+                                    uint32_t n_problems, rkh_rrtstar** out) {
+  if (!scene || !space || !prms || !out || n_problems < 1) return RKH_ERR_BAD_ARG;
+  if (space->n_dof != scene->host.n_dof) {
+    set_error("rkh_rrtstar_create: n_dof mismatch");
+    return RKH_ERR_BAD_ARG;
+  }
+  return rrtstar_create(scene, nullptr, space, prms, n_problems, out);
 }
 
 rkh_status rkh_rrtstar_destroy(rkh_rrtstar* p) {

@@ -113,10 +113,14 @@ rkh_status build_dyn_dev(const rkh_dyn_space& sp, double fraction, DynDev* out) 
     d.lower[i] = sp.lower[i];
     d.upper[i] = sp.upper[i];
   }
-  const double T_goal = fraction * (sp.steps_per_edge * sp.dt);
+  // the schedule is evaluated over the whole step budget (edges with their own travel fraction, EdgeIO::frac, cut it
+  // on the device with the same comparison); n_steps = its length for this call's fraction
+  d.full_time = sp.steps_per_edge * sp.dt;
+  const double T_goal = fraction * d.full_time;
   double current_time = 0.0;
-  int k = 0;
-  while (current_time < T_goal && k < kMaxSteps) {
+  int k = 0, n = 0;
+  while (k < kMaxSteps) {
+    if (current_time < T_goal) n = k + 1;
     double t = current_time;
     const double end_time = current_time + sp.dt;
     int it = 0;
@@ -129,6 +133,7 @@ rkh_status build_dyn_dev(const rkh_dyn_space& sp, double fraction, DynDev* out) 
     current_time += sp.dt;
     ++k;
   }
+  k = n;
   d.n_steps = k;
   *out = d;
   return RKH_OK;

@@ -72,8 +72,8 @@ EXPORTS = [
     "rkh_scene_create", "rkh_scene_create_with_meshes", "rkh_diag_gjk_distance", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
-    "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
-    "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph", "rkh_birrt_create_qs_batch", "rkh_birrt_destroy", "rkh_birrt_solve", "rkh_birrt_get_trees", "rkh_planner_get_solution", "rkh_rrtstar_get_solution", "rkh_birrt_get_solution",
+    "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_create_batch", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
+    "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_create_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph", "rkh_birrt_create_qs_batch", "rkh_birrt_destroy", "rkh_birrt_solve", "rkh_birrt_get_trees", "rkh_planner_get_solution", "rkh_rrtstar_get_solution", "rkh_birrt_get_solution",
 ]
 
 
@@ -522,15 +522,18 @@ class RrtPlannerPool:
 
 
 class RrtStarPlanner:
-    """rrtstar_planner (unidirectional, linear-search k-NN) over the quasi-static free space, batch of problems."""
+    """rrtstar_planner (unidirectional, linear-search k-NN), batch of problems; `space` is a quasi-static space
+    (make_qs_space: vertices = joint positions) or a steerable dynamic space (T.DynSpace: vertices = states (q, qd))."""
 
-    def __init__(self, scene, prm, qs):
-        self.scene, self.lib, self.qs = scene, scene.lib, qs
+    def __init__(self, scene, prm, space):
+        self.scene, self.lib, self.qs = scene, scene.lib, space
         self.prms = list(prm) if isinstance(prm, (list, tuple)) else [prm]
-        self.P, self.D = len(self.prms), qs.n_dof
+        dynamic = isinstance(space, T.DynSpace)
+        self.P, self.D = len(self.prms), (2 * space.n_dof if dynamic else space.n_dof)
         self._prm_arr = T.as_array(self.prms, T.RrtParams)
         self.h = C.c_void_p()
-        _check(self.lib.rkh_rrtstar_create_qs_batch(scene.h, C.byref(qs), self._prm_arr, self.P, C.byref(self.h)))
+        create = self.lib.rkh_rrtstar_create_batch if dynamic else self.lib.rkh_rrtstar_create_qs_batch
+        _check(create(scene.h, C.byref(space), self._prm_arr, self.P, C.byref(self.h)))
         self.all_stats = (RrtStarStats * self.P)()
 
     @property
@@ -571,15 +574,18 @@ class RrtStarPlanner:
 
 
 class PrmPlanner:
-    """prm_planner (linear-search k-NN, adjacency-list motion graph) over the quasi-static free space, batch of problems."""
+    """prm_planner (linear-search k-NN, adjacency-list motion graph), batch of problems; `space` is a quasi-static space
+    (make_qs_space) or a steerable dynamic space (T.DynSpace: vertices = states (q, qd))."""
 
-    def __init__(self, scene, prm, qs):
-        self.scene, self.lib, self.qs = scene, scene.lib, qs
+    def __init__(self, scene, prm, space):
+        self.scene, self.lib, self.qs = scene, scene.lib, space
         self.prms = list(prm) if isinstance(prm, (list, tuple)) else [prm]
-        self.P, self.D = len(self.prms), qs.n_dof
+        dynamic = isinstance(space, T.DynSpace)
+        self.P, self.D = len(self.prms), (2 * space.n_dof if dynamic else space.n_dof)
         self._prm_arr = T.as_array(self.prms, T.PrmParams)
         self.h = C.c_void_p()
-        _check(self.lib.rkh_prm_create_qs_batch(scene.h, C.byref(qs), self._prm_arr, self.P, C.byref(self.h)))
+        create = self.lib.rkh_prm_create_batch if dynamic else self.lib.rkh_prm_create_qs_batch
+        _check(create(scene.h, C.byref(space), self._prm_arr, self.P, C.byref(self.h)))
         self.all_stats = (PrmStats * self.P)()
 
     @property

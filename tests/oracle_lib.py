@@ -121,6 +121,8 @@ def load(fast=False):
     lib.orc_rrt_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtOut)]
     lib.orc_qs_move.argtypes = [C.c_void_p, C.c_int, dp, dp, d, dp, dp, C.c_int, d, dp, u32p]
     lib.orc_rrtstar_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtStarOut)]
+    lib.orc_prm_dyn.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), C.POINTER(T.PrmParams), C.c_int64, C.POINTER(PrmOut)]
+    lib.orc_rrtstar_dyn.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtStarOut)]
     lib.orc_rrtstar_copy.argtypes = [dp, u32p, dp, u32p]
     lib.orc_prm_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.PrmParams), C.c_int64, C.POINTER(PrmOut)]
     lib.orc_prm_copy.argtypes = [dp, u32p, u32p, dp, dp, u32p, C.POINTER(C.c_uint8), u32p]
@@ -225,6 +227,16 @@ class OracleScene:
         self.lib.orc_rrtstar_copy(T.dptr(pos), T.u32ptr(pred), T.dptr(dist), T.u32ptr(near))
         return rc, out, {"pos": pos, "pred": pred, "dist": dist, "near_seq": near[: int(out.loop_iterations)]}
 
+    def rrtstar_dyn(self, prm, max_loop_iterations=-1):
+        """RRT* over the scenario's steerable dynamic space (vertices = states)."""
+        out = RrtStarOut()
+        rc = self.lib.orc_rrtstar_dyn(self.h, C.byref(self.scn.dyn), C.byref(prm), int(max_loop_iterations), C.byref(out))
+        nv, D = int(out.num_vertices), 2 * self.scn.n_dof
+        pos = np.zeros((nv, D)); pred = np.zeros(nv, dtype=np.uint32); dist = np.zeros(nv)
+        near = np.zeros(max(int(out.loop_iterations), 1), dtype=np.uint32)
+        self.lib.orc_rrtstar_copy(T.dptr(pos), T.u32ptr(pred), T.dptr(dist), T.u32ptr(near))
+        return rc, out, {"pos": pos, "pred": pred, "dist": dist, "near_seq": near[: int(out.loop_iterations)]}
+
     def prm_qs(self, lower, upper, min_interval, prm, max_loop_iterations=-1):
         lower = np.ascontiguousarray(lower, dtype=np.float64)
         upper = np.ascontiguousarray(upper, dtype=np.float64)
@@ -232,6 +244,19 @@ class OracleScene:
         rc = self.lib.orc_prm_qs(self.h, len(lower), T.dptr(lower), T.dptr(upper), float(min_interval), C.byref(prm),
                                  int(max_loop_iterations), C.byref(out))
         nv, ne, it, D = int(out.num_vertices), int(out.num_edges), int(out.loop_iterations), len(lower)
+        pos = np.zeros((nv, D)); eu = np.zeros(max(ne, 1), dtype=np.uint32); ev = np.zeros(max(ne, 1), dtype=np.uint32)
+        ew = np.zeros(max(ne, 1)); dens = np.zeros(nv); cc = np.zeros(nv, dtype=np.uint32)
+        kind = np.zeros(max(it, 1), dtype=np.uint8); exp = np.zeros(max(it, 1), dtype=np.uint32)
+        self.lib.orc_prm_copy(T.dptr(pos), T.u32ptr(eu), T.u32ptr(ev), T.dptr(ew), T.dptr(dens), T.u32ptr(cc),
+                              kind.ctypes.data_as(C.POINTER(C.c_uint8)), T.u32ptr(exp))
+        return rc, out, {"pos": pos, "edge_u": eu[:ne], "edge_v": ev[:ne], "edge_w": ew[:ne], "density": dens,
+                         "cc_root": cc, "kind": kind[:it], "expanded": exp[:it]}
+
+    def prm_dyn(self, prm, max_loop_iterations=-1):
+        """PRM over the scenario's steerable dynamic space (vertices = states)."""
+        out = PrmOut()
+        rc = self.lib.orc_prm_dyn(self.h, C.byref(self.scn.dyn), C.byref(prm), int(max_loop_iterations), C.byref(out))
+        nv, ne, it, D = int(out.num_vertices), int(out.num_edges), int(out.loop_iterations), 2 * self.scn.n_dof
         pos = np.zeros((nv, D)); eu = np.zeros(max(ne, 1), dtype=np.uint32); ev = np.zeros(max(ne, 1), dtype=np.uint32)
         ew = np.zeros(max(ne, 1)); dens = np.zeros(nv); cc = np.zeros(nv, dtype=np.uint32)
         kind = np.zeros(max(it, 1), dtype=np.uint8); exp = np.zeros(max(it, 1), dtype=np.uint32)

@@ -396,6 +396,37 @@ def test_rrtstar_graph_identical_to_sequential_planner(L, ctx, oracle, seed):
     assert st.best_cost == rout.best_cost
 
 
+@pytest.mark.parametrize("seed,conn_tol,max_vertices", [(3, 3.0, 1000), (4, 0.05, 250)])
+def test_rrtstar_over_the_dynamic_space_identical_to_sequential_planner(L, ctx, oracle, c2, seed, conn_tol, max_vertices):
+    """RRT* whose vertices are states (q, qd) of the C2 chain and whose candidate edges -- expand_to_nearest from every
+    neighbour, can_be_connected in each direction -- are RK4 propagations with collision checks (the directed branch of
+    the connector; the space's metric is symmetric, so predecessor and successor neighbourhoods coincide).  A loose
+    connection tolerance makes rewiring happen; the reference's default (5 %) practically never connects two states."""
+    sc, osc = L.Scene(ctx, c2), oracle.OracleScene(c2)
+    prm = c2.rrt_params(seed=seed, max_vertices=max_vertices)
+    prm.conn_tol = conn_tol
+    rc, rout, rg = osc.rrtstar_dyn(prm)
+    assert rc == 0
+    pl = L.RrtStarPlanner(sc, prm, c2.dyn)
+    st = pl.solve_planning_query()
+    g = pl.graph()
+    assert (st.num_vertices, st.samples, st.loop_iterations, st.num_solutions, st.rewires, st.edges_checked) == (
+        rout.num_vertices, rout.samples, rout.loop_iterations, rout.num_solutions, rout.rewires, rout.edges_checked)
+    assert st.num_vertices == max_vertices + 2
+    if conn_tol > 1.0:
+        assert st.rewires > 20
+    assert np.array_equal(g["near_seq"], rg["near_seq"])
+    assert np.array_equal(g["pred"], rg["pred"])
+    # end states of the accepted propagations: fp64 to the tolerance of the dynamics tests (the device's sincos differs
+    # from libm's in the last place); the graph itself -- neighbours, predecessors, rewires, counts -- is identical
+    assert np.allclose(g["pos"], rg["pos"], rtol=STATE_RTOL, atol=1e-12)
+    fin = np.isfinite(rg["dist"])
+    assert np.array_equal(np.isfinite(g["dist"]), fin)
+    assert np.allclose(g["dist"][fin], rg["dist"][fin], rtol=10 * STATE_RTOL, atol=1e-12)
+    assert np.isclose(st.best_cost, rout.best_cost, rtol=10 * STATE_RTOL) or (np.isinf(st.best_cost) and np.isinf(rout.best_cost))
+    pl.close()
+
+
 def test_rrtstar_batch_of_seeds(L, ctx, oracle):
     c1 = scenarios.make_c1(world_seed=1)
     sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
@@ -420,6 +451,36 @@ def _prm_same(st, g, rout, rg):
     assert np.array_equal(g["edge_u"], rg["edge_u"]) and np.array_equal(g["edge_v"], rg["edge_v"])
     assert np.array_equal(g["edge_w"], rg["edge_w"])
     assert np.array_equal(g["density"], rg["density"]) and np.array_equal(g["cc_root"], rg["cc_root"])
+
+
+@pytest.mark.parametrize("seed,conn_tol,sampling_radius,max_vertices", [(3, 3.0, 1.0, 1000), (5, 0.05, 0.5, 200)])
+def test_prm_over_the_dynamic_space_identical_to_sequential_planner(L, ctx, oracle, c2, seed, conn_tol, sampling_radius,
+                                                                    max_vertices):
+    """PRM whose vertices are states (q, qd) of the C2 chain: is_free(state) rejection sampling, random walks that are
+    RK4 propagations over a fraction of the edge time, connections by full propagations.  Same loop decisions, vertices,
+    edges, components and expansion queue as the sequential planner; states to the tolerance of the dynamics tests."""
+    sc, osc = L.Scene(ctx, c2), oracle.OracleScene(c2)
+    prm = c2.prm_params(seed=seed, max_vertices=max_vertices, sampling_radius=sampling_radius)
+    prm.base.conn_tol = conn_tol
+    rc, rout, rg = osc.prm_dyn(prm)
+    assert rc == 0
+    pl = L.PrmPlanner(sc, prm, c2.dyn)
+    st = pl.solve_planning_query()
+    g = pl.graph()
+    assert (st.num_vertices, st.num_edges, st.samples, st.rejected, st.loop_iterations, st.num_components,
+            st.publish_calls, st.merged_at_vertex, st.edges_checked) == (
+        rout.num_vertices, rout.num_edges, rout.samples, rout.rejected, rout.loop_iterations, rout.num_components,
+        rout.publish_calls, rout.merged_at_vertex, rout.edges_checked)
+    assert st.num_vertices == max_vertices + 2 and np.bincount(g["kind"], minlength=3)[1] > 10   # walks did expand
+    if conn_tol > 1.0:
+        assert st.num_edges > 2 * max_vertices
+    assert np.array_equal(g["kind"], rg["kind"]) and np.array_equal(g["expanded"], rg["expanded"])
+    assert np.array_equal(g["edge_u"], rg["edge_u"]) and np.array_equal(g["edge_v"], rg["edge_v"])
+    assert np.array_equal(g["cc_root"], rg["cc_root"])
+    assert np.allclose(g["pos"], rg["pos"], rtol=STATE_RTOL, atol=1e-12)
+    assert np.allclose(g["edge_w"], rg["edge_w"], rtol=10 * STATE_RTOL, atol=1e-12)
+    assert np.allclose(g["density"], rg["density"], rtol=1e-8, atol=1e-12)
+    pl.close()
 
 
 @pytest.mark.parametrize("seed", [1, 2])
