@@ -66,6 +66,14 @@ rkh_status rkh_nn_create(rkh_ctx* ctx, int dims, uint64_t capacity, rkh_nn** out
 rkh_status rkh_nn_destroy(rkh_nn* nn);
 rkh_status rkh_nn_clear(rkh_nn* nn);
 uint64_t rkh_nn_size(const rkh_nn* nn);
+/* any_knn_synchro::removed_vertex (ctrl/path_planning/any_knn_synchro.hpp:77-84; called from
+ * planning_visitor_base::vertex_to_be_removed, planning_visitors.hpp:213-216): vertex `index` is never returned by a
+ * query again.  The store stays append-only -- indices of the other vertices do not change and rkh_nn_size still counts
+ * the row -- and the row itself is overwritten with +inf coordinates: every sweep then computes an infinite distance for
+ * it, which no comparison of the reference accepts (d < radius, d < best), at no extra bytes per sweep (a separate n/8
+ * mask would add a read per row).  Removing a vertex twice is allowed.  rkh_nn_live_size counts the vertices left. */
+rkh_status rkh_nn_remove(rkh_nn* nn, uint64_t index);
+uint64_t rkh_nn_live_size(const rkh_nn* nn);
 /* pts: n points, row-major [n][dims] */
 rkh_status rkh_nn_append(rkh_nn* nn, const double* pts, uint64_t n);
 /* q: [B][dims]; idx[B] (0xFFFFFFFF if the set is empty), dist[B] */

@@ -135,11 +135,13 @@ struct hip_knn_synchro {
     const auto& p = get(position, u);
     check(rkh_nn_append(nn.get(), &p[0], 1));
   }
+  // The device store is append-only with tombstones: row numbers = order of the added_vertex calls, so the graph's
+  // vertex descriptor must convert to that number (vecS / pooled vertex lists: the descriptor is the index; a graph
+  // that re-uses the holes of removed vertices has to map descriptors to insertion numbers in `index_of`).
   template <typename Vertex>
-  void removed_vertex(Vertex, Graph&) const {
-    // The append-only device store has no tombstones yet; only branch-and-bound pruning removes vertices
-    // (branch_and_bound_connector.hpp), which is not on the HIP path.
-    throw unsupported_error("hip_knn_synchro: vertex removal is not supported by the device NN store");
+  void removed_vertex(Vertex u, Graph& g) const {
+    (void)g;
+    check(rkh_nn_remove(nn.get(), static_cast<uint64_t>(u)));
   }
 };
 

@@ -462,6 +462,48 @@ void orc_rrtstar_copy(double* pos, uint32_t* pred, double* dist, uint32_t* near_
   if (near_seq) std::memcpy(near_seq, g_last_star.near_seq.data(), g_last_star.near_seq.size() * sizeof(uint32_t));
 }
 
+// ---- bidirectional RRT* over the quasi-static free space
+struct OrcBiRrtStarOut {
+  uint64_t num_vertices, samples, loop_iterations, rewires, fwd_rewires, joins, edges_checked, states_checked;
+  double best_join_cost, seconds;
+};
+static BiRrtStarResult g_last_bistar;
+int orc_birrtstar_qs(void* h, int D, const double* lower, const double* upper, double min_interval,
+                     const rkh_rrt_params* prm, int64_t max_loop_iterations, OrcBiRrtStarOut* out) {
+  Scene* s = static_cast<Scene*>(h);
+  QuasiStaticSpace sp;
+  sp.D = D;
+  sp.lower.assign(lower, lower + D);
+  sp.upper.assign(upper, upper + D);
+  sp.min_interval = min_interval;
+  sp.chain = s->chain;
+  sp.env = s->env;
+  auto t0 = std::chrono::steady_clock::now();
+  generate_rrt_star_bidir(sp, *prm, long(max_loop_iterations), g_last_bistar);
+  out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  out->num_vertices = g_last_bistar.pred.size();
+  out->samples = g_last_bistar.samples;
+  out->loop_iterations = g_last_bistar.loop_iterations;
+  out->rewires = g_last_bistar.rewires;
+  out->fwd_rewires = g_last_bistar.fwd_rewires;
+  out->joins = g_last_bistar.joins;
+  out->edges_checked = g_last_bistar.cnt.edges_checked;
+  out->states_checked = g_last_bistar.cnt.states_checked;
+  out->best_join_cost = g_last_bistar.best_join_cost;
+  return 0;
+}
+void orc_birrtstar_copy(double* pos, uint32_t* pred, double* dist, uint32_t* succ, double* fwd_dist, uint32_t* near_pred,
+                        uint32_t* near_succ) {
+  const BiRrtStarResult& r = g_last_bistar;
+  if (pos) std::memcpy(pos, r.pos.data(), r.pos.size() * sizeof(double));
+  if (pred) std::memcpy(pred, r.pred.data(), r.pred.size() * sizeof(uint32_t));
+  if (dist) std::memcpy(dist, r.dist.data(), r.dist.size() * sizeof(double));
+  if (succ) std::memcpy(succ, r.succ.data(), r.succ.size() * sizeof(uint32_t));
+  if (fwd_dist) std::memcpy(fwd_dist, r.fwd_dist.data(), r.fwd_dist.size() * sizeof(double));
+  if (near_pred) std::memcpy(near_pred, r.near_pred.data(), r.near_pred.size() * sizeof(uint32_t));
+  if (near_succ) std::memcpy(near_succ, r.near_succ.data(), r.near_succ.size() * sizeof(uint32_t));
+}
+
 // ---- PRM over the quasi-static free space
 struct OrcPrmOut {
   uint64_t num_vertices, num_edges, samples, rejected, loop_iterations, num_components, publish_calls;

@@ -199,6 +199,38 @@ struct QuasiStaticSpace {
     p_result = move_position_toward(src, fraction, dest);
     return metric(src, p_result);
   }
+  // vector_topology::move_position_back_to: b + (a - b) * fraction (vector_topology.hpp:115-118)
+  Point lin_move_back(const Point& a, double fraction, const Point& b) const {
+    Point r(D);
+    for (int i = 0; i < D; ++i) r[i] = b[i] + (a[i] - b[i]) * fraction;
+    return r;
+  }
+  // interp_topo_move_position_back_to_pred: interpolated_topologies.hpp:165-191 -- the walk starts at b and moves
+  // towards a.  Kept as written: a walk that completes with fraction == 1.0 returns b, its own starting point (:185-186).
+  Point move_position_back_to(const Point& a, double fraction, const Point& b) {
+    ++cnt.edges_checked;
+    double dist_tot = metric(a, b);
+    if (dist_tot == std::numeric_limits<double>::infinity()) return b;
+    if (dist_tot < min_interval) return lin_move_back(a, fraction, b);
+    double dist_inter = dist_tot * fraction;
+    double dist_cur = min_interval;
+    Point result = b;
+    Point last_result = b;
+    while (dist_cur < dist_inter) {
+      result = lin_move_back(a, dist_cur / dist_tot, b);
+      if (!is_free(result)) return last_result;
+      dist_cur += min_interval;
+      last_result = result;
+    }
+    if (fraction == 1.0) return b;
+    else if (fraction == 0.0) return a;
+    return lin_move_back(a, fraction, b);
+  }
+  // planning_visitor_base::dispatched_steer_back_to_position case 2 (planning_visitors.hpp:311-320)
+  double steer_back(const Point& src, const Point& dest, double fraction, Point& p_result) {
+    p_result = move_position_back_to(src, fraction, dest);
+    return metric(p_result, dest);
+  }
 };
 
 // runge_kutta4_integrate_impl: ctrl/sys_integrators/runge_kutta4_integrator_sys.hpp:53-97 with a
@@ -547,6 +579,262 @@ void generate_rrt_star(Space& space, const rkh_rrt_params& prm, long max_loop_it
         }
       }
     }
+  }
+  res.cnt = space.cnt;
+}
+
+}  // namespace oracle
+
+// --------------------------------------------------------------------------------------------
+// Bidirectional RRT* (undirected motion graph): generate_rrt_star_bidir (ctrl/graph_alg/rrt_star.hpp:612-659) ->
+// generate_rrt_star_bidir_loop (:197-236) with rrg_bidir_generator (node_generators.hpp:215-277: expand_to_nearest
+// over the neighbours that have a predecessor, retract_from_nearest over those that have a successor, :84-118) and the
+// bidirectional lazy_node_connector::operator() (lazy_connector.hpp:465-518: connect_best_predecessor :79-123,
+// connect_best_successor :125-168, create_pred_edge / create_succ_edge pruned_connector.hpp:366-404,
+// connect_successors :230-275, update_successors, connect_predecessors :170-227, update_predecessors :338-360).
+//
+// Reference behaviour kept: (1) the goal vertex has a successor (itself), so connect_successors never gives it a
+// predecessor, and vertex_added's solution test (goal.predecessor != null, planning_visitors.hpp:108-116) never fires:
+// no solution is registered, the graph grows to max_vertex_count; a vertex with both a predecessor and a successor
+// ("joining vertex") is reported here as `joins` / best_join_cost = distance + fwd_distance.  (2) a walk back
+// (move_position_back_to) that completes returns its own starting point, so retract_from_nearest only succeeds on walks
+// cut short by an obstacle.  Defined here where the reference reads indeterminate memory: the start vertex's successor /
+// fwd_distance_accum (bidir_optimal_mg_vertex has no constructor, any_motion_graphs.hpp:255-261) are null / infinity.
+// Not modelled: two parallel edges between the same pair of vertices (a predecessor edge and a successor edge), which
+// BGL's remove_edge(u, v) / incident-edge loops would treat as one pair.
+namespace oracle {
+
+struct BiRrtStarResult {
+  int D = 0;
+  std::vector<double> pos;
+  std::vector<uint32_t> pred, succ;       // 0xFFFFFFFF = none
+  std::vector<double> dist, fwd_dist;     // distance_accum, fwd_distance_accum
+  std::vector<double> weight, fwd_weight; // weight of the edge (pred -> v) / (v -> succ)
+  std::vector<uint32_t> near_pred, near_succ;  // per loop iteration: x_pred / x_succ of the node generator
+  long samples = 0, loop_iterations = 0, rewires = 0, fwd_rewires = 0, joins = 0;
+  double best_join_cost = std::numeric_limits<double>::infinity();
+  SpaceCounters cnt;
+};
+
+template <typename Space>
+void generate_rrt_star_bidir(Space& space, const rkh_rrt_params& prm, long max_loop_iterations, BiRrtStarResult& res) {
+  const int D = space.D;
+  const uint32_t NIL = 0xFFFFFFFFu;
+  const double inf = std::numeric_limits<double>::infinity();
+  GlobalRng rng(prm.seed);
+  res = BiRrtStarResult();
+  res.D = D;
+  Point start(prm.start, prm.start + D), goal(prm.goal, prm.goal + D);
+  std::vector<std::vector<uint32_t>> children, parents;  // incident edges by role: v's predecessor-children / successor-parents
+  auto add_vertex = [&](const Point& p) {
+    res.pos.insert(res.pos.end(), p.begin(), p.end());
+    res.dist.push_back(inf);
+    res.pred.push_back(NIL);
+    res.fwd_dist.push_back(inf);
+    res.succ.push_back(NIL);
+    res.weight.push_back(0.0);
+    res.fwd_weight.push_back(0.0);
+    children.emplace_back();
+    parents.emplace_back();
+    return uint32_t(res.pred.size() - 1);
+  };
+  auto P = [&](uint32_t v) { return Point(res.pos.begin() + std::size_t(v) * D, res.pos.begin() + std::size_t(v + 1) * D); };
+  add_vertex(start);
+  add_vertex(goal);
+  res.dist[0] = 0.0;      // rrt_star.hpp:647-652
+  res.pred[0] = 0;
+  res.fwd_dist[1] = 0.0;
+  res.succ[1] = 1;
+  const double space_dim = double(D);
+  const double gamma = 3.0 * space.metric(start, goal);
+  unsigned long m_iteration_count = 0;
+  auto keep_going = [&]() { return (m_iteration_count < prm.max_vertices) && (prm.max_results > 0ul); };
+  std::vector<std::pair<double, std::size_t>> nc;
+  auto select_neighborhood = [&](const Point& p, std::vector<uint32_t>& out) {
+    std::size_t k;
+    double radius;
+    star_neighborhood(res.pred.size(), space_dim, gamma, &k, &radius);
+    linear_knn(p.data(), res.pos.data(), res.pred.size(), D, k, radius, nc);
+    out.clear();
+    for (auto& e : nc) out.push_back(uint32_t(e.second));
+  };
+  auto can_be_connected = [&](uint32_t u, uint32_t v, double* w) {  // planning_visitors.hpp:385-395
+    Point p_result;
+    Point pu = P(u), pv = P(v);
+    double traveled = space.steer(pu, pv, 1.0, p_result);
+    double remaining = space.metric(p_result, pv);
+    *w = traveled;
+    return (!std::isinf(traveled)) && (remaining < prm.conn_tol * traveled);
+  };
+  std::vector<uint32_t> Nc;
+  // lazy_node_connector::operator() (lazy_connector.hpp:465-518)
+  auto connect_vertex = [&](const Point& p, uint32_t x_pred, double ep_pred, uint32_t x_succ, double ep_succ) {
+    select_neighborhood(p, Nc);
+    uint32_t v = add_vertex(p);  // rrt_conn_visitor::create_vertex (rrt_star.hpp:112-128)
+    ++m_iteration_count;         // vis.vertex_added -> report_progress
+    {  // connect_best_predecessor (:79-123)
+      const uint32_t orig = x_pred;
+      double d_near = inf;
+      if (x_pred != NIL) d_near = res.dist[x_pred] + ep_pred;
+      for (uint32_t u : Nc) {
+        if (u == orig || res.pred[u] == NIL) continue;
+        double d_out = space.metric(P(u), P(v)) + res.dist[u];
+        if (d_out < d_near) {
+          double w;
+          if (can_be_connected(u, v, &w)) {
+            x_pred = u;
+            d_near = d_out;
+            ep_pred = w;
+          }
+        }
+      }
+    }
+    {  // connect_best_successor (:125-168)
+      const uint32_t orig = x_succ;
+      double d_near = inf;
+      if (x_succ != NIL) d_near = res.fwd_dist[x_succ] + ep_succ;
+      for (uint32_t u : Nc) {
+        if (u == orig || res.succ[u] == NIL) continue;
+        double d_in = space.metric(P(v), P(u)) + res.fwd_dist[u];
+        if (d_in < d_near) {
+          double w;
+          if (can_be_connected(v, u, &w)) {
+            x_succ = u;
+            d_near = d_in;
+            ep_succ = w;
+          }
+        }
+      }
+    }
+    if (x_pred == NIL && x_succ == NIL) return;  // (the vertex would be removed; unreachable from the loop below)
+    if (x_pred != NIL) {  // create_pred_edge
+      res.dist[v] = ep_pred + res.dist[x_pred];
+      res.pred[v] = x_pred;
+      res.weight[v] = ep_pred;
+      children[x_pred].push_back(v);
+    }
+    if (x_succ != NIL) {  // create_succ_edge
+      res.fwd_dist[v] = ep_succ + res.fwd_dist[x_succ];
+      res.succ[v] = x_succ;
+      res.fwd_weight[v] = ep_succ;
+      parents[x_succ].push_back(v);
+    }
+    if (res.pred[v] != NIL && res.succ[v] != NIL) {
+      ++res.joins;
+      if (res.dist[v] + res.fwd_dist[v] < res.best_join_cost) res.best_join_cost = res.dist[v] + res.fwd_dist[v];
+    }
+    // connect_successors (:230-275, with the successor map: vertices of the backward tree are left alone)
+    for (uint32_t u : Nc) {
+      if (u == x_pred || res.succ[u] != NIL) continue;
+      double d_in = space.metric(P(v), P(u)) + res.dist[v];
+      if (d_in < res.dist[u]) {
+        double w;
+        if (can_be_connected(v, u, &w)) {
+          res.dist[u] = d_in;
+          uint32_t old_pred = res.pred[u];
+          res.pred[u] = v;
+          res.weight[u] = w;
+          children[v].push_back(u);
+          if (old_pred != u && old_pred != NIL) {
+            auto& ch = children[old_pred];
+            ch.erase(std::find(ch.begin(), ch.end(), u));
+          }
+          ++res.rewires;
+        }
+      }
+    }
+    {  // update_successors (pruned_connector.hpp:310-332)
+      std::vector<uint32_t> incons(1, v);
+      while (!incons.empty()) {
+        uint32_t s = incons.back();
+        incons.pop_back();
+        for (uint32_t t : children[s]) {
+          if (res.pred[t] != s) continue;
+          res.dist[t] = res.dist[s] + res.weight[t];
+          incons.push_back(t);
+        }
+      }
+    }
+    // connect_predecessors (:170-227, with the predecessor map: vertices of the forward tree are left alone)
+    for (uint32_t u : Nc) {
+      if (u == x_succ || res.pred[u] != NIL) continue;
+      double d_in = space.metric(P(u), P(v)) + res.fwd_dist[v];
+      if (d_in < res.fwd_dist[u]) {
+        double w;
+        if (can_be_connected(u, v, &w)) {
+          res.fwd_dist[u] = d_in;
+          uint32_t old_succ = res.succ[u];
+          res.succ[u] = v;
+          res.fwd_weight[u] = w;
+          parents[v].push_back(u);
+          if (old_succ != u && old_succ != NIL) {
+            auto& pa = parents[old_succ];
+            pa.erase(std::find(pa.begin(), pa.end(), u));
+          }
+          ++res.fwd_rewires;
+        }
+      }
+    }
+    {  // update_predecessors (pruned_connector.hpp:338-360)
+      std::vector<uint32_t> incons(1, v);
+      while (!incons.empty()) {
+        uint32_t t = incons.back();
+        incons.pop_back();
+        for (uint32_t s : parents[t]) {
+          if (res.succ[s] != t) continue;
+          res.fwd_dist[s] = res.fwd_dist[t] + res.fwd_weight[s];
+          incons.push_back(s);
+        }
+      }
+    }
+  };
+  while (keep_going() && (max_loop_iterations < 0 || res.loop_iterations < max_loop_iterations)) {
+    ++res.loop_iterations;
+    // ---- rrg_bidir_generator (node_generators.hpp:244-277)
+    Point p_pred, p_succ;
+    uint32_t x_pred = NIL, x_succ = NIL;
+    double ep_pred = 0.0, ep_succ = 0.0;
+    for (std::size_t i = 0;; ++i) {
+      p_pred = space.random_point(rng);
+      ++res.samples;
+      p_succ = p_pred;
+      select_neighborhood(p_pred, Nc);
+      bool was_expanded = false, was_retracted = false;
+      x_pred = NIL;
+      x_succ = NIL;
+      for (uint32_t u : Nc) {  // expand_to_nearest (:84-100)
+        if (res.pred[u] == NIL) continue;
+        Point pu = P(u), p_tmp;
+        double traveled = space.steer(pu, p_pred, 1.0, p_tmp);
+        double best_case = space.metric(pu, p_pred);
+        if ((!std::isinf(traveled)) && (traveled < 2.0 * best_case) && (traveled > prm.steer_tol * best_case)) {
+          p_pred = p_tmp;
+          x_pred = u;
+          ep_pred = traveled;
+          was_expanded = true;
+          break;
+        }
+      }
+      for (uint32_t u : Nc) {  // retract_from_nearest (:102-118); steer_back_to_position planning_visitors.hpp:367-378
+        if (res.succ[u] == NIL) continue;
+        Point pu = P(u), p_tmp;
+        double traveled = space.steer_back(p_succ, pu, 1.0, p_tmp);
+        double best_case = space.metric(p_succ, pu);
+        if ((!std::isinf(traveled)) && (traveled < 2.0 * best_case) && (traveled > prm.steer_tol * best_case)) {
+          p_succ = p_tmp;
+          x_succ = u;
+          ep_succ = traveled;
+          was_retracted = true;
+          break;
+        }
+      }
+      if (was_expanded || was_retracted) break;
+      if (i >= 10) { x_pred = NIL; x_succ = NIL; break; }
+    }
+    res.near_pred.push_back(x_pred);
+    res.near_succ.push_back(x_succ);
+    if (x_pred != NIL) connect_vertex(p_pred, x_pred, ep_pred, NIL, 0.0);
+    if (x_succ != NIL) connect_vertex(p_succ, NIL, 0.0, x_succ, ep_succ);
   }
   res.cnt = space.cnt;
 }

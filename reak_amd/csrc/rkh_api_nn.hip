@@ -84,9 +84,31 @@ rkh_status rkh_nn_clear(rkh_nn* nn) {
   if (!nn) return RKH_ERR_BAD_ARG;
   nn->n = 0;
   nn->max_abs_coord = 0.0;
+  nn->removed.clear();
+  nn->n_removed = 0;
   return RKH_OK;
 }
 uint64_t rkh_nn_size(const rkh_nn* nn) { return nn ? nn->n : 0; }
+uint64_t rkh_nn_live_size(const rkh_nn* nn) { return nn ? nn->n - nn->n_removed : 0; }
+
+rkh_status rkh_nn_remove(rkh_nn* nn, uint64_t index) {
+  if (!nn) return RKH_ERR_BAD_ARG;
+  if (index >= nn->n) {
+    set_error("rkh_nn_remove: no such vertex");
+    return RKH_ERR_BAD_ARG;
+  }
+  if (nn->removed.size() < nn->n) nn->removed.resize(nn->n, 0);
+  if (nn->removed[index]) return RKH_OK;
+  const int DP = nn_padded_dims(nn->st.D);
+  double row[64];
+  for (int d = 0; d < DP; ++d) row[d] = INFINITY;  // the padding columns too: rows past the end look the same to a sweep
+  hipStream_t s = nn->ctx->stream;
+  RKH_HIP(hipMemcpyAsync(nn->st.d_pos + index * DP, row, DP * sizeof(double), hipMemcpyHostToDevice, s));
+  RKH_HIP(hipStreamSynchronize(s));
+  nn->removed[index] = 1;
+  ++nn->n_removed;
+  return RKH_OK;
+}
 
 rkh_status rkh_nn_append(rkh_nn* nn, const double* pts, uint64_t n) {
   if (!nn || (!pts && n)) return RKH_ERR_BAD_ARG;

@@ -181,6 +181,8 @@ struct rkh_nn {
   uint32_t* d_seed = nullptr;  // NnArgs::seed
   uint32_t seed_cap = 0;
   double max_abs_coord = 0.0;  // over the rows appended from the host (checked against coord_bound)
+  std::vector<uint8_t> removed;  // tombstones (host copy; the device row of a removed vertex holds +inf)
+  uint64_t n_removed = 0;
   uint32_t part_blocks = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // one-shot: bracket the next sweep kernel
   void* d_knn_ws = nullptr;  // k-NN workspace

@@ -66,7 +66,7 @@ class PlannerStats(C.Structure):
 
 EXPORTS = [
     "rkh_last_error", "rkh_version", "rkh_ctx_create", "rkh_ctx_destroy", "rkh_ctx_synchronize", "rkh_ctx_stream",
-    "rkh_nn_create", "rkh_nn_destroy", "rkh_nn_clear", "rkh_nn_size", "rkh_nn_append", "rkh_nn_query1",
+    "rkh_nn_create", "rkh_nn_destroy", "rkh_nn_clear", "rkh_nn_size", "rkh_nn_remove", "rkh_nn_live_size", "rkh_nn_append", "rkh_nn_query1",
     "rkh_nn_queryk", "rkh_nn_query1_async", "rkh_nn_queryk_async", "rkh_nn_fill_uniform", "rkh_nn_kernel_name",
     "rkh_nn_set_coord_bound",
     "rkh_scene_create", "rkh_scene_create_with_meshes", "rkh_diag_gjk_distance", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
@@ -108,6 +108,9 @@ def load():
     lib.rkh_nn_clear.argtypes = [vp]
     lib.rkh_nn_size.restype = u64
     lib.rkh_nn_size.argtypes = [vp]
+    lib.rkh_nn_remove.argtypes = [vp, u64]
+    lib.rkh_nn_live_size.restype = u64
+    lib.rkh_nn_live_size.argtypes = [vp]
     lib.rkh_nn_append.argtypes = [vp, dp, u64]
     lib.rkh_nn_query1.argtypes = [vp, dp, u32, u32p, dp]
     lib.rkh_nn_queryk.argtypes = [vp, dp, u32, u32, d, u32p, dp, u32p]
@@ -212,6 +215,12 @@ class HipNeighborSearch:
     def added_vertices(self, pts):
         pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, self.D)
         _check(self.lib.rkh_nn_append(self.h, T.dptr(pts), pts.shape[0]))
+
+    def removed_vertex(self, index):
+        _check(self.lib.rkh_nn_remove(self.h, int(index)))
+
+    def live_size(self):
+        return int(self.lib.rkh_nn_live_size(self.h))
 
     def clear(self):
         _check(self.lib.rkh_nn_clear(self.h))

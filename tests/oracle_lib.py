@@ -32,6 +32,12 @@ class RrtStarOut(C.Structure):
                 ("states_checked", C.c_uint64), ("best_cost", C.c_double), ("seconds", C.c_double)]
 
 
+class BiRrtStarOut(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint64), ("samples", C.c_uint64), ("loop_iterations", C.c_uint64),
+                ("rewires", C.c_uint64), ("fwd_rewires", C.c_uint64), ("joins", C.c_uint64), ("edges_checked", C.c_uint64),
+                ("states_checked", C.c_uint64), ("best_join_cost", C.c_double), ("seconds", C.c_double)]
+
+
 class PrmOut(C.Structure):
     _fields_ = [("num_vertices", C.c_uint64), ("num_edges", C.c_uint64), ("samples", C.c_uint64),
                 ("rejected", C.c_uint64), ("loop_iterations", C.c_uint64), ("num_components", C.c_uint64),
@@ -121,6 +127,8 @@ def load(fast=False):
     lib.orc_rrt_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtOut)]
     lib.orc_qs_move.argtypes = [C.c_void_p, C.c_int, dp, dp, d, dp, dp, C.c_int, d, dp, u32p]
     lib.orc_rrtstar_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtStarOut)]
+    lib.orc_birrtstar_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(BiRrtStarOut)]
+    lib.orc_birrtstar_copy.argtypes = [dp, u32p, dp, u32p, dp, u32p, u32p]
     lib.orc_prm_dyn.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), C.POINTER(T.PrmParams), C.c_int64, C.POINTER(PrmOut)]
     lib.orc_rrtstar_dyn.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtStarOut)]
     lib.orc_rrtstar_copy.argtypes = [dp, u32p, dp, u32p]
@@ -251,6 +259,23 @@ class OracleScene:
                               kind.ctypes.data_as(C.POINTER(C.c_uint8)), T.u32ptr(exp))
         return rc, out, {"pos": pos, "edge_u": eu[:ne], "edge_v": ev[:ne], "edge_w": ew[:ne], "density": dens,
                          "cc_root": cc, "kind": kind[:it], "expanded": exp[:it]}
+
+    def birrtstar_qs(self, lower, upper, min_interval, prm, max_loop_iterations=-1):
+        """Bidirectional RRT* over the quasi-static space."""
+        lower = np.ascontiguousarray(lower, dtype=np.float64)
+        upper = np.ascontiguousarray(upper, dtype=np.float64)
+        out = BiRrtStarOut()
+        rc = self.lib.orc_birrtstar_qs(self.h, len(lower), T.dptr(lower), T.dptr(upper), float(min_interval), C.byref(prm),
+                                       int(max_loop_iterations), C.byref(out))
+        nv, D, it = int(out.num_vertices), len(lower), max(int(out.loop_iterations), 1)
+        pos = np.zeros((nv, D)); pred = np.zeros(nv, dtype=np.uint32); dist = np.zeros(nv)
+        succ = np.zeros(nv, dtype=np.uint32); fwd = np.zeros(nv)
+        npred = np.zeros(it, dtype=np.uint32); nsucc = np.zeros(it, dtype=np.uint32)
+        self.lib.orc_birrtstar_copy(T.dptr(pos), T.u32ptr(pred), T.dptr(dist), T.u32ptr(succ), T.dptr(fwd), T.u32ptr(npred),
+                                    T.u32ptr(nsucc))
+        n = int(out.loop_iterations)
+        return rc, out, {"pos": pos, "pred": pred, "dist": dist, "succ": succ, "fwd_dist": fwd, "near_pred": npred[:n],
+                         "near_succ": nsucc[:n]}
 
     def prm_dyn(self, prm, max_loop_iterations=-1):
         """PRM over the scenario's steerable dynamic space (vertices = states)."""

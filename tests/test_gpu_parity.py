@@ -101,6 +101,50 @@ def test_coordinate_bound_is_checked_where_the_library_holds_the_data(L, ctx):
     assert np.all(idx < 1000)
 
 
+@pytest.mark.parametrize("D,n,bound", [(12, 40000, 0.0), (12, 40000, 3.0), (6, 3000, 3.0), (3, 900, 0.0)])
+def test_removed_vertices_are_never_returned(L, ctx, oracle, D, n, bound):
+    """any_knn_synchro::removed_vertex: tombstoned rows keep their index and vanish from every sweep (register-direct,
+    tiled fp64, packed-fp32 and matrix-core 1-NN; k-NN with radius).  Checked against the oracle's linear search over the
+    remaining vertices, indices mapped back."""
+    rng = np.random.default_rng(31 + D + n)
+    pts = rng.uniform(-3, 3, size=(n, D))
+    nn = L.HipNeighborSearch(ctx, D, n)
+    nn.added_vertices(pts)
+    if bound > 0.0:
+        nn.set_coord_bound(bound)
+    queries = {B: rng.uniform(-3, 3, size=(B, D)) for B in (5, 20, 48, 200)}
+    dead = np.zeros(n, dtype=bool)
+    for B, q in queries.items():     # remove the current nearest neighbour of every query, and a random tenth of the rest
+        idx, _ = nn.nearest(q)
+        dead[idx] = True
+    dead[rng.choice(n, size=n // 10, replace=False)] = True
+    dead[n - 1] = True               # the last row
+    dead[:300] = True                # a whole tile and more
+    for i in np.flatnonzero(dead):
+        nn.removed_vertex(i)
+    nn.removed_vertex(int(np.flatnonzero(dead)[0]))   # twice: allowed
+    assert len(nn) == n and nn.live_size() == n - dead.sum()
+    live = np.flatnonzero(~dead)
+    for B, q in queries.items():
+        idx, dist = nn.nearest(q)
+        ridx, rdist = oracle.nn1(q, pts[live])
+        assert np.array_equal(idx, live[ridx]) and np.array_equal(dist, rdist)
+    q = queries[20]
+    kidx, kdist, kcnt = nn.k_nearest(q, 24, radius=2.5 if D > 3 else 0.4)
+    ridx, rdist, rcnt = oracle.knn(q, pts[live], 24, radius=2.5 if D > 3 else 0.4)
+    assert np.array_equal(kcnt, rcnt)
+    for b in range(len(q)):
+        c = int(kcnt[b])
+        assert np.array_equal(np.sort(kidx[b, :c]), np.sort(live[ridx[b, :c]])) and np.array_equal(kdist[b, :c], rdist[b, :c])
+    with pytest.raises(L.RkhError):
+        nn.removed_vertex(n)         # no such vertex
+    # rows appended after removals take new indices; a cleared store forgets its tombstones
+    nn.clear()
+    nn.added_vertices(pts[:10])
+    idx, _ = nn.nearest(pts[:10])
+    assert np.array_equal(idx, np.arange(10))
+
+
 def test_nn1_ties_first_minimum_wins(L, ctx, oracle):
     rng = np.random.default_rng(7)
     base = rng.uniform(-1, 1, size=(500, 12))
