@@ -217,6 +217,26 @@ rkh_status rkh_rrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_rr
  * near_seq[loop_iterations] (x_near returned by the node generator).  Any pointer may be NULL. */
 rkh_status rkh_rrtstar_get_graph(rkh_rrtstar* p, uint32_t problem, double* pos, uint32_t* pred, double* dist,
                                  uint32_t* near_seq);
+/* ---- bidirectional RRT*: generate_rrt_star_bidir (ctrl/graph_alg/rrt_star.hpp:197-236,612-659) with rrg_bidir_generator
+ * (node_generators.hpp:215-277) and the bidirectional lazy_node_connector (lazy_connector.hpp:465-518), over the
+ * quasi-static free space (the reference requires a reversible space, rrtstar_path_planner.tpp:70).  Every vertex
+ * carries a predecessor / distance_accum towards the start (forward tree, root = vertex 0) and a successor /
+ * fwd_distance_accum towards the goal (backward tree, root = vertex 1).  As in the reference, no solution is ever
+ * registered: the goal has a successor (itself), so connect_successors never gives it a predecessor, which is what
+ * vertex_added tests (planning_visitors.hpp:108-116); the graph grows to max_vertices.  Vertices that end up with both
+ * links are counted (`joins`, best_join_cost = distance_accum + fwd_distance_accum).  A loop iteration can add two
+ * vertices, so the graph may hold max_vertices + 3.  The handle type is rkh_rrtstar; rkh_rrtstar_destroy frees it. */
+typedef struct rkh_birrtstar_stats {
+  uint64_t num_vertices, samples, loop_iterations, rewires, fwd_rewires, joins, edges_checked;
+  double best_join_cost;
+} rkh_birrtstar_stats;
+rkh_status rkh_birrtstar_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_rrt_params* prms,
+                                         uint32_t n_problems, rkh_rrtstar** out);
+rkh_status rkh_birrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_birrtstar_stats* stats);
+/* pos [num_vertices][n_dof]; pred / succ (0xFFFFFFFF = none); dist / fwd_dist; near_pred / near_succ [loop_iterations]:
+ * the generator's x_pred / x_succ.  Any pointer may be NULL. */
+rkh_status rkh_birrtstar_get_graph(rkh_rrtstar* p, uint32_t problem, double* pos, uint32_t* pred, double* dist, uint32_t* succ,
+                                   double* fwd_dist, uint32_t* near_pred, uint32_t* near_succ);
 /* ---- PRM: prm_planner::solve_planning_query (LINEAR_SEARCH_KNN, ADJ_LIST_MOTION_GRAPH, undirected graph) ----
  * (ctrl/path_planning/prm_path_planner.tpp:131-365 -> generate_prm, ctrl/graph_alg/probabilistic_roadmap.hpp:211-249,
  * 309-404; prm_node_connector prm_connector.hpp:68-182; prm_conn_visitor probabilistic_roadmap.hpp:75-196;

@@ -13,6 +13,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -155,6 +157,10 @@ struct GraphBatch {
          off_aaccept = 0, off_axout = 0;
   bool any_knn = false, any_edges = false, any_append = false, any_stage_a = false;
   uint64_t steps = 0;
+  std::vector<uint32_t> knn_k;       // per problem: k, n and radius of the last cmd_knn
+  std::vector<uint64_t> knn_n;
+  std::vector<double> knn_radius;
+  uint64_t tie_replays = 0;
 
   // the steerable dynamic free space: vertices are states (q, qd), edges steer_position_toward (planner.hip's space)
   rkh_status init_dynamic(rkh_scene* sc, const rkh_dyn_space* space, uint32_t n_problems, const uint64_t* capacities,
@@ -186,8 +192,11 @@ struct GraphBatch {
     D = D_;
     DP = nn_padded_dims(D);
     P = n_problems;
-    kmax = kmax_;
-    emax = 2 * kmax_;
+    kmax = kmax_ + 1;  // one neighbour more than asked for: a tie across the k-th place must be visible (neighbours())
+    emax = 2 * kmax;
+    knn_k.assign(P, 0);
+    knn_n.assign(P, 0);
+    knn_radius.assign(P, 0.0);
     RKH_HIP(hipSetDevice(sc->ctx->device));
     RKH_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     cmd_bytes = size_t(P) * (sizeof(KnnArgs) + 2 * sizeof(EdgeIO) + sizeof(GbAux));
@@ -260,6 +269,103 @@ struct GraphBatch {
   uint32_t selected(uint32_t i) const { return reinterpret_cast<const uint32_t*>(hres(i))[3]; }
   const uint8_t* a_accept(uint32_t i) const { return hres(i) + off_aaccept; }
   const double* a_x_out(uint32_t i) const { return reinterpret_cast<const double*>(hres(i) + off_axout); }
+
+  // The neighbourhood of the last cmd_knn of problem i, in the order the reference's search returns it.
+  // min_dist_linear_search (topological_search.hpp:244-274) keeps a bounded max-heap ordered by distance alone, so among
+  // exactly equal distances both the order of the result and -- when a tie straddles the k-th place -- its members are
+  // decided by the heap's history (std::push_heap / pop_heap / sort_heap), while the device returns ascending
+  // (distance, index).  Equal distances only arise from coincident vertices (the bidirectional RRT* pulls the same
+  // point from both trees at a joining vertex); then, and only then, the search is replayed here on the host copy of
+  // the positions with the reference's own sequence of heap operations.  id[e] = vertex, slot[e] = where its edge
+  // verdicts sit in accept() / x_out() (a vertex the device did not list borrows the slot of a listed vertex at the
+  // same position: its walks are the same walks); the second direction of a GB_LIST_KNN_BIDIR list is at stride + slot.
+  struct Neighbours {
+    uint32_t K = 0, stride = 0;
+    std::vector<uint32_t> id, slot;
+  };
+  rkh_status neighbours(uint32_t i, const double* host_pos, const double* query, Neighbours* out) {
+    const uint32_t kc = kcnt(i), k = knn_k[i];
+    const uint32_t* ki = kidx(i);
+    const double* kd = kdist(i);
+    out->stride = kc;
+    out->K = kc < k ? kc : k;
+    out->id.assign(ki, ki + out->K);
+    out->slot.resize(out->K);
+    for (uint32_t e = 0; e < out->K; ++e) out->slot[e] = e;
+    bool tie = false;
+    for (uint32_t e = 0; e + 1 < kc && e < k; ++e) tie = tie || (kd[e] == kd[e + 1]);
+    if (!tie) return RKH_OK;
+    ++tie_replays;
+    // linear k-NN with the reference's heap (the distance is the left-to-right fp64 sum of the device kernels)
+    typedef std::pair<double, uint32_t> Entry;
+    auto cmp = [](const Entry& a, const Entry& b) { return a.first < b.first; };
+    std::vector<Entry> heap;
+    double radius = knn_radius[i];
+    for (uint64_t v = 0; v < knn_n[i]; ++v) {
+      double r = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double df = query[d] - host_pos[v * D + d];
+        r += df * df;
+      }
+      const double dist = std::sqrt(r);
+      if (!(dist < radius)) continue;
+      heap.push_back(Entry(dist, uint32_t(v)));
+      std::push_heap(heap.begin(), heap.end(), cmp);
+      if (heap.size() > k) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        heap.pop_back();
+        radius = heap.front().first;
+      }
+    }
+    std::sort_heap(heap.begin(), heap.end(), cmp);
+    out->K = uint32_t(heap.size());
+    out->id.resize(out->K);
+    out->slot.resize(out->K);
+    for (uint32_t e = 0; e < out->K; ++e) {
+      const uint32_t v = heap[e].second;
+      out->id[e] = v;
+      uint32_t found = 0xFFFFFFFFu;
+      for (uint32_t j = 0; j < kc && found == 0xFFFFFFFFu; ++j)
+        if (ki[j] == v) found = j;
+      for (uint32_t j = 0; j < kc && found == 0xFFFFFFFFu; ++j)
+        if (std::memcmp(&host_pos[size_t(ki[j]) * D], &host_pos[size_t(v) * D], D * sizeof(double)) == 0) found = j;
+      if (found == 0xFFFFFFFFu) {
+        set_error("graph batch: equal neighbour distances between distinct positions (tie order not reproducible)");
+        return RKH_ERR_UNSUPPORTED;
+      }
+      out->slot[e] = found;
+    }
+    return RKH_OK;
+  }
+
+  // the neighbourhood with its edge verdicts gathered in the reference's order: accept[e] / x_out[e] belong to the first
+  // direction of neighbour id[e], accept[K + e] / x_out[K + e] to the second one of a GB_LIST_KNN_BIDIR list
+  struct Verdicts {
+    uint32_t K = 0;
+    std::vector<uint32_t> id;
+    std::vector<uint8_t> accept;
+    std::vector<double> x_out;
+  };
+  rkh_status verdicts(uint32_t i, const double* host_pos, const double* query, Verdicts* out) {
+    Neighbours nb;
+    rkh_status st = neighbours(i, host_pos, query, &nb);
+    if (st != RKH_OK) return st;
+    const uint32_t K = nb.K;
+    out->K = K;
+    out->id = nb.id;
+    out->accept.resize(2 * size_t(K));
+    out->x_out.resize(2 * size_t(K) * D);
+    const uint8_t* acc = accept(i);
+    const double* xo = x_out(i);
+    for (uint32_t e = 0; e < K; ++e) {
+      const uint32_t a = nb.slot[e], b = nb.stride + nb.slot[e];  // b < 2 * kmax = emax: inside the result block
+      out->accept[e] = acc[a];
+      out->accept[K + e] = acc[b];
+      std::memcpy(&out->x_out[size_t(e) * D], &xo[size_t(a) * D], D * sizeof(double));
+      std::memcpy(&out->x_out[size_t(K + e) * D], &xo[size_t(b) * D], D * sizeof(double));
+    }
+    return RKH_OK;
+  }
 
   // ---- command building
   void begin() {
@@ -347,10 +453,14 @@ struct GraphBatch {
   // k nearest of `query` among the first n rows, strictly inside `radius`
   rkh_status cmd_knn(uint32_t i, const double* query, uint64_t n, uint32_t k, double radius) {
     GbProblem& q = prob[i];
-    if (k > kmax) {
+    if (k + 1 > kmax) {
       set_error("graph batch: k exceeds the planned maximum");
       return RKH_ERR_CAPACITY;
     }
+    knn_k[i] = k;
+    knn_n[i] = n;
+    knn_radius[i] = radius;
+    k += 1;  // see neighbours()
     for (int d = 0; d < RKH_MAX_DOF; ++d) h_aux[i].query[d] = d < D ? query[d] : 0.0;
     KnnArgs& a = h_knn[i];
     size_t bytes = 0;

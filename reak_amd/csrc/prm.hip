@@ -288,14 +288,16 @@ void add_edge(PrmProblem& q, uint32_t u, uint32_t v, double w) {
 }
 
 // prm_node_connector::operator() (prm_connector.hpp:136-182) on the verdicts of the finished step
-void connect_vertex(rkh_prm* p, uint32_t i, const double* pt, uint32_t x_near, double eweight) {
+rkh_status connect_vertex(rkh_prm* p, uint32_t i, const double* pt, uint32_t x_near, double eweight) {
   PrmProblem& q = p->prob[i];
-  const GraphBatch& gb = p->gb;
   const int D = p->D;
-  const uint32_t K = gb.kcnt(i);
-  const uint32_t* kidx = gb.kidx(i);
-  const uint8_t* accept = gb.accept(i);
-  const double* x_out = gb.x_out(i);
+  GraphBatch::Verdicts nb;
+  rkh_status vst = p->gb.verdicts(i, q.pos.data(), pt, &nb);
+  if (vst != RKH_OK) return vst;
+  const uint32_t K = nb.K;
+  const uint32_t* kidx = nb.id.data();
+  const uint8_t* accept = nb.accept.data();
+  const double* x_out = nb.x_out.data();
   // prm_conn_visitor::create_vertex (:92-107)
   const uint32_t v = raw_add_vertex(D, q, pt);
   q.cc_root[v] = v;
@@ -316,6 +318,7 @@ void connect_vertex(rkh_prm* p, uint32_t i, const double* pt, uint32_t x_near, d
     requeue(D, q, u);
   }
   requeue(D, q, v);
+  return RKH_OK;
 }
 
 }  // namespace
@@ -504,7 +507,8 @@ rkh_status rkh_prm_solve(rkh_prm* p, int64_t max_loop_iterations, rkh_prm_stats*
         gb.confirm_selected(i);
         double pt[RKH_MAX_DOF];
         std::memcpy(pt, gb.h_aux[i].pts[sel], D * sizeof(double));
-        connect_vertex(p, i, pt, NIL, 0.0);
+        st = connect_vertex(p, i, pt, NIL, 0.0);
+        if (st != RKH_OK) return st;
         q.kind.push_back(0);
         q.expanded.push_back(NIL);
         q.in_construct = false;
@@ -523,7 +527,8 @@ rkh_status rkh_prm_solve(rkh_prm* p, int64_t max_loop_iterations, rkh_prm_stats*
         double pt[RKH_MAX_DOF];
         std::memcpy(pt, gb.a_x_out(i) + size_t(sel) * D, D * sizeof(double));
         const double traveled = euclid(&q.pos[size_t(q.v_top) * D], pt, D);
-        connect_vertex(p, i, pt, q.v_top, traveled);
+        st = connect_vertex(p, i, pt, q.v_top, traveled);
+        if (st != RKH_OK) return st;
         q.kind.push_back(1);
       }
     }

@@ -943,6 +943,7 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
   const double fraction = io.frac ? io.frac[e] : qs.fraction;
   double result = a_d;       // component gl of the returned point
   uint32_t n_checked = 0;
+  bool completed_walk = false;  // the predicate loop ran to dist_inter without a collision (EDGE_STEER_BOTH)
   if (dist_tot == INFINITY) {
     result = a_d;
   } else if (dist_tot < qs.min_interval) {
@@ -993,6 +994,7 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
       if (n_valid < G) break;  // reached dist_inter without a collision
       cur = __shfl(my, (G - 1) * GL + gl, 64);
     }
+    completed_walk = !collided;
     if (collided) result = last_result;
     else if (fraction == 1.0) result = b_d;  // exact end fractions (:159-162)
     else if (fraction == 0.0) result = a_d;
@@ -1004,11 +1006,14 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
     const double n_ar = norm_n(a_d - result);
     const double n_ab = dist_tot;
     const double n_rb = norm_n(result - b_d);
-    if (io.mode == EDGE_STEER_ACCEPT) {
+    if (io.mode == EDGE_STEER_ACCEPT || io.mode == EDGE_STEER_BOTH) {
       // planning_visitor_base::steer_towards_position (planning_visitors.hpp:349-360)
       const double best_case = io.best_case ? io.best_case[e] : n_ab;
       const bool ok = (!isinf(n_ar)) && (n_ar < 2.0 * best_case) && (n_ar > io.steer_tol * best_case);
-      if (lane == 0) io.accept[e] = ok ? 1 : 0;
+      // EDGE_STEER_BOTH: bit 1 = the walk completed.  steer_back_to_position(target, source) walks the same points
+      // (move_position_back_to, interpolated_topologies.hpp:165-191) and returns the same point unless the walk
+      // completes, where it returns the source itself (:185-186): its verdict is bit 0 && !bit 1.
+      if (lane == 0) io.accept[e] = (ok ? 1 : 0) | ((io.mode == EDGE_STEER_BOTH && completed_walk) ? 2 : 0);
     } else if (io.mode == EDGE_GOAL_PROBE) {
       // interp_topo_get_distance_pred (interpolated_topologies.hpp:193-199)
       if (lane == 0) io.goal_dist[si - 1] = (n_rb < DBL_EPSILON) ? n_ab : INFINITY;

@@ -224,6 +224,7 @@ enum EdgeMode : int {
   EDGE_GOAL_PROBE = 2,
   EDGE_CONNECT = 3,
   EDGE_WALK_ACCEPT = 4,  // random_walk: traveled > steer_tol * best_case[e] (best_case carries the target distance)
+  EDGE_STEER_BOTH = 6,   // quasi-static kernel: EDGE_STEER_ACCEPT in bit 0 of accept, bit 1 = the walk ran to its end
   EDGE_POINT = 5,        // accept = is_free(target point), no walk (quasi-static kernel, one-wave-per-edge dynamics kernel)
 };
 

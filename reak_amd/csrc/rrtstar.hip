@@ -46,7 +46,7 @@ size_t highest_set_bit(size_t N) {
   return temp;
 }
 
-enum StarState { ST_IDLE, ST_GENERATE, ST_CONNECT };
+enum StarState { ST_IDLE, ST_GENERATE, ST_CONNECT, ST_CONNECT_PRED, ST_CONNECT_SUCC };
 
 struct StarProblem {
   rkh_rrt_params prm;
@@ -67,11 +67,22 @@ struct StarProblem {
   uint32_t x_near = NIL;
   double eweight = 0.0;
   int tries = 0;
+  // bidirectional RRT*: the backward tree (successor links towards the goal) and the generator's second result
+  std::vector<uint32_t> succ;
+  std::vector<double> fwd_dist, fwd_weight;
+  std::vector<std::vector<uint32_t>> parents;
+  std::vector<uint32_t> near_pred, near_succ;
+  std::vector<double> p_succ;
+  uint32_t x_succ = NIL;
+  double eweight_succ = 0.0;
+  uint64_t fwd_rewires = 0, joins = 0;
+  double best_join_cost = std::numeric_limits<double>::infinity();
 };
 }  // namespace
 
 struct rkh_rrtstar {
   GraphBatch gb;
+  bool bidirectional = false;
   int D = 0;
   uint32_t P = 0;
   double lower[RKH_MAX_DOF], upper[RKH_MAX_DOF];
@@ -99,6 +110,10 @@ uint32_t add_vertex(int D, StarProblem& q, const double* pt, double d, uint32_t 
   q.pred.push_back(pr);
   q.weight.push_back(0.0);
   q.children.emplace_back();
+  q.succ.push_back(NIL);
+  q.fwd_dist.push_back(std::numeric_limits<double>::infinity());
+  q.fwd_weight.push_back(0.0);
+  q.parents.emplace_back();
   return uint32_t(q.pred.size() - 1);
 }
 
@@ -121,15 +136,17 @@ void draw_sample(rkh_rrtstar* p, StarProblem& q) {  // hyperbox_topology::random
 }
 
 // lazy_node_connector::operator() (lazy_connector.hpp:332-372) on the verdicts of the CONNECT step
-void connect_vertex(rkh_rrtstar* p, uint32_t i) {
+rkh_status connect_vertex(rkh_rrtstar* p, uint32_t i) {
   StarProblem& q = p->prob[i];
-  const GraphBatch& gb = p->gb;
   const int D = p->D;
   const uint32_t v = uint32_t(q.pred.size() - 1);
-  const uint32_t K = gb.kcnt(i);
-  const uint32_t* kidx = gb.kidx(i);
-  const uint8_t* accept = gb.accept(i);
-  const double* x_out = gb.x_out(i);
+  GraphBatch::Verdicts nb;
+  rkh_status vst = p->gb.verdicts(i, q.pos.data(), &q.pos[size_t(v) * D], &nb);
+  if (vst != RKH_OK) return vst;
+  const uint32_t K = nb.K;
+  const uint32_t* kidx = nb.id.data();
+  const uint8_t* accept = nb.accept.data();
+  const double* x_out = nb.x_out.data();
   uint32_t x_near = q.x_near;
   double eweight = q.eweight;
   // connect_best_predecessor (:79-123)
@@ -189,6 +206,146 @@ void connect_vertex(rkh_rrtstar* p, uint32_t i) {
       incons.push_back(t);
     }
   }
+  return RKH_OK;
+}
+
+// the bidirectional lazy_node_connector::operator() (lazy_connector.hpp:465-518) on the verdicts of a CONNECT step:
+// verdict e = can_be_connected(u_e, v), verdict K + e = can_be_connected(v, u_e)
+rkh_status connect_vertex_bidir(rkh_rrtstar* p, uint32_t i, uint32_t x_pred, double ep_pred, uint32_t x_succ,
+                                double ep_succ) {
+  StarProblem& q = p->prob[i];
+  const int D = p->D;
+  const double inf = std::numeric_limits<double>::infinity();
+  const uint32_t v = uint32_t(q.pred.size() - 1);
+  GraphBatch::Verdicts nb;
+  rkh_status vst = p->gb.verdicts(i, q.pos.data(), &q.pos[size_t(v) * D], &nb);
+  if (vst != RKH_OK) return vst;
+  const uint32_t K = nb.K;
+  const uint32_t* kidx = nb.id.data();
+  const uint8_t* accept = nb.accept.data();
+  const double* x_out = nb.x_out.data();
+  const double* pv = &q.pos[size_t(v) * D];
+  auto P = [&](uint32_t u) { return &q.pos[size_t(u) * D]; };
+  {  // connect_best_predecessor (:79-123)
+    const uint32_t orig = x_pred;
+    double d_near = inf;
+    if (x_pred != NIL) d_near = q.dist[x_pred] + ep_pred;
+    for (uint32_t e = 0; e < K; ++e) {
+      const uint32_t u = kidx[e];
+      if (u == orig || q.pred[u] == NIL) continue;
+      const double d_out = euclid(P(u), pv, D) + q.dist[u];
+      if (d_out < d_near) {
+        ++q.edges_checked;
+        if (accept[e]) {
+          x_pred = u;
+          d_near = d_out;
+          ep_pred = euclid(P(u), &x_out[size_t(e) * D], D);
+        }
+      }
+    }
+  }
+  {  // connect_best_successor (:125-168)
+    const uint32_t orig = x_succ;
+    double d_near = inf;
+    if (x_succ != NIL) d_near = q.fwd_dist[x_succ] + ep_succ;
+    for (uint32_t e = 0; e < K; ++e) {
+      const uint32_t u = kidx[e];
+      if (u == orig || q.succ[u] == NIL) continue;
+      const double d_in = euclid(pv, P(u), D) + q.fwd_dist[u];
+      if (d_in < d_near) {
+        ++q.edges_checked;
+        if (accept[K + e]) {
+          x_succ = u;
+          d_near = d_in;
+          ep_succ = euclid(pv, &x_out[size_t(K + e) * D], D);
+        }
+      }
+    }
+  }
+  if (x_pred == NIL && x_succ == NIL) return RKH_OK;  // (the reference removes the vertex here; unreachable from the loop)
+  if (x_pred != NIL) {  // create_pred_edge (pruned_connector.hpp:366-382)
+    q.dist[v] = ep_pred + q.dist[x_pred];
+    q.pred[v] = x_pred;
+    q.weight[v] = ep_pred;
+    q.children[x_pred].push_back(v);
+  }
+  if (x_succ != NIL) {  // create_succ_edge (:388-404)
+    q.fwd_dist[v] = ep_succ + q.fwd_dist[x_succ];
+    q.succ[v] = x_succ;
+    q.fwd_weight[v] = ep_succ;
+    q.parents[x_succ].push_back(v);
+  }
+  if (q.pred[v] != NIL && q.succ[v] != NIL) {  // a joining vertex (the reference registers nothing for it)
+    ++q.joins;
+    if (q.dist[v] + q.fwd_dist[v] < q.best_join_cost) q.best_join_cost = q.dist[v] + q.fwd_dist[v];
+  }
+  // connect_successors (:230-275): vertices that have a successor belong to the backward tree and are left alone
+  for (uint32_t e = 0; e < K; ++e) {
+    const uint32_t u = kidx[e];
+    if (u == x_pred || q.succ[u] != NIL) continue;
+    const double d_in = euclid(pv, P(u), D) + q.dist[v];
+    if (d_in < q.dist[u]) {
+      ++q.edges_checked;
+      if (accept[K + e]) {
+        q.dist[u] = d_in;
+        const uint32_t old_pred = q.pred[u];
+        q.pred[u] = v;
+        q.weight[u] = euclid(pv, &x_out[size_t(K + e) * D], D);
+        q.children[v].push_back(u);
+        if (old_pred != u && old_pred != NIL) {
+          std::vector<uint32_t>& ch = q.children[old_pred];
+          ch.erase(std::find(ch.begin(), ch.end(), u));
+        }
+        ++q.rewires;
+      }
+    }
+  }
+  {  // update_successors (pruned_connector.hpp:310-332)
+    std::vector<uint32_t> incons(1, v);
+    while (!incons.empty()) {
+      const uint32_t s = incons.back();
+      incons.pop_back();
+      for (uint32_t t : q.children[s]) {
+        if (q.pred[t] != s) continue;
+        q.dist[t] = q.dist[s] + q.weight[t];
+        incons.push_back(t);
+      }
+    }
+  }
+  // connect_predecessors (:170-227): vertices that have a predecessor belong to the forward tree and are left alone
+  for (uint32_t e = 0; e < K; ++e) {
+    const uint32_t u = kidx[e];
+    if (u == x_succ || q.pred[u] != NIL) continue;
+    const double d_in = euclid(P(u), pv, D) + q.fwd_dist[v];
+    if (d_in < q.fwd_dist[u]) {
+      ++q.edges_checked;
+      if (accept[e]) {
+        q.fwd_dist[u] = d_in;
+        const uint32_t old_succ = q.succ[u];
+        q.succ[u] = v;
+        q.fwd_weight[u] = euclid(P(u), &x_out[size_t(e) * D], D);
+        q.parents[v].push_back(u);
+        if (old_succ != u && old_succ != NIL) {
+          std::vector<uint32_t>& pa = q.parents[old_succ];
+          pa.erase(std::find(pa.begin(), pa.end(), u));
+        }
+        ++q.fwd_rewires;
+      }
+    }
+  }
+  {  // update_predecessors (pruned_connector.hpp:338-360)
+    std::vector<uint32_t> incons(1, v);
+    while (!incons.empty()) {
+      const uint32_t t = incons.back();
+      incons.pop_back();
+      for (uint32_t s : q.parents[t]) {
+        if (q.succ[s] != t) continue;
+        q.fwd_dist[s] = q.fwd_dist[t] + q.fwd_weight[s];
+        incons.push_back(s);
+      }
+    }
+  }
+  return RKH_OK;
 }
 
 }  // namespace
@@ -286,7 +443,7 @@ rkh_status rkh_rrtstar_destroy(rkh_rrtstar* p) {
 
 // Run every problem until keep_going() is false (or max_loop_iterations loop passes, < 0 = unlimited).
 rkh_status rkh_rrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_rrtstar_stats* stats) {
-  if (!p) return RKH_ERR_BAD_ARG;
+  if (!p || p->bidirectional) return RKH_ERR_BAD_ARG;
   const int D = p->D;
   const double inf = std::numeric_limits<double>::infinity();
   GraphBatch& gb = p->gb;
@@ -337,10 +494,13 @@ rkh_status rkh_rrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_rr
     for (uint32_t i = 0; i < p->P; ++i) {
       StarProblem& q = p->prob[i];
       if (q.state == ST_GENERATE) {
-        const uint32_t K = gb.kcnt(i);
-        const uint32_t* kidx = gb.kidx(i);
-        const uint8_t* accept = gb.accept(i);
-        const double* x_out = gb.x_out(i);
+        GraphBatch::Verdicts nb;
+        st = gb.verdicts(i, q.pos.data(), q.p_new.data(), &nb);
+        if (st != RKH_OK) return st;
+        const uint32_t K = nb.K;
+        const uint32_t* kidx = nb.id.data();
+        const uint8_t* accept = nb.accept.data();
+        const double* x_out = nb.x_out.data();
         bool was_expanded = false;
         for (uint32_t e = 0; e < K; ++e) {  // rrg_node_puller::expand_to_nearest (:61-77): first success wins
           ++q.edges_checked;
@@ -374,7 +534,8 @@ rkh_status rkh_rrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_rr
           q.best_cost = q.dist[1];
           ++q.num_solutions;
         }
-        connect_vertex(p, i);
+        st = connect_vertex(p, i);
+        if (st != RKH_OK) return st;
         next_iteration(q);
       }
     }
@@ -427,6 +588,182 @@ rkh_status rkh_rrtstar_get_graph(rkh_rrtstar* p, uint32_t problem, double* pos, 
   if (pred) std::memcpy(pred, q.pred.data(), q.pred.size() * sizeof(uint32_t));
   if (dist) std::memcpy(dist, q.dist.data(), q.dist.size() * sizeof(double));
   if (near_seq) std::memcpy(near_seq, q.near_seq.data(), q.near_seq.size() * sizeof(uint32_t));
+  return RKH_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Bidirectional RRT*: generate_rrt_star_bidir (rrt_star.hpp:612-659) -> generate_rrt_star_bidir_loop (:197-236) with
+// rrg_bidir_generator (node_generators.hpp:215-277) and the bidirectional lazy_node_connector (lazy_connector.hpp:465-518).
+// Device steps: GENERATE = sample + k-NN + one walk per neighbour (EDGE_STEER_BOTH: the verdict of
+// steer_towards_position and, from the same walk, of steer_back_to_position); CONNECT = k-NN + append + both
+// directions of every neighbour, once for the expanded point and once for the retracted one.
+extern "C" {
+
+rkh_status rkh_birrtstar_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_rrt_params* prms,
+                                         uint32_t n_problems, rkh_rrtstar** out) {
+  if (!scene || !space || !prms || !out || n_problems < 1) return RKH_ERR_BAD_ARG;
+  if (space->n_dof != scene->host.n_dof || !(space->min_interval > 0.0)) {
+    set_error("rkh_birrtstar_create: n_dof mismatch or min_interval <= 0");
+    return RKH_ERR_BAD_ARG;
+  }
+  // two vertices can be added per loop iteration, the last iteration may start one short of max_vertices
+  std::vector<rkh_rrt_params> grown(prms, prms + n_problems);
+  for (rkh_rrt_params& g : grown) g.max_vertices += 1;
+  rkh_status st = rrtstar_create(scene, space, nullptr, grown.data(), n_problems, out);
+  if (st != RKH_OK) return st;
+  rkh_rrtstar* p = *out;
+  p->bidirectional = true;
+  for (uint32_t i = 0; i < n_problems; ++i) {
+    StarProblem& q = p->prob[i];
+    q.prm = prms[i];
+    q.p_succ.resize(p->D);
+    q.fwd_dist[1] = 0.0;  // rrt_star.hpp:650-651: the goal is the root of the backward tree
+    q.succ[1] = 1;
+  }
+  return RKH_OK;
+}
+
+rkh_status rkh_birrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_birrtstar_stats* stats) {
+  if (!p || !p->bidirectional) return RKH_ERR_BAD_ARG;
+  const int D = p->D;
+  GraphBatch& gb = p->gb;
+  auto keep = [&](const StarProblem& q) { return q.iteration_count < q.prm.max_vertices && q.prm.max_results > 0; };
+  auto next_iteration = [&](StarProblem& q) {
+    if (keep(q) && (max_loop_iterations < 0 || int64_t(q.loop_iterations) < max_loop_iterations)) {
+      ++q.loop_iterations;
+      q.tries = 0;
+      q.x_near = NIL;
+      q.x_succ = NIL;
+      q.state = ST_GENERATE;
+    } else {
+      q.state = ST_IDLE;
+    }
+  };
+  for (StarProblem& q : p->prob) next_iteration(q);
+  for (;;) {
+    gb.begin();
+    bool any = false;
+    for (uint32_t i = 0; i < p->P; ++i) {
+      StarProblem& q = p->prob[i];
+      if (q.state == ST_IDLE) continue;
+      any = true;
+      uint32_t k;
+      double radius;
+      star_params(q, D, &k, &radius);
+      rkh_status st = RKH_OK;
+      if (q.state == ST_GENERATE) {
+        draw_sample(p, q);
+        st = gb.cmd_knn(i, q.p_new.data(), q.pred.size(), k, radius);
+        gb.cmd_edges(i, GB_LIST_KNN_TO_QUERY, 0, EDGE_STEER_BOTH, q.prm.steer_tol);
+      } else {
+        const double* pt = q.state == ST_CONNECT_PRED ? q.p_new.data() : q.p_succ.data();
+        const uint64_t n_before = q.pred.size();
+        st = gb.cmd_knn(i, pt, n_before, k, radius);
+        if (st == RKH_OK) st = gb.cmd_append(i, pt);
+        gb.cmd_edges(i, GB_LIST_KNN_BIDIR, uint32_t(n_before), EDGE_CONNECT, q.prm.conn_tol);
+      }
+      if (st != RKH_OK) return st;
+    }
+    if (!any) break;
+    rkh_status st = gb.run();
+    if (st != RKH_OK) return st;
+    for (uint32_t i = 0; i < p->P; ++i) {
+      StarProblem& q = p->prob[i];
+      if (q.state == ST_GENERATE) {
+        // rrg_bidir_generator (node_generators.hpp:244-277)
+        GraphBatch::Verdicts nb;
+        st = gb.verdicts(i, q.pos.data(), q.p_new.data(), &nb);
+        if (st != RKH_OK) return st;
+        const uint32_t K = nb.K;
+        const uint32_t* kidx = nb.id.data();
+        const uint8_t* accept = nb.accept.data();
+        const double* x_out = nb.x_out.data();
+        bool was_expanded = false, was_retracted = false;
+        q.x_near = NIL;
+        q.x_succ = NIL;
+        for (uint32_t e = 0; e < K; ++e) {  // expand_to_nearest (:84-100): neighbours of the forward tree, in order
+          const uint32_t u = kidx[e];
+          if (q.pred[u] == NIL) continue;
+          ++q.edges_checked;
+          if (accept[e] & 1) {
+            q.x_near = u;
+            q.eweight = euclid(&q.pos[size_t(u) * D], &x_out[size_t(e) * D], D);
+            was_expanded = true;
+            break;
+          }
+        }
+        for (uint32_t e = 0; e < K; ++e) {  // retract_from_nearest (:102-118): neighbours of the backward tree
+          const uint32_t u = kidx[e];
+          if (q.succ[u] == NIL) continue;
+          ++q.edges_checked;
+          if ((accept[e] & 1) && !(accept[e] & 2)) {  // a completed walk back returns its own start: never accepted
+            q.x_succ = u;
+            q.eweight_succ = euclid(&x_out[size_t(e) * D], &q.pos[size_t(u) * D], D);
+            std::memcpy(q.p_succ.data(), &x_out[size_t(e) * D], D * sizeof(double));
+            was_retracted = true;
+            break;
+          }
+        }
+        if (was_expanded) {  // after the retraction: both pulls start from the sample
+          for (uint32_t e = 0; e < K; ++e)
+            if (kidx[e] == q.x_near) {
+              std::memcpy(q.p_new.data(), &x_out[size_t(e) * D], D * sizeof(double));
+              break;
+            }
+        }
+        bool gen_done = was_expanded || was_retracted;
+        if (!gen_done) {
+          if (q.tries >= 10) gen_done = true;
+          else ++q.tries;
+        }
+        if (gen_done) {
+          q.near_pred.push_back(q.x_near);
+          q.near_succ.push_back(q.x_succ);
+          if (q.x_near != NIL) q.state = ST_CONNECT_PRED;
+          else if (q.x_succ != NIL) q.state = ST_CONNECT_SUCC;
+          else next_iteration(q);
+        }
+      } else if (q.state == ST_CONNECT_PRED || q.state == ST_CONNECT_SUCC) {
+        const bool first = q.state == ST_CONNECT_PRED;
+        add_vertex(D, q, first ? q.p_new.data() : q.p_succ.data(), std::numeric_limits<double>::infinity(), NIL);
+        ++q.iteration_count;
+        st = first ? connect_vertex_bidir(p, i, q.x_near, q.eweight, NIL, 0.0)
+                   : connect_vertex_bidir(p, i, NIL, 0.0, q.x_succ, q.eweight_succ);
+        if (st != RKH_OK) return st;
+        if (first && q.x_succ != NIL) q.state = ST_CONNECT_SUCC;
+        else next_iteration(q);
+      }
+    }
+  }
+  if (stats)
+    for (uint32_t i = 0; i < p->P; ++i) {
+      const StarProblem& q = p->prob[i];
+      rkh_birrtstar_stats& o = stats[i];
+      o.num_vertices = q.pred.size();
+      o.samples = q.samples;
+      o.loop_iterations = q.loop_iterations;
+      o.rewires = q.rewires;
+      o.fwd_rewires = q.fwd_rewires;
+      o.joins = q.joins;
+      o.edges_checked = q.edges_checked;
+      o.best_join_cost = q.best_join_cost;
+    }
+  return RKH_OK;
+}
+
+rkh_status rkh_birrtstar_get_graph(rkh_rrtstar* p, uint32_t problem, double* pos, uint32_t* pred, double* dist, uint32_t* succ,
+                                   double* fwd_dist, uint32_t* near_pred, uint32_t* near_succ) {
+  if (!p || !p->bidirectional || problem >= p->P) return RKH_ERR_BAD_ARG;
+  const StarProblem& q = p->prob[problem];
+  if (pos) std::memcpy(pos, q.pos.data(), q.pos.size() * sizeof(double));
+  if (pred) std::memcpy(pred, q.pred.data(), q.pred.size() * sizeof(uint32_t));
+  if (dist) std::memcpy(dist, q.dist.data(), q.dist.size() * sizeof(double));
+  if (succ) std::memcpy(succ, q.succ.data(), q.succ.size() * sizeof(uint32_t));
+  if (fwd_dist) std::memcpy(fwd_dist, q.fwd_dist.data(), q.fwd_dist.size() * sizeof(double));
+  if (near_pred) std::memcpy(near_pred, q.near_pred.data(), q.near_pred.size() * sizeof(uint32_t));
+  if (near_succ) std::memcpy(near_succ, q.near_succ.data(), q.near_succ.size() * sizeof(uint32_t));
   return RKH_OK;
 }
 

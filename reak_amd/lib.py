@@ -72,7 +72,8 @@ EXPORTS = [
     "rkh_scene_create", "rkh_scene_create_with_meshes", "rkh_diag_gjk_distance", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
-    "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_create_batch", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
+    "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_create_batch", "rkh_birrtstar_create_qs_batch", "rkh_birrtstar_solve",
+    "rkh_birrtstar_get_graph", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
     "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_create_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph", "rkh_birrt_create_qs_batch", "rkh_birrt_destroy", "rkh_birrt_solve", "rkh_birrt_get_trees", "rkh_planner_get_solution", "rkh_rrtstar_get_solution", "rkh_birrt_get_solution",
 ]
 
@@ -140,6 +141,8 @@ def load():
     lib.rkh_rrtstar_destroy.argtypes = [vp]
     lib.rkh_rrtstar_solve.argtypes = [vp, C.c_int64, C.POINTER(RrtStarStats)]
     lib.rkh_rrtstar_get_graph.argtypes = [vp, u32, dp, u32p, dp, u32p]
+    lib.rkh_birrtstar_solve.argtypes = [vp, C.c_int64, C.POINTER(BiRrtStarStats)]
+    lib.rkh_birrtstar_get_graph.argtypes = [vp, u32, dp, u32p, dp, u32p, dp, u32p, u32p]
     lib.rkh_prm_create_qs_batch.argtypes = [vp, C.POINTER(T.QsSpace), C.POINTER(T.PrmParams), u32, C.POINTER(vp)]
     lib.rkh_prm_destroy.argtypes = [vp]
     lib.rkh_prm_solve.argtypes = [vp, C.c_int64, C.POINTER(PrmStats)]
@@ -569,6 +572,57 @@ class RrtStarPlanner:
         near = np.zeros(max(it, 1), dtype=np.uint32)
         _check(self.lib.rkh_rrtstar_get_graph(self.h, problem, T.dptr(pos), T.u32ptr(pred), T.dptr(dist), T.u32ptr(near)))
         return {"pos": pos, "pred": pred, "dist": dist, "near_seq": near[:it]}
+
+    def close(self):
+        if self.h:
+            self.lib.rkh_rrtstar_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BiRrtStarStats(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint64), ("samples", C.c_uint64), ("loop_iterations", C.c_uint64),
+                ("rewires", C.c_uint64), ("fwd_rewires", C.c_uint64), ("joins", C.c_uint64), ("edges_checked", C.c_uint64),
+                ("best_join_cost", C.c_double)]
+
+
+class BiRrtStarPlanner:
+    """rrtstar_planner with BIDIRECTIONAL_PLANNING over the quasi-static free space, batch of problems."""
+
+    def __init__(self, scene, prm, qs):
+        self.scene, self.lib, self.qs = scene, scene.lib, qs
+        self.prms = list(prm) if isinstance(prm, (list, tuple)) else [prm]
+        self.P, self.D = len(self.prms), qs.n_dof
+        self._prm_arr = T.as_array(self.prms, T.RrtParams)
+        self.h = C.c_void_p()
+        _check(self.lib.rkh_birrtstar_create_qs_batch(scene.h, C.byref(qs), self._prm_arr, self.P, C.byref(self.h)))
+        self.all_stats = (BiRrtStarStats * self.P)()
+
+    @property
+    def stats(self):
+        return self.all_stats[0]
+
+    def solve_planning_query(self, max_loop_iterations=-1):
+        _check(self.lib.rkh_birrtstar_solve(self.h, int(max_loop_iterations), self.all_stats))
+        return self.all_stats[0]
+
+    def graph(self, problem=0):
+        st = self.all_stats[problem]
+        nv, it = int(st.num_vertices), max(int(st.loop_iterations), 1)
+        pos = np.zeros((nv, self.D))
+        pred = np.zeros(nv, dtype=np.uint32); succ = np.zeros(nv, dtype=np.uint32)
+        dist = np.zeros(nv); fwd = np.zeros(nv)
+        npred = np.zeros(it, dtype=np.uint32); nsucc = np.zeros(it, dtype=np.uint32)
+        _check(self.lib.rkh_birrtstar_get_graph(self.h, problem, T.dptr(pos), T.u32ptr(pred), T.dptr(dist), T.u32ptr(succ),
+                                                T.dptr(fwd), T.u32ptr(npred), T.u32ptr(nsucc)))
+        n = int(st.loop_iterations)
+        return {"pos": pos, "pred": pred, "dist": dist, "succ": succ, "fwd_dist": fwd, "near_pred": npred[:n],
+                "near_succ": nsucc[:n]}
 
     def close(self):
         if self.h:

@@ -471,6 +471,36 @@ def test_rrtstar_over_the_dynamic_space_identical_to_sequential_planner(L, ctx, 
     pl.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_bidirectional_rrtstar_graph_identical_to_sequential_planner(L, ctx, oracle, seed):
+    """RRT* with BIDIRECTIONAL_PLANNING: a forward tree (predecessor / distance_accum) and a backward tree (successor /
+    fwd_distance_accum) grown and rewired together; the generator pulls one point from each side per sample."""
+    c1 = scenarios.make_c1(world_seed=1)
+    sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    prm = c1.rrt_params(seed=seed, max_vertices=1200)
+    rc, rout, rg = osc.birrtstar_qs(lo, hi, mi, prm)
+    pl = L.BiRrtStarPlanner(sc, prm, L.make_qs_space(3, lo, hi, mi))
+    st = pl.solve_planning_query()
+    g = pl.graph()
+    assert (st.num_vertices, st.samples, st.loop_iterations, st.rewires, st.fwd_rewires, st.joins, st.edges_checked) == (
+        rout.num_vertices, rout.samples, rout.loop_iterations, rout.rewires, rout.fwd_rewires, rout.joins, rout.edges_checked)
+    assert st.num_vertices >= 1202 and st.joins > 100
+    assert (g["near_succ"] != 0xFFFFFFFF).sum() > 50 and (g["near_pred"] != 0xFFFFFFFF).sum() > 50   # both pulls happen
+    # a joining vertex pulls the same point into both trees: coincident vertices, i.e. exactly equal k-NN distances whose
+    # order (and membership at the k-th place) follows the reference's heap, not (distance, index)
+    assert len(np.unique(g["pos"], axis=0)) < len(g["pos"])
+    for key in ("near_pred", "near_succ", "pred", "succ", "pos", "dist", "fwd_dist"):
+        assert np.array_equal(g[key], rg[key]), key
+    assert st.best_join_cost == rout.best_join_cost
+    # a shorter run resumed gives the same graph as the run in one go
+    pl2 = L.BiRrtStarPlanner(sc, prm, L.make_qs_space(3, lo, hi, mi))
+    pl2.solve_planning_query(max_loop_iterations=300)
+    st2 = pl2.solve_planning_query()
+    assert st2.num_vertices == st.num_vertices and np.array_equal(pl2.graph()["fwd_dist"], g["fwd_dist"])
+    pl.close(); pl2.close()
+
+
 def test_rrtstar_batch_of_seeds(L, ctx, oracle):
     c1 = scenarios.make_c1(world_seed=1)
     sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
