@@ -99,13 +99,14 @@ def nn_sweep_microbench(lib, ctx, events, n_rows, B, reps):
     bytes_per_sweep = n_rows * D * 8
     gbps = bytes_per_sweep / (ms * 1e-3) / 1e9
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_nn_sweep_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_nn_sweep_pmc.json")
     if os.path.exists(pmc):  # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (same kernel, same n)
         rec = json.load(open(pmc))
         if rec.get("n_rows") == n_rows and rec.get("queries_per_sweep") == B:
             traffic = rec["hbm_bytes_per_launch"]
+    name = nn.kernel_name()
     nn.close()
-    return {"bound": "hbm", "n": n_rows, "dims": D, "queries_per_sweep": B, "ms_per_sweep": ms, "achieved": gbps,
+    return {"kernel": name, "bound": "hbm", "n": n_rows, "dims": D, "queries_per_sweep": B, "ms_per_sweep": ms, "achieved": gbps,
             "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "queries_per_s": B / (ms * 1e-3),
             "algorithmic_bytes": bytes_per_sweep, "traffic": traffic}
 

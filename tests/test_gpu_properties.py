@@ -103,6 +103,41 @@ def _components(n, eu, ev):
     return np.array([find(i) for i in range(n)])
 
 
+def test_c3_rrtstar_at_two_hundred_thousand_vertices(L, ctx):
+    """BASELINE config C3 (6-DOF chain, 50 obstacles, RRT* with k-NN rewiring) for one problem at the largest size that
+    fits a test run: 200 000 vertices (about 100 s; iterations are sequential, ~2 000 per second per problem, so the
+    configuration's 1 M vertices would take a quarter of an hour -- the 1 M k-NN sweep itself is covered by
+    test_nn_sweep_properties_at_one_million_vertices and bench.py's c3_rrtstar object).  The oracle's linear k-NN makes
+    a comparison impractical here; checked are the invariants of the reference's bookkeeping."""
+    c3 = scenarios.make_c3(world_seed=1)
+    sc = L.Scene(ctx, c3)
+    lo, hi, mi = c3.meta["lower"], c3.meta["upper"], c3.meta["min_interval"]
+    nv = 200000
+    pl = L.RrtStarPlanner(sc, c3.rrt_params(seed=1, max_vertices=nv), L.make_qs_space(6, lo, hi, mi))
+    st = pl.solve_planning_query()
+    g = pl.graph()
+    pred, dist, pos = g["pred"].astype(np.int64), g["dist"], g["pos"]
+    assert st.num_vertices == nv + 2 and len(pred) == nv + 2 and pred[0] == 0 and dist[0] == 0.0
+    v = np.arange(1, len(pred))
+    conn = v[pred[v] != 0xFFFFFFFF]
+    assert len(conn) > 0.99 * nv
+    seg = np.sqrt(((pos[conn] - pos[pred[conn]]) ** 2).sum(axis=1))
+    dw = dist[conn] - dist[pred[conn]]
+    # an edge's weight is the distance travelled along it; can_be_connected (planning_visitors.hpp:385-395) accepts a walk
+    # that stops up to conn_tol = 5 % short of its target, so dist[v] - dist[pred] lies in [|edge| / 1.05, |edge|]
+    assert np.all(dw > 0.0) and np.all(dw <= seg + 1e-9) and np.all(dw >= seg / 1.05 - 1e-9)
+    assert np.all(np.isfinite(dist[conn]))
+    # every connected vertex reaches the start through its predecessors (no cycles): costs strictly decrease towards it
+    assert np.all(dist[pred[conn]] < dist[conn])
+    # triangle inequality up to the connection tolerance
+    assert np.all(dist[conn] >= 0.95 * np.sqrt(((pos[conn] - pos[0]) ** 2).sum(axis=1)) - 1e-9)
+    assert st.rewires > 50000 and st.num_solutions >= 1 and st.best_cost == dist[1]
+    # the rewiring radius shrinks as the tree grows: late vertices sit closer to their predecessors than early ones
+    early, late = conn[conn < 5000], conn[conn > nv - 5000]
+    assert np.median(seg[np.isin(conn, late)]) < np.median(seg[np.isin(conn, early)])
+    pl.close()
+
+
 def test_rrtstar_and_prm_invariants_at_scale(L, ctx):
     """6-DOF chain / 50 obstacles in the quasi-static space, sizes the oracle needs minutes for: RRT* cost bookkeeping
     (accumulated cost = predecessor's + edge length, the start is the only root, costs dominate straight-line
