@@ -149,6 +149,7 @@ def nn_published_config(lib, ctx, events, n_rows=25000, D=6, B=1000, reps=20):
     q = rng.uniform(-1.0, 1.0, size=(B, D))
     nn = lib.HipNeighborSearch(ctx, D, n_rows)
     nn.added_vertices(pts)
+    nn.set_coord_bound(1.0)  # the cloud's hyperbox: lets the sweep run its single-precision pre-filter (same answers)
     dq = torch.from_numpy(q).cuda()
     idx = torch.zeros(B, dtype=torch.int32, device="cuda")
     dist = torch.zeros(B, dtype=torch.float64, device="cuda")

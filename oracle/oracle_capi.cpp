@@ -455,6 +455,36 @@ int orc_rrtstar_dyn(void* h, const rkh_dyn_space* P, const rkh_rrt_params* prm, 
   out->best_cost = g_last_star.best_cost;
   return 0;
 }
+// RRT* with branch-and-bound pruning over the quasi-static free space; the graph is read with orc_rrtstar_copy
+static BnbRrtStarResult g_last_bnb;
+int orc_bnb_rrtstar_qs(void* h, int D, const double* lower, const double* upper, double min_interval,
+                       const rkh_rrt_params* prm, int64_t max_loop_iterations, OrcRrtStarOut* out, uint64_t* pruned,
+                       uint64_t* skipped) {
+  Scene* s = static_cast<Scene*>(h);
+  QuasiStaticSpace sp;
+  sp.D = D;
+  sp.lower.assign(lower, lower + D);
+  sp.upper.assign(upper, upper + D);
+  sp.min_interval = min_interval;
+  sp.chain = s->chain;
+  sp.env = s->env;
+  auto t0 = std::chrono::steady_clock::now();
+  generate_bnb_rrt_star(sp, *prm, long(max_loop_iterations), g_last_bnb);
+  g_last_star = g_last_bnb.g;
+  out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  out->num_vertices = g_last_star.pred.size();
+  out->samples = g_last_star.samples;
+  out->loop_iterations = g_last_star.loop_iterations;
+  out->num_solutions = g_last_star.num_solutions;
+  out->rewires = g_last_star.rewires;
+  out->edges_checked = g_last_star.cnt.edges_checked;
+  out->states_checked = g_last_star.cnt.states_checked;
+  out->best_cost = g_last_star.best_cost;
+  *pruned = uint64_t(g_last_bnb.pruned);
+  *skipped = uint64_t(g_last_bnb.skipped);
+  return 0;
+}
+void orc_bnb_removed_copy(uint8_t* removed) { std::memcpy(removed, g_last_bnb.removed.data(), g_last_bnb.removed.size()); }
 void orc_rrtstar_copy(double* pos, uint32_t* pred, double* dist, uint32_t* near_seq) {
   if (pos) std::memcpy(pos, g_last_star.pos.data(), g_last_star.pos.size() * sizeof(double));
   if (pred) std::memcpy(pred, g_last_star.pred.data(), g_last_star.pred.size() * sizeof(uint32_t));

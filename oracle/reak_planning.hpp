@@ -92,14 +92,17 @@ inline std::size_t linear_nn(const double* q, const double* pts, std::size_t n, 
 
 // min_dist_linear_search (k-NN + radius): topological_search.hpp:244-274
 // compare_pair_first orders the heap by distance only (detail::compare_pair_first :57-66).
+// `removed` (optional): vertices taken out of the graph (remove_vertex) -- they are not in vertices(g) any more
 inline void linear_knn(const double* q, const double* pts, std::size_t n, int D, std::size_t max_neighbors,
-                       double radius, std::vector<std::pair<double, std::size_t>>& out) {
+                       double radius, std::vector<std::pair<double, std::size_t>>& out,
+                       const std::vector<uint8_t>* removed = nullptr) {
   out.clear();
   if (n == 0) return;
   auto p_compare = [](const std::pair<double, std::size_t>& a, const std::pair<double, std::size_t>& b) {
     return a.first < b.first;
   };
   for (std::size_t i = 0; i < n; ++i) {
+    if (removed && (*removed)[i]) continue;
     double d = euclid(q, pts + i * D, D);
     if (!(d < radius)) continue;
     out.push_back(std::make_pair(d, i));
@@ -865,6 +868,8 @@ struct DAryHeap4 {
   std::vector<uint32_t> data;
   std::vector<std::size_t>* index_in_heap = nullptr;
   const std::vector<double>* key = nullptr;
+  bool greater = false;  // std::greater<double> as the compare type: the top is the LARGEST key (branch_and_bound_connector)
+  bool before(double a, double b) const { return greater ? a > b : a < b; }
   static std::size_t parent(std::size_t i) { return (i - 1) / 4; }
   std::size_t& idx(uint32_t v) {
     if (index_in_heap->size() <= v) index_in_heap->resize(v + 1, 0);  // vector_property_map grows with value 0
@@ -881,7 +886,7 @@ struct DAryHeap4 {
       if (index == 0) break;
       std::size_t parent_index = parent(index);
       uint32_t parent_value = data[parent_index];
-      if (moving_dist < (*key)[parent_value]) {
+      if (before(moving_dist, (*key)[parent_value])) {
         ++num_levels_moved;
         index = parent_index;
         continue;
@@ -914,12 +919,12 @@ struct DAryHeap4 {
       std::size_t n_children = (first_child + 4 <= heap_size) ? 4 : heap_size - first_child;
       for (std::size_t i = 1; i < n_children; ++i) {
         double i_dist = (*key)[data[first_child + i]];
-        if (i_dist < smallest_dist) {
+        if (before(i_dist, smallest_dist)) {
           smallest_child = i;
           smallest_dist = i_dist;
         }
       }
-      if (smallest_dist < moving_dist) {
+      if (before(smallest_dist, moving_dist)) {
         std::size_t c = first_child + smallest_child;  // swap_heap_elements(c, index)
         uint32_t va = data[c], vb = data[index];
         data[c] = vb;
@@ -1286,6 +1291,212 @@ void generate_bidirectional_rrt(Space& space, const rkh_rrt_params& prm, long ma
       } else {
         p_target1 = P(1, v2.first);
         v_target1 = std::make_pair(v2.first, true);
+      }
+    }
+  }
+  res.cnt = space.cnt;
+}
+
+}  // namespace oracle
+
+// --------------------------------------------------------------------------------------------
+// RRT* with branch-and-bound pruning (USE_BRANCH_AND_BOUND_PRUNING_FLAG): generate_bnb_rrt_star
+// (ctrl/graph_alg/rrt_star.hpp:690-730) = generate_rrt_star_loop (:169-190) with branch_and_bound_connector
+// (ctrl/graph_alg/branch_and_bound_connector.hpp:105-330) in the place of lazy_node_connector: a new point that cannot
+// improve on the best solution is dropped before (:287-293) or after (:311-317) its predecessor is chosen, every kept
+// vertex sits in a 4-ary max-heap keyed distance_accum + distance to the goal, update_successors re-keys the vertices
+// whose cost changed (push_or_update: sift-up only, also when a key went down) and then removes every vertex whose key
+// exceeds the goal's cost (:174-185).
+//
+// Defined here where the reference leaves things open ("parity unpinned"): (1) vertex ids are append-only -- a removed
+// vertex becomes a tombstone; BGL-Extra's pooled vertex container would hand its slot to the next vertex;
+// (2) the pruning loop reads Q.top() again after the last pop; it stops here when the heap is empty; (3) clear_vertex
+// drops the edges of a removed vertex but its children keep their predecessor field and their cost: they stay candidate
+// parents exactly as in the reference, where the dangling descriptor is only ever compared, not followed.
+namespace oracle {
+
+struct BnbRrtStarResult {
+  RrtStarResult g;
+  std::vector<uint8_t> removed;  // per vertex
+  long pruned = 0;               // vertices removed by the pruning loop or right after their creation
+  long skipped = 0;              // points dropped before a vertex was created
+};
+
+template <typename Space>
+void generate_bnb_rrt_star(Space& space, const rkh_rrt_params& prm, long max_loop_iterations, BnbRrtStarResult& out) {
+  const int D = space.D;
+  const uint32_t NIL = 0xFFFFFFFFu;
+  GlobalRng rng(prm.seed);
+  out = BnbRrtStarResult();
+  RrtStarResult& res = out.g;
+  res.D = D;
+  Point start(prm.start, prm.start + D), goal(prm.goal, prm.goal + D);
+  std::vector<std::vector<uint32_t>> children;
+  std::vector<double> key;
+  std::vector<std::size_t> index_in_heap;
+  DAryHeap4 Q;
+  Q.index_in_heap = &index_in_heap;
+  Q.key = &key;
+  Q.greater = true;
+  auto add_vertex = [&](const Point& p, double d, uint32_t pr) {
+    res.pos.insert(res.pos.end(), p.begin(), p.end());
+    res.dist.push_back(d);
+    res.pred.push_back(pr);
+    res.weight.push_back(0.0);
+    children.emplace_back();
+    out.removed.push_back(0);
+    key.push_back(0.0);
+    uint32_t v = uint32_t(res.pred.size() - 1);
+    Q.idx(v) = std::size_t(-1);
+    return v;
+  };
+  auto P = [&](uint32_t v) { return Point(res.pos.begin() + std::size_t(v) * D, res.pos.begin() + std::size_t(v + 1) * D); };
+  const double inf = std::numeric_limits<double>::infinity();
+  add_vertex(start, 0.0, 0);
+  add_vertex(goal, inf, NIL);
+  const double space_dim = double(D);
+  const double gamma = 3.0 * space.metric(start, goal);
+  unsigned long m_iteration_count = 0;
+  auto keep_going = [&]() {
+    return (m_iteration_count < prm.max_vertices) && (prm.max_results > (unsigned long)res.num_solutions);
+  };
+  std::vector<std::pair<double, std::size_t>> nc;
+  auto select_neighborhood = [&](const Point& p, std::vector<uint32_t>& o) {
+    std::size_t k;
+    double radius;
+    std::size_t live = res.pred.size() - std::size_t(out.pruned);  // num_vertices(g)
+    star_neighborhood(live, space_dim, gamma, &k, &radius);
+    linear_knn(p.data(), res.pos.data(), res.pred.size(), D, k, radius, nc, &out.removed);
+    o.clear();
+    for (auto& e : nc) o.push_back(uint32_t(e.second));
+  };
+  auto can_be_connected = [&](uint32_t u, uint32_t v, double* w) {
+    Point p_result;
+    Point pu = P(u), pv = P(v);
+    double traveled = space.steer(pu, pv, 1.0, p_result);
+    double remaining = space.metric(p_result, pv);
+    *w = traveled;
+    return (!std::isinf(traveled)) && (remaining < prm.conn_tol * traveled);
+  };
+  auto remove_vertex = [&](uint32_t v) {  // vertex_to_be_removed; clear_vertex; remove_vertex
+    out.removed[v] = 1;
+    ++out.pruned;
+    uint32_t pv = res.pred[v];
+    if (pv != NIL && pv != v && !out.removed[pv]) {
+      auto& ch = children[pv];
+      auto it = std::find(ch.begin(), ch.end(), v);
+      if (it != ch.end()) ch.erase(it);
+    }
+    children[v].clear();
+  };
+  std::vector<uint32_t> Nc;
+  while (keep_going() && (max_loop_iterations < 0 || res.loop_iterations < max_loop_iterations)) {
+    ++res.loop_iterations;
+    // ---- rrg_node_generator (node_generators.hpp:137-172)
+    Point p_new;
+    uint32_t x_near = NIL;
+    double eweight = 0.0;
+    for (std::size_t i = 0;; ++i) {
+      p_new = space.random_point(rng);
+      ++res.samples;
+      select_neighborhood(p_new, Nc);
+      bool was_expanded = false;
+      for (uint32_t u : Nc) {
+        Point pu = P(u), p_tmp;
+        double traveled = space.steer(pu, p_new, 1.0, p_tmp);
+        double best_case = space.metric(pu, p_new);
+        bool ok = (!std::isinf(traveled)) && (traveled < 2.0 * best_case) && (traveled > prm.steer_tol * best_case);
+        if (ok) {
+          p_new = p_tmp;
+          x_near = u;
+          eweight = traveled;
+          was_expanded = true;
+          break;
+        }
+      }
+      if (was_expanded) break;
+      if (i >= 10) { x_near = NIL; break; }
+    }
+    res.near_seq.push_back(x_near);
+    if (x_near == NIL || res.dist[x_near] == inf) continue;
+    // ---- branch_and_bound_connector::operator() (:277-330)
+    const double dist_from_start = space.metric(P(0), p_new);
+    const double dist_to_goal = space.metric(p_new, P(1));
+    if (res.pred[1] != NIL && dist_from_start + dist_to_goal > res.dist[1]) {
+      ++out.skipped;
+      continue;
+    }
+    select_neighborhood(p_new, Nc);
+    uint32_t v = add_vertex(p_new, inf, NIL);
+    ++m_iteration_count;
+    if (res.pred[1] != NIL && res.dist[1] < res.best_cost) {
+      res.best_cost = res.dist[1];
+      ++res.num_solutions;
+    }
+    {  // connect_best_predecessor
+      const uint32_t x_near_original = x_near;
+      double d_near = res.dist[x_near] + eweight;
+      for (uint32_t u : Nc) {
+        if (u == x_near_original || res.pred[u] == NIL) continue;
+        double d_out = space.metric(P(u), P(v)) + res.dist[u];
+        if (d_out < d_near) {
+          double w;
+          if (can_be_connected(u, v, &w)) {
+            x_near = u;
+            d_near = d_out;
+            eweight = w;
+          }
+        }
+      }
+    }
+    res.dist[v] = eweight + res.dist[x_near];  // create_pred_edge
+    res.pred[v] = x_near;
+    res.weight[v] = eweight;
+    children[x_near].push_back(v);
+    if (res.pred[1] != NIL && res.dist[v] + dist_to_goal > res.dist[1]) {  // :311-317
+      remove_vertex(v);
+      continue;
+    }
+    key[v] = res.dist[v] + dist_to_goal;
+    Q.push(v);
+    for (uint32_t u : Nc) {  // connect_successors (lazy_connector.hpp:230-275)
+      if (u == x_near) continue;
+      double d_in = space.metric(P(v), P(u)) + res.dist[v];
+      if (d_in < res.dist[u]) {
+        double w;
+        if (can_be_connected(v, u, &w)) {
+          res.dist[u] = d_in;
+          uint32_t old_pred = res.pred[u];
+          res.pred[u] = v;
+          res.weight[u] = w;
+          children[v].push_back(u);
+          if (old_pred != u && old_pred != NIL && !out.removed[old_pred]) {
+            auto& ch = children[old_pred];
+            auto it = std::find(ch.begin(), ch.end(), u);
+            if (it != ch.end()) ch.erase(it);
+          }
+          ++res.rewires;
+        }
+      }
+    }
+    {  // branch_and_bound_connector::update_successors (:142-185)
+      std::vector<uint32_t> incons(1, v);
+      while (!incons.empty()) {
+        uint32_t s = incons.back();
+        incons.pop_back();
+        for (uint32_t t : children[s]) {
+          if (res.pred[t] != s) continue;
+          res.dist[t] = res.dist[s] + res.weight[t];
+          key[t] = res.dist[t] + space.metric(P(t), P(1));
+          Q.push_or_update(t);
+          incons.push_back(t);
+        }
+      }
+      if (res.pred[1] != NIL) {  // prune all the worst nodes
+        while (!Q.empty() && key[Q.top()] > res.dist[1]) {
+          remove_vertex(Q.top());
+          Q.pop();
+        }
       }
     }
   }

@@ -127,6 +127,9 @@ def load(fast=False):
     lib.orc_rrt_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtOut)]
     lib.orc_qs_move.argtypes = [C.c_void_p, C.c_int, dp, dp, d, dp, dp, C.c_int, d, dp, u32p]
     lib.orc_rrtstar_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtStarOut)]
+    lib.orc_bnb_rrtstar_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtStarOut),
+                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.orc_bnb_removed_copy.argtypes = [C.POINTER(C.c_uint8)]
     lib.orc_birrtstar_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(BiRrtStarOut)]
     lib.orc_birrtstar_copy.argtypes = [dp, u32p, dp, u32p, dp, u32p, u32p]
     lib.orc_prm_dyn.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), C.POINTER(T.PrmParams), C.c_int64, C.POINTER(PrmOut)]
@@ -259,6 +262,23 @@ class OracleScene:
                               kind.ctypes.data_as(C.POINTER(C.c_uint8)), T.u32ptr(exp))
         return rc, out, {"pos": pos, "edge_u": eu[:ne], "edge_v": ev[:ne], "edge_w": ew[:ne], "density": dens,
                          "cc_root": cc, "kind": kind[:it], "expanded": exp[:it]}
+
+    def bnb_rrtstar_qs(self, lower, upper, min_interval, prm, max_loop_iterations=-1):
+        """RRT* with branch-and-bound pruning: (rc, out, graph incl. "removed", pruned, skipped)."""
+        lower = np.ascontiguousarray(lower, dtype=np.float64)
+        upper = np.ascontiguousarray(upper, dtype=np.float64)
+        out = RrtStarOut()
+        pruned, skipped = C.c_uint64(), C.c_uint64()
+        rc = self.lib.orc_bnb_rrtstar_qs(self.h, len(lower), T.dptr(lower), T.dptr(upper), float(min_interval), C.byref(prm),
+                                         int(max_loop_iterations), C.byref(out), C.byref(pruned), C.byref(skipped))
+        nv, D = int(out.num_vertices), len(lower)
+        pos = np.zeros((nv, D)); pred = np.zeros(nv, dtype=np.uint32); dist = np.zeros(nv)
+        near = np.zeros(max(int(out.loop_iterations), 1), dtype=np.uint32)
+        removed = np.zeros(nv, dtype=np.uint8)
+        self.lib.orc_rrtstar_copy(T.dptr(pos), T.u32ptr(pred), T.dptr(dist), T.u32ptr(near))
+        self.lib.orc_bnb_removed_copy(removed.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return rc, out, {"pos": pos, "pred": pred, "dist": dist, "near_seq": near[: int(out.loop_iterations)],
+                         "removed": removed}, pruned.value, skipped.value
 
     def birrtstar_qs(self, lower, upper, min_interval, prm, max_loop_iterations=-1):
         """Bidirectional RRT* over the quasi-static space."""
