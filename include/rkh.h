@@ -196,6 +196,7 @@ void* rkh_planner_stream(rkh_planner* p);
 typedef struct rkh_rrtstar_stats {
   uint64_t num_vertices, samples, loop_iterations, num_solutions, rewires, edges_checked;
   double best_cost;
+  uint64_t pruned, skipped; /* branch-and-bound: vertices removed / points dropped before a vertex was created */
 } rkh_rrtstar_stats;
 rkh_status rkh_rrtstar_create_qs_batch(rkh_scene* scene, const rkh_qs_space* space, const rkh_rrt_params* prms,
                                        uint32_t n_problems, rkh_rrtstar** out);
@@ -210,6 +211,17 @@ rkh_status rkh_rrtstar_create_qs_batch(rkh_scene* scene, const rkh_qs_space* spa
  * are evaluated per direction. */
 rkh_status rkh_rrtstar_create_batch(rkh_scene* scene, const rkh_dyn_space* space, const rkh_rrt_params* prms,
                                     uint32_t n_problems, rkh_rrtstar** out);
+/* USE_BRANCH_AND_BOUND_PRUNING_FLAG (rrtstar_path_planner.tpp:270-283; unidirectional planners, before the first solve):
+ * generate_bnb_rrt_star (rrt_star.hpp:690-730) with branch_and_bound_connector (branch_and_bound_connector.hpp:105-330).
+ * Once the goal has a predecessor, a new point whose straight-line bound |start p| + |p goal| exceeds the goal's cost is
+ * dropped, and after every connection the vertices whose distance_accum + |v goal| exceeds it are removed from the graph
+ * (vertex_to_be_removed -> the KNN synchro's removed_vertex: the vertex keeps its index, its row on the device becomes
+ * +inf).  Kept as in the reference: with nothing but uniform sampling almost every later point is dropped, so a run is
+ * normally ended by max_loop_iterations; children of a removed vertex keep their cost and stay candidate parents.
+ * Defined here: ids are append-only (the reference's pooled container would re-use the hole), the pruning loop stops on
+ * an empty queue. */
+rkh_status rkh_rrtstar_set_branch_and_bound(rkh_rrtstar* p, int enabled);
+rkh_status rkh_rrtstar_get_removed(rkh_rrtstar* p, uint32_t problem, uint8_t* removed);
 rkh_status rkh_rrtstar_destroy(rkh_rrtstar* p);
 /* stats: array of n_problems entries.  max_loop_iterations < 0: run until keep_going() is false. */
 rkh_status rkh_rrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_rrtstar_stats* stats);

@@ -125,6 +125,103 @@ static __global__ void gb_list_kernel(const GbAux* __restrict__ aux) {
   if (threadIdx.x == 0) *a.n_edges = E;
 }
 
+// boost::d_ary_heap_indirect<Vertex, 4, IndexInHeapMap, KeyMap, Compare> restated from its published definition (push,
+// push_or_update = insert-or-sift-UP-only, pop, top).  greater = false: std::less (PRM's density queue, smallest key on
+// top); greater = true: std::greater (branch_and_bound_connector's queue, largest key on top).
+struct Heap4 {
+  bool greater = false;
+  bool before(double a, double b) const { return greater ? a > b : a < b; }
+  std::vector<uint32_t> data;
+  std::vector<size_t> index;
+  const std::vector<double>* key = nullptr;
+  size_t& idx(uint32_t v) {
+    if (index.size() <= v) index.resize(size_t(v) + 1, 0);
+    return index[v];
+  }
+  void sift_up(size_t i) {
+    if (i == 0) return;
+    const size_t orig = i;
+    const uint32_t moving = data[i];
+    const double moving_key = (*key)[moving];
+    size_t levels = 0;
+    while (i != 0) {
+      const size_t parent = (i - 1) / 4;
+      if (before(moving_key, (*key)[data[parent]])) {
+        ++levels;
+        i = parent;
+      } else {
+        break;
+      }
+    }
+    i = orig;
+    for (size_t l = 0; l < levels; ++l) {
+      const size_t parent = (i - 1) / 4;
+      const uint32_t pv = data[parent];
+      idx(pv) = i;
+      data[i] = pv;
+      i = parent;
+    }
+    data[i] = moving;
+    idx(moving) = i;
+  }
+  void sift_down() {
+    if (data.empty()) return;
+    size_t i = 0;
+    const double moving_key = (*key)[data[0]];
+    const size_t n = data.size();
+    for (;;) {
+      const size_t first = 4 * i + 1;
+      if (first >= n) break;
+      const size_t nc = (first + 4 <= n) ? 4 : n - first;
+      size_t best = 0;
+      double best_key = (*key)[data[first]];
+      for (size_t c = 1; c < nc; ++c) {
+        const double k = (*key)[data[first + c]];
+        if (before(k, best_key)) {
+          best = c;
+          best_key = k;
+        }
+      }
+      if (before(best_key, moving_key)) {
+        const size_t c = first + best;
+        std::swap(data[c], data[i]);
+        idx(data[i]) = i;
+        idx(data[c]) = c;
+        i = c;
+      } else {
+        break;
+      }
+    }
+  }
+  void push(uint32_t v) {
+    const size_t i = data.size();
+    data.push_back(v);
+    idx(v) = i;
+    sift_up(i);
+  }
+  void push_or_update(uint32_t v) {
+    size_t i = idx(v);
+    if (i == size_t(-1)) {
+      i = data.size();
+      data.push_back(v);
+      idx(v) = i;
+    }
+    sift_up(i);
+  }
+  void pop() {
+    idx(data[0]) = size_t(-1);
+    if (data.size() != 1) {
+      data[0] = data.back();
+      idx(data[0]) = 0;
+      data.pop_back();
+      sift_down();
+    } else {
+      data.pop_back();
+    }
+  }
+};
+
+
 struct GbProblem {
   NnStore tree;
   uint64_t n_dev = 0;            // rows on the device
@@ -161,6 +258,7 @@ struct GraphBatch {
   std::vector<uint64_t> knn_n;
   std::vector<double> knn_radius;
   uint64_t tie_replays = 0;
+  std::vector<double> inf_row;
 
   // the steerable dynamic free space: vertices are states (q, qd), edges steer_position_toward (planner.hip's space)
   rkh_status init_dynamic(rkh_scene* sc, const rkh_dyn_space* space, uint32_t n_problems, const uint64_t* capacities,
@@ -283,7 +381,8 @@ struct GraphBatch {
     uint32_t K = 0, stride = 0;
     std::vector<uint32_t> id, slot;
   };
-  rkh_status neighbours(uint32_t i, const double* host_pos, const double* query, Neighbours* out) {
+  rkh_status neighbours(uint32_t i, const double* host_pos, const double* query, Neighbours* out,
+                        const uint8_t* removed = nullptr) {
     const uint32_t kc = kcnt(i), k = knn_k[i];
     const uint32_t* ki = kidx(i);
     const double* kd = kdist(i);
@@ -302,6 +401,7 @@ struct GraphBatch {
     std::vector<Entry> heap;
     double radius = knn_radius[i];
     for (uint64_t v = 0; v < knn_n[i]; ++v) {
+      if (removed && removed[v]) continue;  // not a vertex of the graph any more
       double r = 0.0;
       for (int d = 0; d < D; ++d) {
         const double df = query[d] - host_pos[v * D + d];
@@ -346,9 +446,10 @@ struct GraphBatch {
     std::vector<uint8_t> accept;
     std::vector<double> x_out;
   };
-  rkh_status verdicts(uint32_t i, const double* host_pos, const double* query, Verdicts* out) {
+  rkh_status verdicts(uint32_t i, const double* host_pos, const double* query, Verdicts* out,
+                      const uint8_t* removed = nullptr) {
     Neighbours nb;
-    rkh_status st = neighbours(i, host_pos, query, &nb);
+    rkh_status st = neighbours(i, host_pos, query, &nb, removed);
     if (st != RKH_OK) return st;
     const uint32_t K = nb.K;
     out->K = K;
@@ -436,6 +537,19 @@ struct GraphBatch {
     return RKH_OK;
   }
   void confirm_selected(uint32_t i) { ++prob[i].n_dev; }
+  // any_knn_synchro::removed_vertex: the row keeps its index and is overwritten with +inf (no sweep returns it);
+  // stream-ordered before the next step's kernels
+  rkh_status remove_row(uint32_t i, uint32_t row) {
+    if (inf_row.empty()) inf_row.assign(64, INFINITY);
+    GbProblem& q = prob[i];
+    if (row >= q.n_dev) {
+      set_error("graph batch: no such vertex row");
+      return RKH_ERR_BAD_ARG;
+    }
+    RKH_HIP(hipMemcpyAsync(q.tree.d_pos + uint64_t(row) * DP, inf_row.data(), DP * sizeof(double), hipMemcpyHostToDevice,
+                           stream));
+    return RKH_OK;
+  }
   // vertex row n_dev of problem i (the caller's vertex ids are row numbers)
   rkh_status cmd_append(uint32_t i, const double* row) {
     GbProblem& q = prob[i];

@@ -85,98 +85,6 @@ struct RngStream {
   }
 };
 
-// boost::d_ary_heap_indirect<Vertex, 4, IndexInHeapMap, DensityMap, std::less<double>>
-struct Heap4 {
-  std::vector<uint32_t> data;
-  std::vector<size_t> index;
-  const std::vector<double>* key = nullptr;
-  size_t& idx(uint32_t v) {
-    if (index.size() <= v) index.resize(size_t(v) + 1, 0);
-    return index[v];
-  }
-  void sift_up(size_t i) {
-    if (i == 0) return;
-    const size_t orig = i;
-    const uint32_t moving = data[i];
-    const double moving_key = (*key)[moving];
-    size_t levels = 0;
-    while (i != 0) {
-      const size_t parent = (i - 1) / 4;
-      if (moving_key < (*key)[data[parent]]) {
-        ++levels;
-        i = parent;
-      } else {
-        break;
-      }
-    }
-    i = orig;
-    for (size_t l = 0; l < levels; ++l) {
-      const size_t parent = (i - 1) / 4;
-      const uint32_t pv = data[parent];
-      idx(pv) = i;
-      data[i] = pv;
-      i = parent;
-    }
-    data[i] = moving;
-    idx(moving) = i;
-  }
-  void sift_down() {
-    if (data.empty()) return;
-    size_t i = 0;
-    const double moving_key = (*key)[data[0]];
-    const size_t n = data.size();
-    for (;;) {
-      const size_t first = 4 * i + 1;
-      if (first >= n) break;
-      const size_t nc = (first + 4 <= n) ? 4 : n - first;
-      size_t best = 0;
-      double best_key = (*key)[data[first]];
-      for (size_t c = 1; c < nc; ++c) {
-        const double k = (*key)[data[first + c]];
-        if (k < best_key) {
-          best = c;
-          best_key = k;
-        }
-      }
-      if (best_key < moving_key) {
-        const size_t c = first + best;
-        std::swap(data[c], data[i]);
-        idx(data[i]) = i;
-        idx(data[c]) = c;
-        i = c;
-      } else {
-        break;
-      }
-    }
-  }
-  void push(uint32_t v) {
-    const size_t i = data.size();
-    data.push_back(v);
-    idx(v) = i;
-    sift_up(i);
-  }
-  void push_or_update(uint32_t v) {
-    size_t i = idx(v);
-    if (i == size_t(-1)) {
-      i = data.size();
-      data.push_back(v);
-      idx(v) = i;
-    }
-    sift_up(i);
-  }
-  void pop() {
-    idx(data[0]) = size_t(-1);
-    if (data.size() != 1) {
-      data[0] = data.back();
-      idx(data[0]) = 0;
-      data.pop_back();
-      sift_down();
-    } else {
-      data.pop_back();
-    }
-  }
-};
-
 enum PrmPending { PD_NONE, PD_CONSTRUCT, PD_EXPAND };
 
 struct PrmProblem {

@@ -77,12 +77,19 @@ struct StarProblem {
   double eweight_succ = 0.0;
   uint64_t fwd_rewires = 0, joins = 0;
   double best_join_cost = std::numeric_limits<double>::infinity();
+  // branch-and-bound pruning: tombstones, the queue keyed distance_accum + distance to the goal (largest on top)
+  std::vector<uint8_t> removed;
+  std::vector<double> key;
+  Heap4 Q;
+  uint64_t pruned = 0, skipped = 0;
+  double dist_to_goal = 0.0;  // of the point being connected
 };
 }  // namespace
 
 struct rkh_rrtstar {
   GraphBatch gb;
   bool bidirectional = false;
+  bool branch_and_bound = false;
   int D = 0;
   uint32_t P = 0;
   double lower[RKH_MAX_DOF], upper[RKH_MAX_DOF];
@@ -114,11 +121,32 @@ uint32_t add_vertex(int D, StarProblem& q, const double* pt, double d, uint32_t 
   q.fwd_dist.push_back(std::numeric_limits<double>::infinity());
   q.fwd_weight.push_back(0.0);
   q.parents.emplace_back();
-  return uint32_t(q.pred.size() - 1);
+  q.removed.push_back(0);
+  q.key.push_back(0.0);
+  const uint32_t v = uint32_t(q.pred.size() - 1);
+  q.Q.idx(v) = size_t(-1);  // put(index_in_heap, v, -1) (branch_and_bound_connector.hpp:137,301)
+  return v;
+}
+
+// vertex_to_be_removed + clear_vertex + remove_vertex: a tombstone (ids are append-only; the row on the device becomes
+// +inf so that no sweep returns it, any_knn_synchro::removed_vertex).  The children of a removed vertex keep their
+// predecessor field and their cost, as in the reference.
+rkh_status remove_vertex(rkh_rrtstar* p, uint32_t i, uint32_t v) {
+  StarProblem& q = p->prob[i];
+  q.removed[v] = 1;
+  ++q.pruned;
+  const uint32_t pv = q.pred[v];
+  if (pv != NIL && pv != v && !q.removed[pv]) {
+    std::vector<uint32_t>& ch = q.children[pv];
+    auto it = std::find(ch.begin(), ch.end(), v);
+    if (it != ch.end()) ch.erase(it);
+  }
+  q.children[v].clear();
+  return p->gb.remove_row(i, v);
 }
 
 void star_params(const StarProblem& q, int D, uint32_t* k, double* radius) {
-  const size_t N = q.pred.size();
+  const size_t N = q.pred.size() - size_t(q.pruned);  // num_vertices(g)
   const size_t log_N = highest_set_bit(N) + 1;
   *k = uint32_t(4 * log_N);
   *radius = q.gamma * std::pow(log_N / double(N), 1.0 / double(D));
@@ -141,7 +169,7 @@ rkh_status connect_vertex(rkh_rrtstar* p, uint32_t i) {
   const int D = p->D;
   const uint32_t v = uint32_t(q.pred.size() - 1);
   GraphBatch::Verdicts nb;
-  rkh_status vst = p->gb.verdicts(i, q.pos.data(), &q.pos[size_t(v) * D], &nb);
+  rkh_status vst = p->gb.verdicts(i, q.pos.data(), &q.pos[size_t(v) * D], &nb, q.removed.data());
   if (vst != RKH_OK) return vst;
   const uint32_t K = nb.K;
   const uint32_t* kidx = nb.id.data();
@@ -173,6 +201,12 @@ rkh_status connect_vertex(rkh_rrtstar* p, uint32_t i) {
   q.pred[v] = x_near;
   q.weight[v] = eweight;
   q.children[x_near].push_back(v);
+  const bool bnb = p->branch_and_bound;
+  if (bnb) {  // branch_and_bound_connector::operator() (branch_and_bound_connector.hpp:311-320)
+    if (q.pred[1] != NIL && q.dist[v] + q.dist_to_goal > q.dist[1]) return remove_vertex(p, i, v);
+    q.key[v] = q.dist[v] + q.dist_to_goal;
+    q.Q.push(v);
+  }
   // connect_successors (:230-275)
   for (uint32_t e = 0; e < K; ++e) {
     const uint32_t u = kidx[e];
@@ -187,15 +221,17 @@ rkh_status connect_vertex(rkh_rrtstar* p, uint32_t i) {
         q.pred[u] = v;
         q.weight[u] = euclid(&q.pos[size_t(v) * D], &x_out[size_t(K + e) * D], D);
         q.children[v].push_back(u);
-        if (old_pred != u && old_pred != NIL) {
+        if (old_pred != u && old_pred != NIL && !q.removed[old_pred]) {
           std::vector<uint32_t>& ch = q.children[old_pred];
-          ch.erase(std::find(ch.begin(), ch.end(), u));
+          auto it = std::find(ch.begin(), ch.end(), u);
+          if (it != ch.end()) ch.erase(it);
         }
         ++q.rewires;
       }
     }
   }
-  // update_successors (pruned_connector.hpp:310-332)
+  // update_successors (pruned_connector.hpp:310-332; with pruning: branch_and_bound_connector.hpp:142-185 -- the vertices
+  // whose cost changed are re-keyed (sift-up only), then every vertex whose key exceeds the goal's cost is removed)
   std::vector<uint32_t> incons(1, v);
   while (!incons.empty()) {
     const uint32_t s = incons.back();
@@ -203,7 +239,18 @@ rkh_status connect_vertex(rkh_rrtstar* p, uint32_t i) {
     for (uint32_t t : q.children[s]) {
       if (q.pred[t] != s) continue;
       q.dist[t] = q.dist[s] + q.weight[t];
+      if (bnb) {
+        q.key[t] = q.dist[t] + euclid(&q.pos[size_t(t) * D], &q.pos[size_t(1) * D], D);
+        q.Q.push_or_update(t);
+      }
       incons.push_back(t);
+    }
+  }
+  if (bnb && q.pred[1] != NIL) {
+    while (!q.Q.data.empty() && q.key[q.Q.data[0]] > q.dist[1]) {
+      const rkh_status st = remove_vertex(p, i, q.Q.data[0]);
+      if (st != RKH_OK) return st;
+      q.Q.pop();
     }
   }
   return RKH_OK;
@@ -495,7 +542,7 @@ rkh_status rkh_rrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_rr
       StarProblem& q = p->prob[i];
       if (q.state == ST_GENERATE) {
         GraphBatch::Verdicts nb;
-        st = gb.verdicts(i, q.pos.data(), q.p_new.data(), &nb);
+        st = gb.verdicts(i, q.pos.data(), q.p_new.data(), &nb, q.removed.data());
         if (st != RKH_OK) return st;
         const uint32_t K = nb.K;
         const uint32_t* kidx = nb.id.data();
@@ -524,8 +571,21 @@ rkh_status rkh_rrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_rr
         }
         if (gen_done) {
           q.near_seq.push_back(q.x_near);
-          if (q.x_near == NIL || q.dist[q.x_near] == inf) next_iteration(q);  // rrt_star.hpp:181-182
-          else q.state = ST_CONNECT;
+          if (q.x_near == NIL || q.dist[q.x_near] == inf) {
+            next_iteration(q);  // rrt_star.hpp:181-182
+          } else if (p->branch_and_bound) {
+            // branch_and_bound_connector::operator() (:284-293): a point that cannot lie on a better path is dropped
+            const double dist_from_start = euclid(&q.pos[0], q.p_new.data(), D);
+            q.dist_to_goal = euclid(q.p_new.data(), &q.pos[size_t(1) * D], D);
+            if (q.pred[1] != NIL && dist_from_start + q.dist_to_goal > q.dist[1]) {
+              ++q.skipped;
+              next_iteration(q);
+            } else {
+              q.state = ST_CONNECT;
+            }
+          } else {
+            q.state = ST_CONNECT;
+          }
         }
       } else if (q.state == ST_CONNECT) {
         add_vertex(D, q, q.p_new.data(), inf, NIL);          // rrt_conn_visitor::create_vertex
@@ -551,7 +611,34 @@ rkh_status rkh_rrtstar_solve(rkh_rrtstar* p, int64_t max_loop_iterations, rkh_rr
       o.rewires = q.rewires;
       o.edges_checked = q.edges_checked;
       o.best_cost = q.best_cost;
+      o.pruned = q.pruned;
+      o.skipped = q.skipped;
     }
+  return RKH_OK;
+}
+
+// USE_BRANCH_AND_BOUND_PRUNING_FLAG (rrtstar_path_planner.tpp:270-283): generate_bnb_rrt_star instead of
+// generate_rrt_star; to be chosen before the first rkh_rrtstar_solve
+rkh_status rkh_rrtstar_set_branch_and_bound(rkh_rrtstar* p, int enabled) {
+  if (!p || p->bidirectional) return RKH_ERR_BAD_ARG;
+  for (const StarProblem& q : p->prob)
+    if (q.loop_iterations != 0) {
+      set_error("rkh_rrtstar_set_branch_and_bound: the planner has already run");
+      return RKH_ERR_BAD_ARG;
+    }
+  p->branch_and_bound = enabled != 0;
+  for (StarProblem& q : p->prob) {
+    q.Q.greater = true;
+    q.Q.key = &q.key;
+  }
+  return RKH_OK;
+}
+
+// removed[num_vertices]: 1 for the vertices taken out of the graph (branch-and-bound pruning)
+rkh_status rkh_rrtstar_get_removed(rkh_rrtstar* p, uint32_t problem, uint8_t* removed) {
+  if (!p || problem >= p->P || !removed) return RKH_ERR_BAD_ARG;
+  const StarProblem& q = p->prob[problem];
+  std::memcpy(removed, q.removed.data(), q.removed.size());
   return RKH_OK;
 }
 

@@ -35,7 +35,7 @@ class SingularityError(RkhError):
 class RrtStarStats(C.Structure):
     _fields_ = [("num_vertices", C.c_uint64), ("samples", C.c_uint64), ("loop_iterations", C.c_uint64),
                 ("num_solutions", C.c_uint64), ("rewires", C.c_uint64), ("edges_checked", C.c_uint64),
-                ("best_cost", C.c_double)]
+                ("best_cost", C.c_double), ("pruned", C.c_uint64), ("skipped", C.c_uint64)]
 
 
 class PrmStats(C.Structure):
@@ -73,7 +73,7 @@ EXPORTS = [
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
     "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_create_batch", "rkh_birrtstar_create_qs_batch", "rkh_birrtstar_solve",
-    "rkh_birrtstar_get_graph", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
+    "rkh_birrtstar_get_graph", "rkh_rrtstar_set_branch_and_bound", "rkh_rrtstar_get_removed", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
     "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_create_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph", "rkh_birrt_create_qs_batch", "rkh_birrt_destroy", "rkh_birrt_solve", "rkh_birrt_get_trees", "rkh_planner_get_solution", "rkh_rrtstar_get_solution", "rkh_birrt_get_solution",
 ]
 
@@ -141,6 +141,8 @@ def load():
     lib.rkh_rrtstar_destroy.argtypes = [vp]
     lib.rkh_rrtstar_solve.argtypes = [vp, C.c_int64, C.POINTER(RrtStarStats)]
     lib.rkh_rrtstar_get_graph.argtypes = [vp, u32, dp, u32p, dp, u32p]
+    lib.rkh_rrtstar_set_branch_and_bound.argtypes = [vp, C.c_int]
+    lib.rkh_rrtstar_get_removed.argtypes = [vp, u32, C.POINTER(C.c_uint8)]
     lib.rkh_birrtstar_solve.argtypes = [vp, C.c_int64, C.POINTER(BiRrtStarStats)]
     lib.rkh_birrtstar_get_graph.argtypes = [vp, u32, dp, u32p, dp, u32p, dp, u32p, u32p]
     lib.rkh_prm_create_qs_batch.argtypes = [vp, C.POINTER(T.QsSpace), C.POINTER(T.PrmParams), u32, C.POINTER(vp)]
@@ -555,6 +557,15 @@ class RrtStarPlanner:
     def solve_planning_query(self, max_loop_iterations=-1):
         _check(self.lib.rkh_rrtstar_solve(self.h, int(max_loop_iterations), self.all_stats))
         return self.all_stats[0]
+
+    def set_branch_and_bound(self, enabled=True):
+        """USE_BRANCH_AND_BOUND_PRUNING_FLAG: branch_and_bound_connector instead of lazy_node_connector."""
+        _check(self.lib.rkh_rrtstar_set_branch_and_bound(self.h, 1 if enabled else 0))
+
+    def removed(self, problem=0):
+        out = np.zeros(int(self.all_stats[problem].num_vertices), dtype=np.uint8)
+        _check(self.lib.rkh_rrtstar_get_removed(self.h, problem, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
 
     def solution(self, problem=0):
         n, cost = C.c_uint32(), C.c_double()

@@ -501,6 +501,34 @@ def test_bidirectional_rrtstar_graph_identical_to_sequential_planner(L, ctx, ora
     pl.close(); pl2.close()
 
 
+@pytest.mark.parametrize("scene,seed,iterations", [("c4", 2, 1500), ("c4", 1, 1500), ("c1", 1, 4000)])
+def test_rrtstar_with_branch_and_bound_pruning_identical_to_sequential_planner(L, ctx, oracle, scene, seed, iterations):
+    """USE_BRANCH_AND_BOUND_PRUNING_FLAG: points that cannot improve on the best solution are dropped, vertices whose
+    cost + distance to the goal exceeds it are removed from the graph (tombstones in the device NN store).  With
+    uniform sampling almost every point is dropped once the goal is connected (reference behaviour), so the runs are
+    ended by their iteration budget."""
+    scn = scenarios.make_c4(world_seed=1) if scene == "c4" else scenarios.make_c1(world_seed=1)
+    sc, osc = L.Scene(ctx, scn), oracle.OracleScene(scn)
+    lo, hi, mi = scn.meta["lower"], scn.meta["upper"], scn.meta["min_interval"]
+    prm = scn.rrt_params(seed=seed, max_vertices=1500)
+    rc, rout, rg, rpruned, rskipped = osc.bnb_rrtstar_qs(lo, hi, mi, prm, max_loop_iterations=iterations)
+    pl = L.RrtStarPlanner(sc, prm, L.make_qs_space(scn.n_dof, lo, hi, mi))
+    pl.set_branch_and_bound(True)
+    st = pl.solve_planning_query(max_loop_iterations=iterations)
+    g = pl.graph()
+    assert (st.num_vertices, st.samples, st.loop_iterations, st.num_solutions, st.rewires, st.edges_checked, st.pruned,
+            st.skipped) == (rout.num_vertices, rout.samples, rout.loop_iterations, rout.num_solutions, rout.rewires,
+                            rout.edges_checked, rpruned, rskipped)
+    assert st.pruned >= 4 and st.skipped > 1000 and st.num_solutions >= 2
+    for key in ("near_seq", "pred", "pos", "dist"):
+        assert np.array_equal(g[key], rg[key]), key
+    assert np.array_equal(pl.removed(), rg["removed"]) and rg["removed"].sum() == st.pruned
+    assert st.best_cost == rout.best_cost
+    with pytest.raises(L.RkhError):
+        pl.set_branch_and_bound(False)   # only before the first solve
+    pl.close()
+
+
 def test_rrtstar_batch_of_seeds(L, ctx, oracle):
     c1 = scenarios.make_c1(world_seed=1)
     sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
