@@ -618,3 +618,82 @@ def test_planar_chain_kinematics_and_cull_sequence(oracle):
     d_rev = oracle.OracleScene(mk([link, near, far])).min_distance(np.zeros((1, 2)))[0]
     assert d_seq == pytest.approx(0.01, rel=1e-9)
     assert d_rev == pytest.approx(-0.05, rel=1e-9)
+
+
+def _walk_cost(pos, link, start_root):
+    """Sum of straight-line lengths along predecessor (or successor) links down to the root."""
+    out = np.full(len(link), np.inf)
+    for v in range(len(link)):
+        u, total, hops = v, 0.0, 0
+        while link[u] != 0xFFFFFFFF and u != start_root and hops <= len(link):
+            total += np.sqrt(((pos[u] - pos[link[u]]) ** 2).sum())
+            u = link[u]
+            hops += 1
+        if u == start_root:
+            out[v] = total
+    return out
+
+
+def test_bidirectional_rrtstar_restatement_bookkeeping(oracle):
+    """generate_rrt_star_bidir: both trees are trees (every linked vertex reaches its root), the accumulated costs are
+    the sums of the edge weights along them (an edge's weight is the distance travelled: within the 5 % connection
+    tolerance of the straight line), the quirks the header documents hold (no vertex is ever the goal's predecessor;
+    joining vertices carry both links) and the run is reproducible."""
+    c1 = scenarios.make_c1(world_seed=1)
+    osc = oracle.OracleScene(c1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    prm = c1.rrt_params(seed=4, max_vertices=400)
+    rc, out, g = osc.birrtstar_qs(lo, hi, mi, prm)
+    rc2, out2, g2 = osc.birrtstar_qs(lo, hi, mi, prm)
+    assert rc == 0 and all(np.array_equal(g[k], g2[k]) for k in g)
+    pos, pred, succ = g["pos"], g["pred"].astype(np.int64), g["succ"].astype(np.int64)
+    NIL = 0xFFFFFFFF
+    assert pred[0] == 0 and succ[1] == 1 and pred[1] == NIL and succ[0] == NIL      # the two roots never join the other tree
+    assert g["dist"][0] == 0.0 and g["fwd_dist"][1] == 0.0
+    straight = _walk_cost(pos, np.where(pred == np.arange(len(pred)), NIL, pred), 0)
+    has_pred = pred != NIL
+    assert np.all(np.isfinite(straight[has_pred]))                                   # every forward vertex reaches the start
+    assert np.all(g["dist"][has_pred] <= straight[has_pred] + 1e-9) and np.all(g["dist"][has_pred] >= straight[has_pred] / 1.05 - 1e-9)
+    back = _walk_cost(pos, np.where(succ == np.arange(len(succ)), NIL, succ), 1)
+    has_succ = succ != NIL
+    assert np.all(np.isfinite(back[has_succ]))
+    assert np.all(g["fwd_dist"][has_succ] <= back[has_succ] + 1e-9) and np.all(g["fwd_dist"][has_succ] >= back[has_succ] / 1.05 - 1e-9)
+    both = has_pred & has_succ
+    assert out.joins > 50 and both.sum() > 50
+    # recorded when a vertex is created with both links; later rewiring only lowers the costs
+    assert out.best_join_cost >= (g["dist"] + g["fwd_dist"])[both].min() - 1e-12
+    assert (g["near_pred"] != NIL).any() and (g["near_succ"] != NIL).any()
+
+
+def test_move_position_back_to_returns_its_start_when_the_walk_completes(oracle):
+    """interp_topo_move_position_back_to_pred (interpolated_topologies.hpp:165-191) as written: through the generator's
+    retract step a walk back that meets no obstacle yields distance 0 and is never accepted, so on an obstacle-free scene
+    the backward tree only grows through connect_best_successor / connect_predecessors."""
+    c1 = scenarios.make_c1(world_seed=1)
+    free = scenarios.make_c1(world_seed=1)
+    free.shapes = [s for s in free.shapes if s.anchor >= 0]       # robot shapes only: nothing to collide with
+    osc = oracle.OracleScene(free)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    rc, out, g = osc.birrtstar_qs(lo, hi, mi, free.rrt_params(seed=2, max_vertices=150))
+    assert rc == 0 and (g["near_succ"] == 0xFFFFFFFF).all()       # retract_from_nearest never succeeded
+    assert (g["near_pred"] != 0xFFFFFFFF).sum() > 100 and (g["succ"] != 0xFFFFFFFF).sum() > 50
+
+
+def test_branch_and_bound_restatement_bookkeeping(oracle):
+    """generate_bnb_rrt_star: after the first solution no live vertex has cost + distance to the goal above the goal's
+    cost at the time it was last keyed, removed vertices are exactly the pruned ones, dropped points create no vertex."""
+    c4 = scenarios.make_c4(world_seed=1)
+    osc = oracle.OracleScene(c4)
+    lo, hi, mi = c4.meta["lower"], c4.meta["upper"], c4.meta["min_interval"]
+    prm = c4.rrt_params(seed=2, max_vertices=1500)
+    rc, out, g, pruned, skipped = osc.bnb_rrtstar_qs(lo, hi, mi, prm, max_loop_iterations=1200)
+    assert rc == 0 and g["removed"].sum() == pruned and pruned > 10 and skipped > 500
+    assert out.loop_iterations == 1200 and out.num_vertices + skipped <= 2 + 1200
+    # a solution is registered when the NEXT vertex is added (vertex_added tests the goal), so the last improvement of the
+    # goal's cost may not be registered yet
+    assert g["pred"][1] != 0xFFFFFFFF and out.num_solutions >= 2 and out.best_cost >= g["dist"][1]
+    live = np.flatnonzero((g["removed"] == 0) & (g["pred"] != 0xFFFFFFFF))
+    live = live[live > 1]
+    bound = g["dist"][live] + np.sqrt(((g["pos"][live] - g["pos"][1]) ** 2).sum(axis=1))
+    # keys only move when update_successors touches a vertex, so a few live vertices may sit above the final cost; most do not
+    assert (bound <= g["dist"][1] + 1e-9).mean() > 0.8
