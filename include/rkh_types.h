@@ -105,13 +105,19 @@ typedef struct rkh_dyn_space {
 } rkh_dyn_space;
 
 /* manip_quasi_static_env (ctrl/topologies/manip_free_workspace.hpp:113-300) over a hyperbox joint space with linear
- * interpolation: points are joint positions (D = n_dof), edges are walked in min_interval steps. */
+ * interpolation: points are joint positions (D = n_dof), edges are walked in min_interval steps.
+ * speed_limits: the space may be the RATE-LIMITED joint space the reference's manipulator environments plan in
+ * (Ndof_rl_space, ctrl/topologies/Ndof_spaces.hpp; joint_limits_collection::map_to_space, joint_space_limits.tpp:62-84):
+ * a point holds reach times t_i = q_i / gen_speed_limits[i] (joint_space_limits_detail.hpp:1552-1561), hyperbox, metric
+ * and interpolation live in those coordinates, and the model is evaluated at q_i = t_i * gen_speed_limits[i]
+ * (:1868-1875) before every proximity test.  0 (or 1) = an ordinary joint space. */
 typedef struct rkh_qs_space {
   int32_t n_dof;
   int32_t pad;
   double min_interval;
   double lower[RKH_MAX_DOF];
   double upper[RKH_MAX_DOF];
+  double speed_limits[RKH_MAX_DOF];
 } rkh_qs_space;
 
 /* sample_based_planner options (ctrl/path_planning/motion_planner_base.hpp:400-422) and the

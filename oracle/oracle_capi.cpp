@@ -278,6 +278,21 @@ double orc_pair_distance(const rkh_shape* a, const rkh_shape* b) {
   return computeProximity(f[0], g).mDistance;
 }
 
+// rate-limited joint space (Ndof_rl_space): speed limits for the quasi-static spaces created from now on (empty = none)
+static std::vector<double> g_qs_speed;
+static QuasiStaticSpace make_qs(Scene* s, int D, const double* lower, const double* upper, double min_interval) {
+  QuasiStaticSpace sp;
+  sp.D = D;
+  sp.lower.assign(lower, lower + D);
+  sp.upper.assign(upper, upper + D);
+  sp.min_interval = min_interval;
+  sp.speed.assign(D, 1.0);
+  for (int i = 0; i < D && i < int(g_qs_speed.size()); ++i)
+    if (g_qs_speed[i] != 0.0) sp.speed[i] = g_qs_speed[i];
+  sp.chain = s->chain;
+  sp.env = s->env;
+  return sp;
+}
 static DynSpace make_dyn(Scene* s, const rkh_dyn_space* P) {
   DynSpace sp;
   sp.P = *P;
@@ -362,17 +377,14 @@ int orc_rrt_dyn(void* h, const rkh_dyn_space* P, const rkh_rrt_params* prm, int6
   fill_out(g_last, sp.env.n_pair_tests, secs, out);
   return 0;
 }
+void orc_set_qs_speed_limits(const double* speed, int n) {
+  g_qs_speed.assign(speed, speed + (speed ? n : 0));
+}
 // RRT over the quasi-static joint space (positions only, D = n_dof)
 int orc_rrt_qs(void* h, int D, const double* lower, const double* upper, double min_interval,
                const rkh_rrt_params* prm, int64_t max_iterations, OrcRrtOut* out) {
   Scene* s = static_cast<Scene*>(h);
-  QuasiStaticSpace sp;
-  sp.D = D;
-  sp.lower.assign(lower, lower + D);
-  sp.upper.assign(upper, upper + D);
-  sp.min_interval = min_interval;
-  sp.chain = s->chain;
-  sp.env = s->env;
+  QuasiStaticSpace sp = make_qs(s, D, lower, upper, min_interval);
   auto t0 = std::chrono::steady_clock::now();
   generate_rrt(sp, *prm, long(max_iterations), g_last);
   double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -383,13 +395,7 @@ int orc_rrt_qs(void* h, int D, const double* lower, const double* upper, double 
 void orc_qs_move(void* h, int D, const double* lower, const double* upper, double min_interval, const double* a,
                  const double* b, int B, double fraction, double* out, uint32_t* n_checked) {
   Scene* s = static_cast<Scene*>(h);
-  QuasiStaticSpace sp;
-  sp.D = D;
-  sp.lower.assign(lower, lower + D);
-  sp.upper.assign(upper, upper + D);
-  sp.min_interval = min_interval;
-  sp.chain = s->chain;
-  sp.env = s->env;
+  QuasiStaticSpace sp = make_qs(s, D, lower, upper, min_interval);
   for (int i = 0; i < B; ++i) {
     Point ai(a + std::size_t(i) * D, a + std::size_t(i + 1) * D), bi(b + std::size_t(i) * D, b + std::size_t(i + 1) * D);
     long before = sp.cnt.states_checked;
@@ -407,13 +413,7 @@ static RrtStarResult g_last_star;
 int orc_rrtstar_qs(void* h, int D, const double* lower, const double* upper, double min_interval,
                    const rkh_rrt_params* prm, int64_t max_loop_iterations, OrcRrtStarOut* out) {
   Scene* s = static_cast<Scene*>(h);
-  QuasiStaticSpace sp;
-  sp.D = D;
-  sp.lower.assign(lower, lower + D);
-  sp.upper.assign(upper, upper + D);
-  sp.min_interval = min_interval;
-  sp.chain = s->chain;
-  sp.env = s->env;
+  QuasiStaticSpace sp = make_qs(s, D, lower, upper, min_interval);
   auto t0 = std::chrono::steady_clock::now();
   generate_rrt_star(sp, *prm, long(max_loop_iterations), g_last_star);
   out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -461,13 +461,7 @@ int orc_bnb_rrtstar_qs(void* h, int D, const double* lower, const double* upper,
                        const rkh_rrt_params* prm, int64_t max_loop_iterations, OrcRrtStarOut* out, uint64_t* pruned,
                        uint64_t* skipped) {
   Scene* s = static_cast<Scene*>(h);
-  QuasiStaticSpace sp;
-  sp.D = D;
-  sp.lower.assign(lower, lower + D);
-  sp.upper.assign(upper, upper + D);
-  sp.min_interval = min_interval;
-  sp.chain = s->chain;
-  sp.env = s->env;
+  QuasiStaticSpace sp = make_qs(s, D, lower, upper, min_interval);
   auto t0 = std::chrono::steady_clock::now();
   generate_bnb_rrt_star(sp, *prm, long(max_loop_iterations), g_last_bnb);
   g_last_star = g_last_bnb.g;
@@ -501,13 +495,7 @@ static BiRrtStarResult g_last_bistar;
 int orc_birrtstar_qs(void* h, int D, const double* lower, const double* upper, double min_interval,
                      const rkh_rrt_params* prm, int64_t max_loop_iterations, OrcBiRrtStarOut* out) {
   Scene* s = static_cast<Scene*>(h);
-  QuasiStaticSpace sp;
-  sp.D = D;
-  sp.lower.assign(lower, lower + D);
-  sp.upper.assign(upper, upper + D);
-  sp.min_interval = min_interval;
-  sp.chain = s->chain;
-  sp.env = s->env;
+  QuasiStaticSpace sp = make_qs(s, D, lower, upper, min_interval);
   auto t0 = std::chrono::steady_clock::now();
   generate_rrt_star_bidir(sp, *prm, long(max_loop_iterations), g_last_bistar);
   out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -545,13 +533,7 @@ static PrmResult g_last_prm;
 int orc_prm_qs(void* h, int D, const double* lower, const double* upper, double min_interval,
                const rkh_prm_params* prm, int64_t max_loop_iterations, OrcPrmOut* out) {
   Scene* s = static_cast<Scene*>(h);
-  QuasiStaticSpace sp;
-  sp.D = D;
-  sp.lower.assign(lower, lower + D);
-  sp.upper.assign(upper, upper + D);
-  sp.min_interval = min_interval;
-  sp.chain = s->chain;
-  sp.env = s->env;
+  QuasiStaticSpace sp = make_qs(s, D, lower, upper, min_interval);
   auto t0 = std::chrono::steady_clock::now();
   generate_prm(sp, *prm, long(max_loop_iterations), g_last_prm);
   out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -612,13 +594,7 @@ static BiRrtResult g_last_birrt;
 int orc_birrt_qs(void* h, int D, const double* lower, const double* upper, double min_interval, const rkh_rrt_params* prm,
                  int64_t max_loop_iterations, OrcBiRrtOut* out) {
   Scene* s = static_cast<Scene*>(h);
-  QuasiStaticSpace sp;
-  sp.D = D;
-  sp.lower.assign(lower, lower + D);
-  sp.upper.assign(upper, upper + D);
-  sp.min_interval = min_interval;
-  sp.chain = s->chain;
-  sp.env = s->env;
+  QuasiStaticSpace sp = make_qs(s, D, lower, upper, min_interval);
   auto t0 = std::chrono::steady_clock::now();
   generate_bidirectional_rrt(sp, *prm, long(max_loop_iterations), g_last_birrt);
   out->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -150,6 +150,10 @@ struct QuasiStaticSpace {
   int D = 0;
   std::vector<double> lower, upper;
   double min_interval = 0.1;
+  // rate-limited joint space (Ndof_rl_space): the point holds q_i / speed_limit_i, the model is evaluated at
+  // point_i * speed_limit_i (joint_space_limits_detail.hpp:1552-1561,1868-1875; manip_free_workspace.hpp: apply_to_model
+  // maps the point to the normal joint space first); empty = an ordinary joint space
+  std::vector<double> speed;
   KteChain chain;
   ProxyEnv env;
   SpaceCounters cnt;
@@ -161,7 +165,7 @@ struct QuasiStaticSpace {
     ++cnt.states_checked;
     if (!hyperbox_is_in_bounds(p.data(), lower.data(), upper.data(), D)) return false;
     std::vector<double> x(2 * D, 0.0);
-    for (int i = 0; i < D; ++i) x[2 * i] = p[i];
+    for (int i = 0; i < D; ++i) x[2 * i] = speed.empty() ? p[i] : p[i] * speed[i];
     chain.apply_kinematics(x.data());
     return env.is_free(chain);
   }

@@ -278,6 +278,7 @@ struct GraphBatch {
     std::memset(&qs, 0, sizeof(qs));
     qs.min_interval = space->min_interval;
     qs.fraction = 1.0;
+    qs_set_speed(qs, space->speed_limits, space->n_dof);
     for (int d = 0; d < space->n_dof; ++d) {
       qs.lower[d] = space->lower[d];
       qs.upper[d] = space->upper[d];

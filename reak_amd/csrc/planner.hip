@@ -768,6 +768,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     std::memset(&p->qs, 0, sizeof(p->qs));
     p->qs.min_interval = qspace->min_interval;
     p->qs.fraction = 1.0;
+    qs_set_speed(p->qs, qspace->speed_limits, qspace->n_dof);
     for (int d = 0; d < p->D; ++d) {
       p->lower[d] = p->qs.lower[d] = qspace->lower[d];
       p->upper[d] = p->qs.upper[d] = qspace->upper[d];

@@ -904,6 +904,7 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
   const double b_d = (gl < N) ? io.tgt[trow * io.tgt_stride + gl] : 0.0;
   const double lo = (gl < N) ? qs.lower[gl] : 0.0;
   const double hi = (gl < N) ? qs.upper[gl] : 0.0;
+  const double speed = (gl < N) ? qs.speed[gl] : 1.0;  // rate-limited space: the model sees point * speed limit
   for (int t = gl; t < 2 * N; t += GL) ws.x[t] = 0.0;  // velocities stay zero (apply_to_model writes positions only)
   __syncthreads();
   const CPack<N> cp = load_cpack<N>(lds.joints, lane);
@@ -920,7 +921,7 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
   };
   if (io.mode == EDGE_POINT) {
     // is_free(target): hyperbox bounds, then proximity (manip_free_workspace.hpp:79-99,154-156); group 0 tests it
-    if (gl < N) ws.x[2 * gl] = b_d;
+    if (gl < N) ws.x[2 * gl] = b_d * speed;
     bool oob = false;
     if (gl < N) {
       if (lo < hi) oob = (b_d < lo) || (b_d > hi);
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
       const bool valid = my < dist_inter;
       if (!__any(valid)) break;
       const double pt = a_d + (b_d - a_d) * (my / dist_tot);
-      if (gl < N) ws.x[2 * gl] = pt;
+      if (gl < N) ws.x[2 * gl] = pt * speed;
       bool oob = false;
       if (gl < N) {
         if (lo < hi) oob = (pt < lo) || (pt > hi);

@@ -231,7 +231,11 @@ enum EdgeMode : int {
 struct QsDev {  // manip_quasi_static_env on the device (passed by value)
   double min_interval, fraction;
   double lower[kMaxDof], upper[kMaxDof];
+  double speed[kMaxDof];  // joint = point * speed (rate-limited joint space; 1.0 otherwise)
 };
+inline void qs_set_speed(QsDev& qs, const double* speed_limits, int n) {
+  for (int i = 0; i < kMaxDof; ++i) qs.speed[i] = (speed_limits && i < n && speed_limits[i] != 0.0) ? speed_limits[i] : 1.0;
+}
 
 struct EdgeIO {  // inputs / outputs of one propagate launch (all device pointers)
   const double* src = nullptr;         // source rows

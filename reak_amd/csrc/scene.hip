@@ -756,6 +756,7 @@ rkh_status rkh_edge_check(rkh_scene* scene, const double* lower, const double* u
   std::memset(&qs, 0, sizeof(qs));
   qs.min_interval = min_interval;
   qs.fraction = fraction;
+  qs_set_speed(qs, nullptr, n);  // this entry point takes an ordinary joint space
   for (int i = 0; i < n; ++i) {
     qs.lower[i] = lower[i];
     qs.upper[i] = upper[i];

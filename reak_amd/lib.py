@@ -362,13 +362,15 @@ class Scene:
             pass
 
 
-def make_qs_space(n_dof, lower, upper, min_interval):
+def make_qs_space(n_dof, lower, upper, min_interval, speed_limits=None):
+    """rkh_qs_space; speed_limits makes it the rate-limited joint space (points = joint / speed limit)."""
     q = T.QsSpace()
     q.n_dof = n_dof
     q.min_interval = float(min_interval)
     for i in range(n_dof):
         q.lower[i] = float(lower[i])
         q.upper[i] = float(upper[i])
+        q.speed_limits[i] = 0.0 if speed_limits is None else float(speed_limits[i])
     return q
 
 

@@ -72,7 +72,8 @@ class DynSpace(C.Structure):
 
 class QsSpace(C.Structure):
     _fields_ = [("n_dof", C.c_int32), ("pad", C.c_int32), ("min_interval", C.c_double),
-                ("lower", C.c_double * RKH_MAX_DOF), ("upper", C.c_double * RKH_MAX_DOF)]
+                ("lower", C.c_double * RKH_MAX_DOF), ("upper", C.c_double * RKH_MAX_DOF),
+                ("speed_limits", C.c_double * RKH_MAX_DOF)]
 
 
 class RrtParams(C.Structure):

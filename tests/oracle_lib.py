@@ -366,6 +366,17 @@ def pair_distance(a, b):
     return lib.orc_pair_distance(C.byref(a), C.byref(b))
 
 
+def set_qs_speed_limits(speed, fast=False):
+    """Speed limits of the rate-limited joint space for the quasi-static spaces created from now on (None = ordinary)."""
+    lib = load(fast)
+    lib.orc_set_qs_speed_limits.argtypes = [C.POINTER(C.c_double), C.c_int]
+    if speed is None:
+        lib.orc_set_qs_speed_limits(None, 0)
+    else:
+        sp = np.ascontiguousarray(speed, dtype=np.float64)
+        lib.orc_set_qs_speed_limits(T.dptr(sp), len(sp))
+
+
 def nn1(q, pts, fast=False):
     lib = load(fast)
     q = np.ascontiguousarray(q, dtype=np.float64)

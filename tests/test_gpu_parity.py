@@ -529,6 +529,53 @@ def test_rrtstar_with_branch_and_bound_pruning_identical_to_sequential_planner(L
     pl.close()
 
 
+def test_rate_limited_joint_space(L, ctx, oracle):
+    """The reference's manipulator environments plan in the rate-limited joint space (Ndof_rl_space): a point holds
+    reach times q_i / speed_limit_i, the hyperbox, the metric and the interpolation live in those coordinates and the
+    model is posed at point_i * speed_limit_i.  RRT* and PRM graphs against the oracle, and the space's is_free against
+    the ordinary distance query at the mapped configuration."""
+    c1 = scenarios.make_c1(world_seed=1)
+    sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
+    speed = np.array([2.0, 0.5, 1.25])
+    lo, hi, mi = np.asarray(c1.meta["lower"]) / speed, np.asarray(c1.meta["upper"]) / speed, c1.meta["min_interval"]
+    qs = L.make_qs_space(3, lo, hi, mi, speed_limits=speed)
+    prm = c1.rrt_params(seed=3, max_vertices=600)
+    for d in range(3):
+        prm.start[d] /= speed[d]
+        prm.goal[d] /= speed[d]
+    oracle.set_qs_speed_limits(speed)
+    try:
+        rc, rout, rg = osc.rrtstar_qs(lo, hi, mi, prm)
+        pprm = c1.prm_params(seed=4, max_vertices=300, sampling_radius=0.8)
+        for d in range(3):
+            pprm.base.start[d] /= speed[d]
+            pprm.base.goal[d] /= speed[d]
+        rc2, pout, pg = osc.prm_qs(lo, hi, mi, pprm)
+    finally:
+        oracle.set_qs_speed_limits(None)
+    pl = L.RrtStarPlanner(sc, prm, qs)
+    st = pl.solve_planning_query()
+    g = pl.graph()
+    assert (st.num_vertices, st.samples, st.rewires, st.edges_checked) == (rout.num_vertices, rout.samples, rout.rewires,
+                                                                            rout.edges_checked)
+    for key in ("near_seq", "pred", "pos", "dist"):
+        assert np.array_equal(g[key], rg[key]), key
+    pp = L.PrmPlanner(sc, pprm, qs)
+    _prm_same(pp.solve_planning_query(), pp.graph(), pout, pg)
+    # the vertices are free where the model is posed at point * speed (all but the odd end point: a completed walk
+    # returns its target without testing it, interpolated_topologies.hpp:146-160), and the plain joint-space planner on
+    # the same seed builds a different tree (the metric is another one)
+    x = np.zeros((len(g["pos"]), 6)); x[:, 0::2] = g["pos"] * speed
+    d = sc.min_distance(x)
+    assert (d >= 0.0).mean() > 0.98 and d.min() > -0.05
+    x[:, 0::2] = g["pos"]   # posed at the raw reach times instead, many of the same points collide
+    assert (sc.min_distance(x) < 0.0).sum() > 2 * (d < 0.0).sum()
+    plain = L.RrtStarPlanner(sc, c1.rrt_params(seed=3, max_vertices=600), L.make_qs_space(3, c1.meta["lower"], c1.meta["upper"], mi))
+    plain.solve_planning_query()
+    assert not np.allclose(plain.graph()["pos"][2:50] , g["pos"][2:50] * speed)
+    pl.close(); pp.close(); plain.close()
+
+
 def test_rrtstar_batch_of_seeds(L, ctx, oracle):
     c1 = scenarios.make_c1(world_seed=1)
     sc, osc = L.Scene(ctx, c1), oracle.OracleScene(c1)
