@@ -613,7 +613,14 @@ def main():
         # (oracle/flop_count.cpp, mean over sampled states) + 20 proximity tests (not counted).  The reference's operation
         # order forbids FMA contraction, so the usable peak is one operation per lane and cycle = half of the 78.6 TFLOP/s
         # FMA figure.
-        if tot["steer_ms"] > 0:
+        # the per-round HIP events stop after 8192 rounds per planner (planner.hip kProfRounds): beyond that the NN / steer
+        # figures would cover a prefix of the run only while the work counters cover all of it -- say so instead
+        profiled_all = tot["steer_launches"] >= tot["rounds"]
+        out["profile_coverage"] = {"rounds": tot["rounds"], "profiled_rounds": tot["steer_launches"], "complete": profiled_all}
+        if not profiled_all:
+            for k in ("roofline", "nn_sweep_mfma_timed"):
+                out[k]["note"] = "INCOMPLETE: only the first profiled_rounds rounds were timed (profile_coverage); " + out[k]["note"]
+        if tot["steer_ms"] > 0 and profiled_all:
             fe = feval_ops(scn)
             ops_per_edge = 20 * 4 * fe["useful"]
             rate = tot["spec"] * ops_per_edge / (tot["steer_ms"] * 1e-3) / 1e12
