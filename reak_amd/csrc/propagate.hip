@@ -875,27 +875,49 @@ __global__ __launch_bounds__(64) void state_derivative_kernel(const SceneDev* __
 // Kernel: quasi-static edge walk interp_topo_move_position_toward_pred
 // (ctrl/interpolation/interpolated_topologies.hpp:137-163) over joint positions (D = N), with
 // manip_quasi_static_env::is_free (manip_free_workspace.hpp:154-156) as the predicate.
-// One wave per edge; its four 16-lane groups test four consecutive interpolation points at a time
-// (the points of a straight edge are independent), and a ballot finds the first colliding one.
+// One block of W waves per edge; its (64 / GL) W lane groups test that many consecutive interpolation points at a time
+// (the points of a straight edge are independent), and the first colliding one is found from the groups' verdicts.
 // dist_cur is accumulated by repeated addition exactly like the reference loop (":157 dist_cur += min_interval"),
-// so the number of tested points is the same integer.
-template <int N>
-__global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __restrict__ sc,
+// so the number of tested points is the same integer.  Three shapes of the same code (launch_edge_check):
+//   GL = 16, W = 1  -- a launch with thousands of edges (the batch planner's rounds) fills the machine with one wave per
+//                      edge, 4 points at a time, each 16-lane group running the chain kinematics once for its point;
+//   GL = 16, W = 4  -- a few hundred to a few thousand edges (a step of a batch of graph planners): 16 points at a time;
+//   GL = 64, W = 16 -- a few hundred edges (a step of one or a few graph planners): the machine is empty and the step
+//                      waits for the longest edge, so a whole wave scans the shape pairs of ONE point (300 pairs in
+//                      5 passes instead of 19) and 16 waves take 16 points at a time.  A single-problem RRT* spent 85 %
+//                      of its time in this kernel at 230 us per launch with one wave per edge.
+template <int N, int GL, int W>
+struct BlockLdsQsW {
+  JointLds joints[N];
+  double base[10];
+  double sink[64][4];     // dummy store targets of the non-leading lanes (never read; shared by the waves)
+  GroupWsQs<N> g[(64 / GL) * W];
+  double pts[(64 / GL) * W][N];   // the groups' interpolation points (space coordinates)
+  uint32_t masks[W];      // per wave: bit t = group t's point lies on the edge, bit 4 + t = it passed the predicate
+};
+template <int N, int GL, int W>
+struct SmemLayoutQsW {
+  static constexpr size_t block_bytes = (sizeof(BlockLdsQsW<N, GL, W>) + 15) / 16 * 16;
+  static size_t bytes(int n_env) { return block_bytes + size_t(n_env) * sizeof(ShapeDev); }
+};
+template <int N, int GL, int W>
+__global__ __launch_bounds__(64 * W) void edge_check_kernel(const SceneDev* __restrict__ sc,
                                                             const PairDev* __restrict__ pairs, int n_pairs, QsDev qs,
                                                             EdgeIO io_a, EdgeIO io_b, const EdgeIO* __restrict__ tab_a,
                                                             const EdgeIO* __restrict__ tab_b, uint32_t grid_a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int GL = 16, G = 4;
-  BlockLdsQs<N, GL>& lds = *reinterpret_cast<BlockLdsQs<N, GL>*>(smem_raw);
-  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayoutQs<N, GL>::block_bytes);
+  constexpr int GPW = 64 / GL, G = GPW * W;  // groups per wave, groups (= points per pass) of the block
+  BlockLdsQsW<N, GL, W>& lds = *reinterpret_cast<BlockLdsQsW<N, GL, W>*>(smem_raw);
+  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayoutQsW<N, GL, W>::block_bytes);
   const bool group_b = blockIdx.x >= grid_a;
   const EdgeIO io = tab_a ? (group_b ? tab_b[blockIdx.y] : tab_a[blockIdx.y]) : (group_b ? io_b : io_a);
   const uint32_t B = io.d_B ? *io.d_B : io.B;
   const uint32_t e = group_b ? blockIdx.x - grid_a : blockIdx.x;
   if (e >= B) return;
-  const int lane = threadIdx.x;
-  const int g = lane / GL, gl = lane % GL, gb = g * GL;
-  stage_chain<N>(sc, lds.joints, lds.base, lane);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = tid / GL, gl = lane % GL, gb = (lane / GL) * GL;  // group of the block, lane of the group, its base lane in the wave
+  stage_chain<N>(sc, lds.joints, lds.base, lane);  // (every wave writes the same values)
   stage_env(sc, env_lds, lane);
   GroupWsQs<N>& ws = lds.g[g];
   const uint32_t si = io.src_idx ? io.src_idx[e] : ((io.d_src_first ? *io.d_src_first : 0u) + e);
@@ -928,13 +950,13 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
       else oob = (b_d > lo) || (b_d < hi);
     }
     const unsigned long long mo = __ballot(oob);
-    const bool group_oob = ((mo >> gb) & 0xFFFFull) != 0ull;
+    const bool group_oob = (GL == 64 ? mo : ((mo >> gb) & ((1ull << (GL & 63)) - 1ull))) != 0ull;
     __syncthreads();
     const double dmin = proximity_min<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true,
                                              g != 0 || group_oob);
     const bool is_free = !group_oob && !(dmin < 0.0);
     if (g == 0 && gl < N) io.x_out[uint64_t(e) * N + gl] = b_d;
-    if (lane == 0) {
+    if (tid == 0) {
       io.steps_free[e] = 1;
       io.accept[e] = is_free ? 1 : 0;
     }
@@ -955,45 +977,60 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
     double last_result = a_d;  // last point that passed the predicate
     bool collided = false;
     for (;;) {
-      double my = cur;
+      // dist_cur of this group's point and of the block's first and last ones: cur + min_interval, repeatedly
+      double my = cur, last = cur;
 #pragma unroll
-      for (int t = 0; t < G; ++t)
+      for (int t = 0; t < G; ++t) {
         if (t <= g) my = my + qs.min_interval;
+        last = last + qs.min_interval;
+      }
+      if (!((cur + qs.min_interval) < dist_inter)) break;  // not even the first point is on the edge (block-uniform)
       const bool valid = my < dist_inter;
-      if (!__any(valid)) break;
       const double pt = a_d + (b_d - a_d) * (my / dist_tot);
-      if (gl < N) ws.x[2 * gl] = pt * speed;
+      if (gl < N) {
+        ws.x[2 * gl] = pt * speed;
+        lds.pts[g][gl] = pt;
+      }
       bool oob = false;
       if (gl < N) {
         if (lo < hi) oob = (pt < lo) || (pt > hi);
         else oob = (pt > lo) || (pt < hi);
       }
       const unsigned long long mo = __ballot(oob);
-      const bool group_oob = ((mo >> gb) & 0xFFFFull) != 0ull;
+      const bool group_oob = (GL == 64 ? mo : ((mo >> gb) & ((1ull << (GL & 63)) - 1ull))) != 0ull;
       __syncthreads();
       const double dmin = proximity_min<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true,
                                                !valid || group_oob);
       const bool is_free = valid && !group_oob && !(dmin < 0.0);
-      // group masks (bit g): valid / free
-      const unsigned long long mv = __ballot(valid && gl == 0), mf = __ballot(is_free && gl == 0);
+      {  // the wave's verdicts -> LDS, then every thread scans the block's groups in edge order
+        const unsigned long long mv = __ballot(valid && gl == 0), mf = __ballot(is_free && gl == 0);
+        uint32_t m = 0;
+#pragma unroll
+        for (int t = 0; t < GPW; ++t)
+          m |= (uint32_t((mv >> ((t * GL) & 63)) & 1ull) << t) | (uint32_t((mf >> ((t * GL) & 63)) & 1ull) << (4 + t));
+        if (lane == 0) lds.masks[wave] = m;
+      }
+      __syncthreads();
       int first_bad = G;  // first valid group whose point fails the predicate
       int n_valid = 0;
 #pragma unroll
       for (int t = G - 1; t >= 0; --t) {
-        const bool v = (mv >> (t * GL)) & 1ull, f = (mf >> (t * GL)) & 1ull;
+        const uint32_t m = lds.masks[t / GPW];
+        const bool v = (m >> (t % GPW)) & 1u, f = (m >> (4 + (t % GPW))) & 1u;
         if (v && !f) first_bad = t;
         if (v) n_valid = n_valid > t + 1 ? n_valid : t + 1;
       }
       if (first_bad < G) {
         n_checked += uint32_t(first_bad + 1);
-        if (first_bad > 0) last_result = __shfl(pt, (first_bad - 1) * GL + gl, 64);
+        if (first_bad > 0 && gl < N) last_result = lds.pts[first_bad - 1][gl];
         collided = true;
         break;
       }
       n_checked += uint32_t(n_valid);
-      last_result = __shfl(pt, (n_valid - 1) * GL + gl, 64);
+      if (gl < N) last_result = lds.pts[n_valid - 1][gl];
       if (n_valid < G) break;  // reached dist_inter without a collision
-      cur = __shfl(my, (G - 1) * GL + gl, 64);
+      cur = last;
+      __syncthreads();         // the points and verdicts are rewritten by the next pass
     }
     completed_walk = !collided;
     if (collided) result = last_result;
@@ -1002,7 +1039,7 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
     else result = a_d + (b_d - a_d) * fraction;
   }
   if (g == 0 && gl < N) io.x_out[uint64_t(e) * N + gl] = result;
-  if (lane == 0) io.steps_free[e] = n_checked;
+  if (tid == 0) io.steps_free[e] = n_checked;
   if (io.mode != EDGE_PLAIN) {
     const double n_ar = norm_n(a_d - result);
     const double n_ab = dist_tot;
@@ -1014,18 +1051,18 @@ __global__ __launch_bounds__(64, 2) void edge_check_kernel(const SceneDev* __res
       // EDGE_STEER_BOTH: bit 1 = the walk completed.  steer_back_to_position(target, source) walks the same points
       // (move_position_back_to, interpolated_topologies.hpp:165-191) and returns the same point unless the walk
       // completes, where it returns the source itself (:185-186): its verdict is bit 0 && !bit 1.
-      if (lane == 0) io.accept[e] = (ok ? 1 : 0) | ((io.mode == EDGE_STEER_BOTH && completed_walk) ? 2 : 0);
+      if (tid == 0) io.accept[e] = (ok ? 1 : 0) | ((io.mode == EDGE_STEER_BOTH && completed_walk) ? 2 : 0);
     } else if (io.mode == EDGE_GOAL_PROBE) {
       // interp_topo_get_distance_pred (interpolated_topologies.hpp:193-199)
-      if (lane == 0) io.goal_dist[si - 1] = (n_rb < DBL_EPSILON) ? n_ab : INFINITY;
+      if (tid == 0) io.goal_dist[si - 1] = (n_rb < DBL_EPSILON) ? n_ab : INFINITY;
     } else if (io.mode == EDGE_CONNECT) {
       // planning_visitor_base::can_be_connected (planning_visitors.hpp:385-395)
       const bool ok = (!isinf(n_ar)) && (n_rb < io.steer_tol * n_ar);  // steer_tol carries the connection tolerance
-      if (lane == 0) io.accept[e] = ok ? 1 : 0;
+      if (tid == 0) io.accept[e] = ok ? 1 : 0;
     } else if (io.mode == EDGE_WALK_ACCEPT) {
       // planning_visitor_base::random_walk (planning_visitors.hpp:418-421)
       const bool ok = (!isinf(n_ar)) && (n_ar > io.steer_tol * io.best_case[e]);
-      if (lane == 0) io.accept[e] = ok ? 1 : 0;
+      if (tid == 0) io.accept[e] = ok ? 1 : 0;
     }
   }
 }
@@ -1184,9 +1221,27 @@ rkh_status launch_edge_check(hipStream_t s, int n_dof, int n_env, const SceneDev
   if (grid_edges + eb == 0 || n_problems == 0) return RKH_OK;
   const EdgeIO second = io_b ? *io_b : EdgeIO();
   const PairDev* pp = static_cast<const PairDev*>(d_pairs);
-  RKH_DISPATCH_N_QS(n_dof, hipLaunchKernelGGL((edge_check_kernel<N>), dim3(grid_edges + eb, n_problems), dim3(64),
-                                           (SmemLayoutQs<N, 16>::bytes(n_env)), s, d_scene, pp, n_pairs, qs, io, second, tab_a,
-                                           tab_b, grid_edges));
+  // the shape of the launch (see edge_check_kernel): by the number of edges, and by what fits 64 KB of LDS
+  const uint64_t n_edges = uint64_t(grid_edges + eb) * n_problems;
+  int shape = 0;  // 0: GL 16 x 1 wave, 1: GL 16 x 4 waves, 2: GL 16 x 2 waves, 3: GL 16 x 8 waves
+  if (n_edges < 4096) {
+    RKH_DISPATCH_N_QS(n_dof, shape = (SmemLayoutQsW<N, 16, 4>::bytes(n_env) <= 65536) ? 1
+                                     : ((SmemLayoutQsW<N, 16, 2>::bytes(n_env) <= 65536) ? 2 : 0));
+  }
+  if (n_edges < 512) {
+    RKH_DISPATCH_N_QS(n_dof, shape = (SmemLayoutQsW<N, 16, 8>::bytes(n_env) <= 65536) ? 3 : shape);
+  }
+#define RKH_EDGE_LAUNCH(GL_, W_)                                                                                          \
+  RKH_DISPATCH_N_QS(n_dof, hipLaunchKernelGGL((edge_check_kernel<N, GL_, W_>), dim3(grid_edges + eb, n_problems),         \
+                                           dim3(64 * W_), (SmemLayoutQsW<N, GL_, W_>::bytes(n_env)), s, d_scene, pp, n_pairs, \
+                                           qs, io, second, tab_a, tab_b, grid_edges))
+  switch (shape) {
+    case 1: RKH_EDGE_LAUNCH(16, 4); break;
+    case 2: RKH_EDGE_LAUNCH(16, 2); break;
+    case 3: RKH_EDGE_LAUNCH(16, 8); break;
+    default: RKH_EDGE_LAUNCH(16, 1); break;
+  }
+#undef RKH_EDGE_LAUNCH
   RKH_HIP(hipGetLastError());
   return RKH_OK;
 }
