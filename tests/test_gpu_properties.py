@@ -105,8 +105,8 @@ def _components(n, eu, ev):
 
 def test_c3_rrtstar_at_two_hundred_thousand_vertices(L, ctx):
     """BASELINE config C3 (6-DOF chain, 50 obstacles, RRT* with k-NN rewiring) for one problem at the largest size that
-    fits a test run: 200 000 vertices (about 100 s; iterations are sequential, ~2 000 per second per problem, so the
-    configuration's 1 M vertices would take a quarter of an hour -- the 1 M k-NN sweep itself is covered by
+    fits a test run: 200 000 vertices (about 50 s; iterations are sequential, 3-4 000 per second per problem, so the
+    configuration's 1 M vertices would take several minutes -- the 1 M k-NN sweep itself is covered by
     test_nn_sweep_properties_at_one_million_vertices and bench.py's c3_rrtstar object).  The oracle's linear k-NN makes
     a comparison impractical here; checked are the invariants of the reference's bookkeeping."""
     c3 = scenarios.make_c3(world_seed=1)
