@@ -641,6 +641,11 @@ def main():
         # the microbenchmarks and the CPU baselines are single-GPU extras: rank 0 at N = 1 only
         if not args.no_microbench and world == 1:
             out["nn_sweep_hbm"] = nn_sweep_microbench(lib, ctx, events, 4 * 1024 * 1024, 8, 20)
+            # the same tree with fewer queries per sweep (8 queries are 288 fp64 operations per row: there the sweep is
+            # no longer purely bandwidth-bound)
+            out["nn_sweep_hbm"]["by_queries_per_sweep"] = {
+                str(b): {k: v for k, v in nn_sweep_microbench(lib, ctx, events, 4 * 1024 * 1024, b, 20).items()
+                         if k in ("ms_per_sweep", "achieved", "frac")} for b in (1, 4)}
             out["nn_sweep_mfma"] = nn_mfma_microbench(lib, ctx, events)
         if not args.no_microbench and world == 1:
             out["single_problem"] = [single_problem_rate(lib, scene, scn, 1, 20000),
