@@ -39,8 +39,9 @@ enum rkh_kte_kind {
   /* Planar chains (position level: quasi-static free spaces).  Poses are pose_2D<double> carried in rkh_pose as
    * pos[0..1] = Position and quat[0..1] = rot_mat_2D::q = (cos, sin) (core/kinetostatics/rotations_2D.hpp:89);
    * a chain is planar when its joints are REVOLUTE_JOINT_2D, and then all its links and shapes must be 2D. */
-  RKH_KTE_REVOLUTE_JOINT_2D = 7,    /* ctrl/mbd_kte/revolute_joint.cpp:30-56     : coord, base, end           */
-  RKH_KTE_RIGID_LINK_2D = 8         /* ctrl/mbd_kte/rigid_link.cpp:87-99         : base, end, pose offset     */
+  RKH_KTE_REVOLUTE_JOINT_2D = 7,    /* ctrl/mbd_kte/revolute_joint.cpp:30-97     : coord, base, end           */
+  RKH_KTE_RIGID_LINK_2D = 8,        /* ctrl/mbd_kte/rigid_link.cpp:87-128        : base, end, pose offset     */
+  RKH_KTE_INERTIA_2D = 9            /* ctrl/mbd_kte/inertia.cpp:60-87            : frame(end), mass, inertia[0] = mMomentOfInertia */
 };
 
 typedef struct rkh_kte_op {

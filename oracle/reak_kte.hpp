@@ -43,11 +43,12 @@ struct KteChain {
   int n_coords = 0, n_frames = 0;
   std::vector<GenCoord> coords;
   std::vector<Frame> frames;
-  std::vector<Pose2> frames2;   // planar chains: frame_2D Position / Rotation per frame index
+  std::vector<Frame2D> frames2; // planar chains: frame_2D per frame index
   bool planar = false;
   std::vector<double> drive;    // driving_actuator_gen::mDriveForce per coord (system input)
   std::vector<JacGen3D> jac;    // per coord: the revolute joint's mJacobian
-  std::vector<int> gen_inertias, inertias_3D;  // op indices, registration order of mass_matrix_calc
+  std::vector<int> gen_inertias, inertias_3D, inertias_2D;  // op indices, registration order of mass_matrix_calc
+  std::vector<JacGen2D> jac2;   // per coord: the revolute_joint_2D's mJacobian
   uint64_t feval_flops = 0;     // not used for parity; see count in DESIGN.md
 
   KteChain() {}
@@ -59,13 +60,15 @@ struct KteChain {
     }
     coords.assign(n_coords, GenCoord());
     frames.assign(n_frames, Frame());
-    frames2.assign(n_frames, Pose2());
+    frames2.assign(n_frames, Frame2D());
     for (const auto& op : ops) planar = planar || op.kind == RKH_KTE_REVOLUTE_JOINT_2D;
     drive.assign(n_coords, 0.0);
     jac.assign(n_coords, JacGen3D());
+    jac2.assign(n_coords, JacGen2D());
     for (int i = 0; i < n_ops; ++i) {
       if (ops[i].kind == RKH_KTE_INERTIA_GEN) gen_inertias.push_back(i);
       if (ops[i].kind == RKH_KTE_INERTIA_3D) inertias_3D.push_back(i);
+      if (ops[i].kind == RKH_KTE_INERTIA_2D) inertias_2D.push_back(i);
     }
     reset_base();
   }
@@ -76,7 +79,9 @@ struct KteChain {
     f.Q = Quat(base.pose.quat[0], base.pose.quat[1], base.pose.quat[2], base.pose.quat[3]);
     f.Acceleration = V3(base.acceleration[0], base.acceleration[1], base.acceleration[2]);
     frames[0] = f;
-    frames2[0] = to_pose2(base.pose);
+    frames2[0] = Frame2D();
+    static_cast<Pose2&>(frames2[0]) = to_pose2(base.pose);
+    frames2[0].Acceleration = V2(base.acceleration[0], base.acceleration[1]);  // gravity enters as base Acceleration
   }
 
   // kte_map_chain::doMotion: kte_map_chain.hpp:71-76
@@ -85,14 +90,30 @@ struct KteChain {
       switch (op.kind) {
         case RKH_KTE_REVOLUTE_JOINT_3D: revolute_doMotion(op); break;
         case RKH_KTE_RIGID_LINK_3D: link_doMotion(op); break;
-        case RKH_KTE_REVOLUTE_JOINT_2D:  // revolute_joint_2D::doMotion, revolute_joint.cpp:30-47 (pose part)
-          frames2[op.end_frame].Position = frames2[op.base_frame].Position;
-          frames2[op.end_frame].Rotation = frames2[op.base_frame].Rotation * rot_from_angle(coords[op.coord].q);
+        case RKH_KTE_REVOLUTE_JOINT_2D: {  // revolute_joint_2D::doMotion, revolute_joint.cpp:30-56
+          const Frame2D& B = frames2[op.base_frame];
+          Frame2D& E = frames2[op.end_frame];
+          E.Position = B.Position;
+          E.Velocity = B.Velocity;
+          E.Acceleration = B.Acceleration;
+          E.Rotation = B.Rotation * rot_from_angle(coords[op.coord].q);
+          E.AngVelocity = B.AngVelocity + coords[op.coord].q_dot;
+          E.AngAcceleration = B.AngAcceleration + coords[op.coord].q_ddot;
+          jac2[op.coord].Parent = op.end_frame;  // :50-55: qd_vel = 0, qd_avel = 1
+          jac2[op.coord].qd_vel = V2();
+          jac2[op.coord].qd_avel = 1.0;
           break;
-        case RKH_KTE_RIGID_LINK_2D: {  // rigid_link_2D::doMotion, rigid_link.cpp:87-99 (pose part)
+        }
+        case RKH_KTE_RIGID_LINK_2D: {  // rigid_link_2D::doMotion, rigid_link.cpp:87-99
           const Pose2 off = to_pose2(op.offset);
-          frames2[op.end_frame].Position = frames2[op.base_frame].Position + frames2[op.base_frame].Rotation * off.Position;
-          frames2[op.end_frame].Rotation = frames2[op.base_frame].Rotation * off.Rotation;
+          const Frame2D B = frames2[op.base_frame];
+          Frame2D& E = frames2[op.end_frame];
+          E.Position = B.Position + B.Rotation * off.Position;
+          E.Velocity = B.Velocity + B.Rotation * cross_sv(B.AngVelocity, off.Position);
+          E.Acceleration = B.Acceleration + B.Rotation * ((-B.AngVelocity * B.AngVelocity) * off.Position + cross_sv(B.AngAcceleration, off.Position));
+          E.Rotation = B.Rotation * off.Rotation;
+          E.AngVelocity = B.AngVelocity;
+          E.AngAcceleration = B.AngAcceleration;
           break;
         }
         default: break;  // inertia_*::doMotion (inertia.cpp:36-45,100-109) and actuators only store
@@ -104,7 +125,10 @@ struct KteChain {
     for (const auto& op : ops) {
       if (op.base_frame >= 0) { frames[op.base_frame].Force = V3(); frames[op.base_frame].Torque = V3(); }
       if (op.end_frame >= 0) { frames[op.end_frame].Force = V3(); frames[op.end_frame].Torque = V3(); }
-      if (op.coord >= 0 && (op.kind == RKH_KTE_REVOLUTE_JOINT_3D || op.kind == RKH_KTE_INERTIA_GEN))
+      if (op.base_frame >= 0) { frames2[op.base_frame].Force = V2(); frames2[op.base_frame].Torque = 0.0; }
+      if (op.end_frame >= 0) { frames2[op.end_frame].Force = V2(); frames2[op.end_frame].Torque = 0.0; }
+      if (op.coord >= 0 && (op.kind == RKH_KTE_REVOLUTE_JOINT_3D || op.kind == RKH_KTE_REVOLUTE_JOINT_2D ||
+                            op.kind == RKH_KTE_INERTIA_GEN))
         coords[op.coord].f = 0.0;
     }
   }
@@ -119,9 +143,46 @@ struct KteChain {
         case RKH_KTE_RIGID_LINK_3D: link_doForce(op); break;
         case RKH_KTE_INERTIA_3D: inertia_3D_doForce(op); break;
         case RKH_KTE_FLEXIBLE_BEAM_3D: beam_doForce(op); break;
+        case RKH_KTE_REVOLUTE_JOINT_2D: {  // revolute_joint_2D::doForce, revolute_joint.cpp:58-67: the end frame's torque
+          Frame2D& B = frames2[op.base_frame];  // goes to the joint coordinate only, nothing reaches the base's torque
+          const Frame2D& E = frames2[op.end_frame];
+          B.Force += rot_from_angle(coords[op.coord].q) * E.Force;
+          coords[op.coord].f += E.Torque;
+          break;
+        }
+        case RKH_KTE_RIGID_LINK_2D: {  // rigid_link_2D::doForce, rigid_link.cpp:104-106
+          const Pose2 off = to_pose2(op.offset);
+          Frame2D& B = frames2[op.base_frame];
+          const Frame2D& E = frames2[op.end_frame];
+          const V2 tmp_force = off.Rotation * E.Force;
+          B.Force += tmp_force;
+          B.Torque += E.Torque + cross_vv(off.Position, tmp_force);
+          break;
+        }
+        case RKH_KTE_INERTIA_2D: {  // inertia_2D::doForce, inertia.cpp:73-81 (getGlobalFrame of a parentless frame = itself)
+          Frame2D& F = frames2[op.end_frame];
+          F.Force -= op.mass * (F.Acceleration * F.Rotation);
+          F.Torque -= op.inertia[0] * F.AngAcceleration;
+          break;
+        }
         default: break;
       }
     }
+  }
+  // jacobian_gen_2D::get_jac_relative_to (motion_jacobians.hpp:138-146), velocity part.  Both frames hang off the global
+  // node, so getFrameRelativeTo is (~Parent) * aFrame (frame_2D.hpp:164-167, operator~ :350-359, operator* :287-300).
+  JacGen2D get_jac_relative_to_2D(const JacGen2D& J, int aFrame) const {
+    const Frame2D& Pf = frames2[J.Parent];
+    const Frame2D& A = frames2[aFrame];
+    const V2 inv_pos = (-Pf.Position) * Pf.Rotation;
+    const Rot2 inv_rot(Pf.Rotation.q[0], -Pf.Rotation.q[1]);  // invert = transpose (rotations_2D.hpp:389-391)
+    const V2 f2_pos = inv_pos + inv_rot * A.Position;
+    const Rot2 f2_rot = inv_rot * A.Rotation;
+    JacGen2D r;
+    r.Parent = aFrame;
+    r.qd_vel = (cross_sv(J.qd_avel, f2_pos) + J.qd_vel) * f2_rot;
+    r.qd_avel = J.qd_avel;
+    return r;
   }
 
   // flexible_beam_3D::doForce without an object frame: flexible_beam.cpp:155-193 (:176-186)
@@ -234,7 +295,11 @@ struct KteChain {
   // driving_actuator_gen::doForce: driving_actuator.cpp:31-39
   void actuator_doForce(const rkh_kte_op& op) {
     coords[op.coord].f += drive[op.coord];
-    revolute_applyReactionForce(ops[op.joint_op], drive[op.coord]);
+    const rkh_kte_op& joint = ops[op.joint_op];
+    if (joint.kind == RKH_KTE_REVOLUTE_JOINT_2D)  // revolute_joint_2D::applyReactionForce: revolute_joint.cpp:112-115
+      frames2[joint.base_frame].Torque -= drive[op.coord];
+    else
+      revolute_applyReactionForce(joint, drive[op.coord]);
   }
 
   // jacobian_gen_3D::get_jac_relative_to: motion_jacobians.hpp:238-251.  aFrame and the
@@ -262,7 +327,7 @@ struct KteChain {
   // "mat<symmetric> M = transpose(Tcm) * (Mcm * Tcm)" performs.
   void getMassMatrix(std::vector<double>& M) const {
     const int n = n_coords;
-    const int m = int(gen_inertias.size()) + 6 * int(inertias_3D.size());
+    const int m = int(gen_inertias.size()) + 3 * int(inertias_2D.size()) + 6 * int(inertias_3D.size());
     std::vector<double> Tcm(static_cast<std::size_t>(m) * n, 0.0);
     std::vector<double> Mcm(static_cast<std::size_t>(m) * m, 0.0);
     for (int i = 0; i < n; ++i) {
@@ -270,6 +335,15 @@ struct KteChain {
       for (int j : gen_inertias) {  // :117-130, jacobian_gen_gen(1.0, 0.0)::write_to_matrices
         if (ops[j].upstream & (1u << i)) Tcm[RowInd * n + i] = 1.0;
         RowInd++;
+      }
+      for (int j : inertias_2D) {  // :130-145, three rows per inertia_2D: (v_x, v_y, omega)
+        if (ops[j].upstream & (1u << i)) {
+          JacGen2D r = get_jac_relative_to_2D(jac2[i], ops[j].end_frame);
+          Tcm[(RowInd + 0) * n + i] = r.qd_vel[0];
+          Tcm[(RowInd + 1) * n + i] = r.qd_vel[1];
+          Tcm[(RowInd + 2) * n + i] = r.qd_avel;
+        }
+        RowInd += 3;
       }
       for (int j : inertias_3D) {  // :147-161
         if (ops[j].upstream & (1u << i)) {
@@ -284,6 +358,11 @@ struct KteChain {
     }
     int RowInd = 0;  // :262-285
     for (int j : gen_inertias) { Mcm[RowInd * m + RowInd] = ops[j].mass; RowInd++; }
+    for (int j : inertias_2D) {  // :275-279
+      Mcm[RowInd * m + RowInd] = ops[j].mass; RowInd++;
+      Mcm[RowInd * m + RowInd] = ops[j].mass; RowInd++;
+      Mcm[RowInd * m + RowInd] = ops[j].inertia[0]; RowInd++;
+    }
     for (int j : inertias_3D) {
       for (int k = 0; k < 3; ++k) { Mcm[RowInd * m + RowInd] = ops[j].mass; RowInd++; }
       const double* t = ops[j].inertia;

@@ -68,6 +68,20 @@ struct Pose2 {
   V2 rotateToParent(const V2& V) const { return Rotation * V; }                     // :149-151
   V2 rotateFromParent(const V2& V) const { return V * Rotation; }                   // :163-165
 };
+// 2D cross products (vect_alg.hpp:1142-1144, :1193-1198)
+inline double cross_vv(const V2& a, const V2& b) { return a[0] * b[1] - a[1] * b[0]; }
+// frame_2D<double>: core/kinetostatics/frame_2D.hpp (the kinematic and force fields on top of the pose)
+struct Frame2D : Pose2 {
+  V2 Velocity, Acceleration, Force;
+  double AngVelocity = 0.0, AngAcceleration = 0.0, Torque = 0.0;
+};
+// jacobian_gen_2D<double>: core/kinetostatics/motion_jacobians.hpp:114-137 (velocity part); Parent is a frame index
+struct JacGen2D {
+  int Parent = -1;
+  V2 qd_vel;
+  double qd_avel = 0.0;
+};
+
 inline Pose2 to_pose2(const rkh_pose& p) {
   Pose2 r;
   r.Position = V2(p.pos[0], p.pos[1]);

@@ -820,6 +820,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
       !(p->n_dof <= 7 && scene_fits_lane_kernel(scene->host, p->lanes_per_edge == 1 ? 1 : p->lane_variant)))
     p->lanes_per_edge = 64;  // the two-lanes-per-edge kernel does not take this scene
   if (p->lanes_per_edge == 16 && 2 * p->n_dof > 16) p->lanes_per_edge = 64;  // a 16-lane group holds at most 16 components
+  if (scene->host.planar) p->lanes_per_edge = 64;  // planar chains have one mapping (one lane per edge, propagate_planar.hip)
   if (const char* e = getenv("RKH_PROFILE_NN")) p->profile_nn = atoi(e) != 0;
   // candidates per round = batch_factor * sqrt(n): a single problem is latency-bound (bigger batches, fewer rounds), a
   // large batch of problems fills the chip anyway and prefers less discarded speculation (measured optimum 1.25)
@@ -978,8 +979,8 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
 rkh_status rkh_planner_create_batch(rkh_scene* scene, const rkh_dyn_space* space, const rkh_rrt_params* prms,
                                     uint32_t n_problems, rkh_planner** out) {
   if (!space) return RKH_ERR_BAD_ARG;
-  if (scene && scene->host.planar) {
-    set_error("planar (2D) chains are built at position level: quasi-static spaces only, no dynamics");
+  if (scene && scene->host.planar && !scene->host.planar_dynamics) {
+    set_error("this planar (2D) chain was given at position level (no actuators / inertias): quasi-static spaces only");
     return RKH_ERR_UNSUPPORTED;
   }
   return planner_create_common(scene, space, nullptr, prms, n_problems, out);

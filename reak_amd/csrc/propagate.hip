@@ -1186,6 +1186,9 @@ rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev*
                             uint32_t n_problems, double* d_lane_ws, KernelGate gate) {
   const uint32_t eb = (io_b || tab_b) ? grid_b : 0u;
   if (grid_edges + eb == 0 || n_problems == 0) return RKH_OK;
+  if (is_planar_scene(d_scene))  // planar chains: one lane per edge, whatever mapping was asked for (propagate_planar.hip)
+    return launch_propagate_planar(s, n_dof, d_scene, d_pairs, n_pairs, dyn, io, grid_edges, io_b, grid_b, tab_a, tab_b,
+                                   n_problems, gate);
   if (lanes_per_edge == 1)  // two lanes per edge, first generation (propagate_lane.hip)
     return launch_propagate_lanes(s, n_dof, d_scene, dyn, io, grid_edges, io_b, grid_b, tab_a, tab_b, n_problems, d_lane_ws,
                                   gate);
@@ -1208,6 +1211,7 @@ rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev*
 rkh_status launch_state_derivative(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x,
                                    const double* d_u, uint32_t B, double* d_pd, double* d_M, double* d_f, int* d_err) {
   if (B == 0) return RKH_OK;
+  if (is_planar_scene(d_scene)) return launch_state_derivative_planar(s, n_dof, d_scene, d_x, d_u, B, d_pd, d_M, d_f, d_err);
   RKH_DISPATCH_N(n_dof, hipLaunchKernelGGL((state_derivative_kernel<N>), dim3(B), dim3(64), 0, s, d_scene, d_x, d_u, B,
                                            d_pd, d_M, d_f, d_err));
   RKH_HIP(hipGetLastError());

@@ -136,6 +136,7 @@ struct SceneDev {
   int32_t n_branches;  // joints with branch_start (0 for a plain serial chain)
   int32_t beam_j1;     // the beam's anchor 1 is the link end frame of this joint
   int32_t beam_j2;     // anchor 2: link end frame of this joint, or -1 = the world anchor (beam_pos, beam_quat)
+  int32_t planar_dynamics;  // planar chain given with its actuators and inertias: the dynamics entry points accept it
   int32_t planar;      // 1: planar chain (revolute_joint_2D / rigid_link_2D, 2D shapes): poses carry (x, y) and (cos, sin)
   int32_t branch_first[kMaxDof];  // first joint of the branch joint j belongs to
   double mount_pos[kMaxDof][3];
@@ -304,6 +305,16 @@ uint32_t lane_kernel_edges_per_wave();
 // second-generation two-lanes-per-edge kernel (propagate_pair.hip): registers + DPP instead of LDS, two waves per SIMD.
 // Same edges per wave, same scenes (scene_fits_lane_kernel), same results.
 size_t propagate_pairs_workspace_bytes(int n_dof, uint32_t edges_a, uint32_t edges_b, uint32_t n_problems);
+// planar chains (propagate_planar.hip): one lane per edge; scenes register themselves at upload
+void register_planar_scene(const SceneDev* d_scene);
+void forget_planar_scene(const SceneDev* d_scene);
+bool is_planar_scene(const SceneDev* d_scene);
+rkh_status launch_propagate_planar(hipStream_t s, int n_dof, const SceneDev* d_scene, const void* d_pairs, int n_pairs,
+                                   const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges, const EdgeIO* io_b,
+                                   uint32_t grid_b, const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems,
+                                   KernelGate gate);
+rkh_status launch_state_derivative_planar(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x,
+                                          const double* d_u, uint32_t B, double* d_pd, double* d_M, double* d_f, int* d_err);
 rkh_status launch_propagate_pairs(hipStream_t s, int n_dof, const SceneDev* d_scene, const DynDev& dyn, const EdgeIO& io,
                                   uint32_t grid_edges, const EdgeIO* io_b, uint32_t grid_b, const EdgeIO* tab_a,
                                   const EdgeIO* tab_b, uint32_t n_problems, double* d_ws, KernelGate gate = KernelGate());

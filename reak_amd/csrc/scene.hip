@@ -172,6 +172,7 @@ static rkh_status upload_scene(rkh_ctx* ctx, rkh_scene* sc, const std::vector<Pa
   if (!pairs.empty()) RKH_HIP(hipMemcpy(sc->d_pairs, pairs.data(), pairs.size() * sizeof(PairDev), hipMemcpyHostToDevice));
   RKH_HIP(hipMalloc(&sc->d_err, sizeof(int)));
   RKH_HIP(hipMemset(sc->d_err, 0, sizeof(int)));
+  if (S.planar) register_planar_scene(sc->d_scene);
   *out = sc;
   return RKH_OK;
 }
@@ -180,9 +181,14 @@ static rkh_status upload_scene(rkh_ctx* ctx, rkh_scene* sc, const std::vector<Pa
 // Position level: the scene serves the quasi-static entry points; the dynamics entry points refuse it.
 static rkh_status create_planar_scene(rkh_ctx* ctx, const rkh_kte_op* prog, int n_ops, const rkh_chain_base* base,
                                       const rkh_shape* shapes, int n_shapes, rkh_scene** out) {
-  const int n = n_ops / 2;
-  if (n_ops % 2 != 0 || n < 1 || n > kMaxDof) {
-    set_error("rkh_scene_create: a planar chain is a sequence of {revolute_joint_2D, rigid_link_2D} pairs");
+  // position level: {revolute_joint_2D, rigid_link_2D} per joint; with dynamics: {driving_actuator_gen, inertia_gen,
+  // revolute_joint_2D, rigid_link_2D, inertia_2D on the link's end frame} per joint
+  const bool dynamics = prog[0].kind == RKH_KTE_DRIVING_ACTUATOR_GEN;
+  const int per = dynamics ? 5 : 2;
+  const int n = n_ops / per;
+  if (n_ops % per != 0 || n < 1 || n > kMaxDof) {
+    set_error("rkh_scene_create: a planar chain is a sequence of {revolute_joint_2D, rigid_link_2D} pairs, or of "
+              "{driving_actuator_gen, inertia_gen, revolute_joint_2D, rigid_link_2D, inertia_2D} groups");
     return RKH_ERR_UNSUPPORTED;
   }
   rkh_scene* sc = new rkh_scene();
@@ -191,23 +197,39 @@ static rkh_status create_planar_scene(rkh_ctx* ctx, const rkh_kte_op* prog, int 
   std::memset(&S, 0, sizeof(S));
   S.n_dof = n;
   S.planar = 1;
+  S.planar_dynamics = dynamics ? 1 : 0;
   for (int i = 0; i < 2; ++i) {
     S.base_pos[i] = base->pose.pos[i];
     S.base_quat[i] = base->pose.quat[i];
+    S.base_acc[i] = base->acceleration[i];
   }
   std::vector<int> joint_end_frame(n);
   int prev_end = 0;
   for (int j = 0; j < n; ++j) {
-    const rkh_kte_op& rev = prog[2 * j], &lnk = prog[2 * j + 1];
+    const rkh_kte_op& rev = prog[per * j + (dynamics ? 2 : 0)], &lnk = prog[per * j + (dynamics ? 3 : 1)];
     if (rev.kind != RKH_KTE_REVOLUTE_JOINT_2D || lnk.kind != RKH_KTE_RIGID_LINK_2D || rev.coord != j ||
         rev.base_frame != prev_end || lnk.base_frame != rev.end_frame) {
       delete sc;
-      set_error("rkh_scene_create: planar op pair " + std::to_string(j) + " does not continue the serial chain");
+      set_error("rkh_scene_create: planar op group " + std::to_string(j) + " does not continue the serial chain");
       return RKH_ERR_UNSUPPORTED;
+    }
+    JointDev& J = S.joints[j];
+    if (dynamics) {
+      const rkh_kte_op& act = prog[per * j], &gen = prog[per * j + 1], &in2 = prog[per * j + 4];
+      if (act.kind != RKH_KTE_DRIVING_ACTUATOR_GEN || act.coord != j || act.joint_op != per * j + 2 ||
+          gen.kind != RKH_KTE_INERTIA_GEN || gen.coord != j || gen.upstream != (1u << j) ||
+          in2.kind != RKH_KTE_INERTIA_2D || in2.end_frame != lnk.end_frame || in2.upstream != ((1u << (j + 1)) - 1u)) {
+        delete sc;
+        set_error("rkh_scene_create: planar op group " + std::to_string(j) +
+                  " is not {actuator, inertia_gen, revolute_joint_2D, rigid_link_2D, inertia_2D} of one serial joint");
+        return RKH_ERR_UNSUPPORTED;
+      }
+      J.joint_inertia = gen.mass;
+      J.mass = in2.mass;
+      J.inertia[0] = in2.inertia[0];
     }
     prev_end = lnk.end_frame;
     joint_end_frame[j] = rev.end_frame;
-    JointDev& J = S.joints[j];
     for (int i = 0; i < 2; ++i) {
       J.off_pos[i] = lnk.offset.pos[i];
       J.off_quat[i] = lnk.offset.quat[i];
@@ -295,7 +317,9 @@ rkh_status rkh_scene_create_with_meshes(rkh_ctx* ctx, const rkh_kte_op* prog, in
   if (n_mesh_vertices > 0 && !mesh_vertices) return RKH_ERR_BAD_ARG;
   g_mesh_vertices = mesh_vertices;  // for bounding_radius() / validation while the scene is built (one host thread per ctx)
   g_n_mesh_vertices = n_mesh_vertices;
-  if (prog[0].kind == RKH_KTE_REVOLUTE_JOINT_2D) return create_planar_scene(ctx, prog, n_ops, base, shapes, n_shapes, out);
+  if (prog[0].kind == RKH_KTE_REVOLUTE_JOINT_2D ||
+      (n_ops >= 3 && prog[0].kind == RKH_KTE_DRIVING_ACTUATOR_GEN && prog[2].kind == RKH_KTE_REVOLUTE_JOINT_2D))
+    return create_planar_scene(ctx, prog, n_ops, base, shapes, n_shapes, out);
   const bool has_beam = n_ops > 1 && prog[n_ops - 1].kind == RKH_KTE_FLEXIBLE_BEAM_3D;
   if (has_beam) --n_ops;  // the beam is validated below, after the chain
   // parse: [optional mount link from frame 0] {actuator, inertia_gen, revolute, link, inertia_3D} ...
@@ -576,6 +600,7 @@ rkh_status rkh_diag_gjk_distance(rkh_ctx* ctx, const rkh_shape* a, const rkh_sha
 
 rkh_status rkh_scene_destroy(rkh_scene* scene) {
   if (!scene) return RKH_OK;
+  forget_planar_scene(scene->d_scene);  // (a later allocation may get the same address)
   hipFree(scene->d_scene);
   hipFree(scene->d_pairs);
   if (scene->d_mesh_verts) hipFree(scene->d_mesh_verts);
@@ -596,8 +621,8 @@ struct DevBuf {  // scoped device scratch
 };
 // dynamics entry points: branching chains are fine (wave-per-edge kernels); planar chains are position level only
 rkh_status reject_branches(const rkh_scene* scene) {
-  if (scene->host.planar) {
-    set_error("planar (2D) chains are built at position level: quasi-static spaces only, no dynamics");
+  if (scene->host.planar && !scene->host.planar_dynamics) {
+    set_error("this planar (2D) chain was given at position level (no actuators / inertias): quasi-static spaces only");
     return RKH_ERR_UNSUPPORTED;
   }
   return RKH_OK;

@@ -270,7 +270,28 @@ def make_c1(world_seed=1, n_obstacles=10, min_interval=0.05):
     return scn
 
 
-def make_c1_planar(world_seed=1, n_obstacles=10, min_interval=0.05, link_width=0.08):
+def planar_chain_ops(lengths, dynamics=False, masses=None, moments=None, joint_inertias=None):
+    """kte_map_chain of a planar serial arm (manip_3R_arm.cpp:75-150): per joint {revolute_joint_2D, rigid_link_2D}, and
+    with dynamics {driving_actuator_gen, inertia_gen, revolute_joint_2D, rigid_link_2D, inertia_2D at the link's end}."""
+    ops = []
+    for j, length in enumerate(lengths):
+        if dynamics:
+            ops.append(T.KteOp(kind=T.KTE_DRIVING_ACTUATOR_GEN, coord=j, base_frame=-1, end_frame=-1, joint_op=5 * j + 2))
+            ops.append(T.KteOp(kind=T.KTE_INERTIA_GEN, coord=j, base_frame=-1, end_frame=-1, joint_op=-1, upstream=(1 << j),
+                               mass=float(joint_inertias[j])))
+        ops.append(T.KteOp(kind=T.KTE_REVOLUTE_JOINT_2D, coord=j, base_frame=2 * j, end_frame=2 * j + 1, joint_op=-1))
+        l = T.KteOp(kind=T.KTE_RIGID_LINK_2D, coord=-1, base_frame=2 * j + 1, end_frame=2 * j + 2, joint_op=-1)
+        l.offset = T.make_pose_2d((length, 0.0))
+        ops.append(l)
+        if dynamics:
+            i2 = T.KteOp(kind=T.KTE_INERTIA_2D, coord=-1, base_frame=-1, end_frame=2 * j + 2, joint_op=-1,
+                         upstream=(1 << (j + 1)) - 1, mass=float(masses[j]))
+            i2.inertia[0] = float(moments[j])
+            ops.append(i2)
+    return ops
+
+
+def make_c1_planar(world_seed=1, n_obstacles=10, min_interval=0.05, link_width=0.08, dynamics=False):
     """BASELINE config C1 with the reference's own 2D classes: the planar 3R arm of ctrl/kte_models/manip_3R_arm.cpp:45-152
     (revolute_joint_2D / rigid_link_2D, link lengths 0.5, 0.5, 0.3), links = capped_rectangle of width 0.08 anchored on
     the joints' end frames, obstacles = rectangle (0.2-0.5 m sides, centres uniform in [-1.5, 1.5]^2, uniform yaw),
@@ -278,12 +299,10 @@ def make_c1_planar(world_seed=1, n_obstacles=10, min_interval=0.05, link_width=0
     rng = np.random.Generator(np.random.PCG64(1000 + world_seed))
     lengths = [0.5, 0.5, 0.3]
     n = 3
-    ops, shapes = [], []
+    shapes = []
+    ops = planar_chain_ops(lengths, dynamics=dynamics, masses=[3.0, 2.0, 1.0], moments=[0.06, 0.04, 0.01],
+                           joint_inertias=[0.05, 0.04, 0.02])
     for j in range(n):
-        ops.append(T.KteOp(kind=T.KTE_REVOLUTE_JOINT_2D, coord=j, base_frame=2 * j, end_frame=2 * j + 1, joint_op=-1))
-        l = T.KteOp(kind=T.KTE_RIGID_LINK_2D, coord=-1, base_frame=2 * j + 1, end_frame=2 * j + 2, joint_op=-1)
-        l.offset = T.make_pose_2d((lengths[j], 0.0))
-        ops.append(l)
         s = T.Shape(kind=T.SHAPE_CRECT, anchor=2 * j + 1)
         s.pose = T.make_pose_2d((0.5 * lengths[j], 0.0))
         s.dims[:] = [lengths[j], link_width, 0.0]
@@ -307,8 +326,19 @@ def make_c1_planar(world_seed=1, n_obstacles=10, min_interval=0.05, link_width=0
         placed += 1
     dyn = T.DynSpace()
     dyn.n_dof = n
+    start, goal = np.zeros(n), np.array([np.pi / 2, 0.0, 0.0])
+    if dynamics:  # the steerable dynamic space over the planar arm (states (q, qd)), gravity along -y of the plane
+        base.acceleration[:] = [0.0, 9.81, 0.0]
+        dyn.steps_per_edge, dyn.dt = 20, 1e-3
+        dyn.kp, dyn.kd, dyn.u_max, dyn.goal_tol = 50.0, 10.0, 50.0, 1e-3
+        for j in range(n):
+            dyn.lower[2 * j], dyn.upper[2 * j] = -np.pi, np.pi
+            dyn.lower[2 * j + 1], dyn.upper[2 * j + 1] = -2.0, 2.0
+        s0, g0 = np.zeros(2 * n), np.zeros(2 * n)
+        s0[0::2], g0[0::2] = start, goal
+        start, goal = s0, g0
     return Scenario(name="C1-planar", ops=ops, base=base, shapes=shapes, dyn=dyn, n_dof=n, n_frames=2 * n + 1,
-                    start=np.zeros(n), goal=np.array([np.pi / 2, 0.0, 0.0]),
+                    start=start, goal=goal,
                     meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi), "min_interval": min_interval})
 
 

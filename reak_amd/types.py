@@ -16,6 +16,7 @@ KTE_INERTIA_3D = 5
 KTE_FLEXIBLE_BEAM_3D = 6
 KTE_REVOLUTE_JOINT_2D = 7
 KTE_RIGID_LINK_2D = 8
+KTE_INERTIA_2D = 9
 
 # rkh_shape_kind
 SHAPE_SPHERE = 1

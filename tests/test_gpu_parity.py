@@ -244,6 +244,65 @@ def test_state_derivative_c2(L, ctx, oracle, c2):
     assert np.array_equal(pd[:, 0::2], x[:, 1::2])  # q_dot rows are copies
 
 
+def test_planar_chain_dynamics(L, ctx, oracle):
+    """The 2D halves of the KTE rows: revolute_joint_2D / rigid_link_2D / inertia_2D doForce, the 2D rows of the mass
+    matrix, the steer loop and the planners over the planar arm's dynamic state space (one lane per edge,
+    propagate_planar.hip) against the oracle's 2D classes."""
+    scn = scenarios.make_c1_planar(world_seed=1, dynamics=True)
+    sc, osc = L.Scene(ctx, scn), oracle.OracleScene(scn)
+    rng = np.random.default_rng(21)
+    lo = np.array([scn.dyn.lower[i] for i in range(6)])
+    hi = np.array([scn.dyn.upper[i] for i in range(6)])
+    x = rng.uniform(lo, hi, size=(1000, 6))
+    u = rng.uniform(-50, 50, size=(1000, 3))
+    pd, M, f = sc.state_derivative(x, u)
+    rc, rpd, rM, rf = osc.state_derivative(x, u)
+    assert rc == 0
+    assert np.max(np.abs(M - rM)) <= 1e-13 * np.abs(rM).max()
+    assert np.allclose(f, rf, rtol=1e-11, atol=1e-11) and np.allclose(pd, rpd, rtol=1e-10, atol=1e-10)
+    assert np.array_equal(pd[:, 0::2], x[:, 1::2])
+    # steer: free starts, random targets; full edges and edges cut by obstacles / bounds
+    a = rng.uniform(lo, hi, size=(600, 6)) * 0.6
+    a[:, 0::2] = rng.uniform(-3.0, 3.0, size=(600, 3))
+    a = a[osc.min_distance(a) > 0.01][:256]
+    b = rng.uniform(lo, hi, size=(len(a), 6))
+    out, steps, rec = sc.steer_position_toward(a, b, record=True)
+    rc, rout, rsteps, rrec = osc.steer(a, b, record=True)
+    assert rc == 0 and np.array_equal(steps, rsteps)
+    assert np.allclose(out, rout, rtol=STATE_RTOL, atol=1e-12) and np.allclose(rec, rrec, rtol=STATE_RTOL, atol=1e-12)
+    assert steps.min() < 20 <= steps.max()
+    for fr in (0.0, 0.5):
+        o2, s2, _ = sc.steer_position_toward(a[:16], b[:16], fraction=fr)
+        rc, ro2, rs2, _ = osc.steer(a[:16], b[:16], fraction=fr)
+        assert np.array_equal(s2, rs2) and np.allclose(o2, ro2, rtol=STATE_RTOL, atol=1e-13)
+    # RRT over the dynamic space (batch planner), then RRT* over it (graph batch)
+    prm = scn.rrt_params(seed=2, max_vertices=800)
+    rc, rout, rtree = osc.rrt_dyn(prm)
+    pl = L.RrtPlanner(sc, prm)
+    st = pl.solve_planning_query()
+    tree = pl.tree()
+    assert rc == 0 and st.num_vertices == rout.num_vertices == 801 and st.iterations == rout.iterations
+    assert np.array_equal(tree["nn_seq"], rtree["nn_seq"]) and np.array_equal(tree["accept"], rtree["accept"])
+    assert np.array_equal(tree["parent"], rtree["parent"])
+    assert np.allclose(tree["pos"], rtree["pos"], rtol=STATE_RTOL, atol=1e-12)
+    pl.close()
+    prm = scn.rrt_params(seed=3, max_vertices=300)
+    prm.conn_tol = 3.0
+    rc, sout, rg = osc.rrtstar_dyn(prm)
+    ps = L.RrtStarPlanner(sc, prm, scn.dyn)
+    ss = ps.solve_planning_query()
+    g = ps.graph()
+    assert (ss.num_vertices, ss.samples, ss.rewires, ss.edges_checked) == (sout.num_vertices, sout.samples, sout.rewires,
+                                                                            sout.edges_checked)
+    assert np.array_equal(g["pred"], rg["pred"]) and np.array_equal(g["near_seq"], rg["near_seq"])
+    assert np.allclose(g["pos"], rg["pos"], rtol=STATE_RTOL, atol=1e-12)
+    ps.close()
+    # a planar chain given at position level still refuses the dynamics entry points
+    sq = L.Scene(ctx, scenarios.make_c1_planar(world_seed=1))
+    with pytest.raises(L.RkhError):
+        sq.state_derivative(x[:1], u[:1])
+
+
 def test_singular_mass_matrix_is_reported(L, ctx):
     scn = scenarios.make_pendulum(length=0.0, mass=0.0)  # M = 0 -> pivot < 1e-8 -> singularity_error
     sc = L.Scene(ctx, scn)

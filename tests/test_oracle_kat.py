@@ -696,3 +696,31 @@ def test_branch_and_bound_restatement_bookkeeping(oracle):
     # vertices whose key exceeds the FINAL cost can stay -- as in the reference)
     removed = np.flatnonzero(g["removed"])
     assert np.all(removed > 1)                                   # start and goal are never in the queue's reach
+
+
+def test_planar_dynamics_2d_classes_equal_the_3d_classes_on_the_same_mechanism(oracle):
+    """The 2D KTE restatement (revolute_joint_2D / rigid_link_2D / inertia_2D, the 2D rows of mass_matrix_calc) against
+    the 3D restatement, which is pinned by the reference's own cases: a planar 3R arm modelled with z-axis
+    revolute_joint_3D, links along x and inertia tensors (0, 0, I_zz) is the same mechanism, so mass matrix, bias forces
+    and accelerations must agree to rounding (both classes pass no joint-axis torque on to the base frame)."""
+    lengths, masses, moments, jin = [0.5, 0.5, 0.3], [3.0, 2.0, 1.0], [0.06, 0.04, 0.01], [0.05, 0.04, 0.02]
+    p2 = scenarios.make_c1_planar(world_seed=1, n_obstacles=0, dynamics=True)
+    ops3 = scenarios.serial_chain_ops([(0, 0, 1)] * 3, [(L_, 0, 0) for L_ in lengths], masses,
+                                      [(0, 0, 0, 0, 0, m) for m in moments], jin)
+    base3 = T.ChainBase()
+    base3.pose = T.make_pose()
+    base3.acceleration[:] = [0.0, 9.81, 0.0]
+    p3 = scenarios.Scenario(name="3d", ops=ops3, base=base3, shapes=[], dyn=p2.dyn, n_dof=3, n_frames=7,
+                            start=np.zeros(6), goal=np.zeros(6))
+    o2, o3 = oracle.OracleScene(p2), oracle.OracleScene(p3)
+    rng = np.random.default_rng(1)
+    x, u = rng.uniform(-2, 2, size=(200, 6)), rng.uniform(-20, 20, size=(200, 3))
+    rc2, pd2, M2, f2 = o2.state_derivative(x, u)
+    rc3, pd3, M3, f3 = o3.state_derivative(x, u)
+    assert rc2 == 0 and rc3 == 0
+    assert np.max(np.abs(M2 - M3)) < 1e-13 and np.max(np.abs(f2 - f3)) < 1e-12 and np.max(np.abs(pd2 - pd3)) < 1e-11
+    # and a closed form: at rest and stretched out along x under gravity g along +y, joint 3's bias torque is -m3 g (l3)
+    # ... with the inertia_2D on the link's END frame the lever arm of link 3's mass about joint 3 is l3
+    rc, pd, M, f = o2.state_derivative(np.zeros((1, 6)), np.zeros((1, 3)))
+    assert np.isclose(f[0, 2], -masses[2] * 9.81 * lengths[2], rtol=1e-14)
+    assert np.isclose(M[0, 2, 2], jin[2] + moments[2] + masses[2] * lengths[2] ** 2, rtol=1e-14)
