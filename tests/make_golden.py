@@ -69,6 +69,7 @@ def main():
     print("wrote", path, os.path.getsize(path), "bytes")
     make_c1_golden(scenarios.make_c1(world_seed=1), "c1_golden.npz")
     make_c1_golden(scenarios.make_c1_planar(world_seed=1), "c1_planar_golden.npz")
+    make_round2_golden()
 
 
 def make_c1_golden(c1, file_name):
@@ -98,6 +99,80 @@ def make_c1_golden(c1, file_name):
                prm_pos=g["pos"], prm_edge_u=g["edge_u"], prm_edge_v=g["edge_v"], prm_edge_w=g["edge_w"],
                prm_density=g["density"], prm_cc_root=g["cc_root"], prm_kind=g["kind"], prm_expanded=g["expanded"])
     path = os.path.join(ROOT, "tests", "golden", file_name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def round2_cases(osc_of):
+    """The planners added in round 2, small sizes: bidirectional RRT*, RRT* with branch-and-bound pruning, RRT* in the
+    rate-limited joint space (all C1), RRT* and PRM over the dynamic state space of the planar arm.  `osc_of(scn)` gives
+    the object with the oracle's call surface (the oracle itself, or the HIP path behind the same names)."""
+    out = {}
+    c1 = scenarios.make_c1(world_seed=1)
+    lo, hi, mi = c1.meta["lower"], c1.meta["upper"], c1.meta["min_interval"]
+    o = osc_of(c1)
+    c, g = o.birrtstar(lo, hi, mi, c1.rrt_params(seed=5, max_vertices=400))
+    out.update(bistar_counts=np.array(c, dtype=np.int64), bistar_pred=g["pred"], bistar_succ=g["succ"],
+               bistar_dist=g["dist"], bistar_fwd=g["fwd_dist"], bistar_pos=g["pos"])
+    c, g = o.bnb(lo, hi, mi, c1.rrt_params(seed=5, max_vertices=400), 1500)
+    out.update(bnb_counts=np.array(c, dtype=np.int64), bnb_pred=g["pred"], bnb_dist=g["dist"], bnb_pos=g["pos"],
+               bnb_removed=g["removed"])
+    speed = np.array([2.0, 0.5, 1.25])
+    prm = c1.rrt_params(seed=6, max_vertices=300)
+    for d in range(3):
+        prm.start[d] /= speed[d]
+        prm.goal[d] /= speed[d]
+    c, g = o.rrtstar_rl(np.asarray(lo) / speed, np.asarray(hi) / speed, mi, speed, prm)
+    out.update(rl_counts=np.array(c, dtype=np.int64), rl_pred=g["pred"], rl_dist=g["dist"], rl_pos=g["pos"])
+    pd = scenarios.make_c1_planar(world_seed=1, dynamics=True)
+    o = osc_of(pd)
+    prm = pd.rrt_params(seed=7, max_vertices=250)
+    prm.conn_tol = 3.0
+    c, g = o.rrtstar_dyn(prm)
+    out.update(dynstar_counts=np.array(c, dtype=np.int64), dynstar_pred=g["pred"], dynstar_pos=g["pos"],
+               dynstar_dist=g["dist"])
+    pp = pd.prm_params(seed=8, max_vertices=200, sampling_radius=1.0)
+    pp.base.conn_tol = 3.0
+    c, g = o.prm_dyn(pp)
+    out.update(dynprm_counts=np.array(c, dtype=np.int64), dynprm_pos=g["pos"], dynprm_edge_u=g["edge_u"],
+               dynprm_edge_v=g["edge_v"], dynprm_kind=g["kind"])
+    return out
+
+
+class OracleSurface:
+    """oracle_lib behind the call surface of round2_cases."""
+
+    def __init__(self, scn):
+        self.osc = oracle_lib.OracleScene(scn)
+
+    def birrtstar(self, lo, hi, mi, prm):
+        rc, o, g = self.osc.birrtstar_qs(lo, hi, mi, prm)
+        return [o.num_vertices, o.samples, o.loop_iterations, o.rewires, o.fwd_rewires, o.joins, o.edges_checked], g
+
+    def bnb(self, lo, hi, mi, prm, iters):
+        rc, o, g, pruned, skipped = self.osc.bnb_rrtstar_qs(lo, hi, mi, prm, max_loop_iterations=iters)
+        return [o.num_vertices, o.samples, o.loop_iterations, o.num_solutions, o.rewires, o.edges_checked, pruned, skipped], g
+
+    def rrtstar_rl(self, lo, hi, mi, speed, prm):
+        oracle_lib.set_qs_speed_limits(speed)
+        try:
+            rc, o, g = self.osc.rrtstar_qs(lo, hi, mi, prm)
+        finally:
+            oracle_lib.set_qs_speed_limits(None)
+        return [o.num_vertices, o.samples, o.loop_iterations, o.num_solutions, o.rewires, o.edges_checked], g
+
+    def rrtstar_dyn(self, prm):
+        rc, o, g = self.osc.rrtstar_dyn(prm)
+        return [o.num_vertices, o.samples, o.loop_iterations, o.num_solutions, o.rewires, o.edges_checked], g
+
+    def prm_dyn(self, pp):
+        rc, o, g = self.osc.prm_dyn(pp)
+        return [o.num_vertices, o.num_edges, o.samples, o.rejected, o.loop_iterations, o.num_components, o.edges_checked], g
+
+
+def make_round2_golden():
+    out = round2_cases(OracleSurface)
+    path = os.path.join(ROOT, "tests", "golden", "round2_planners_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 

@@ -159,3 +159,68 @@ def test_hip_reproduces_c1_golden(gold1):
     prm = ([st.num_vertices, st.num_edges, st.samples, st.rejected, st.loop_iterations, st.num_components, st.publish_calls,
             st.merged_at_vertex, st.edges_checked], pp.graph())
     _check_c1(gold1, walk, rrt, star, prm)
+
+
+# ------------------------------------------------------------------ round-2 planners
+STATE_KEYS = ("dynstar_pos", "dynstar_dist", "dynprm_pos")   # propagated states: fp64 to 1e-10 (device sincos), the rest exact
+
+
+def _check_round2(got):
+    gold = dict(np.load(os.path.join(os.path.dirname(GOLD_C1), "round2_planners_golden.npz"), allow_pickle=False))
+    assert set(got) == set(gold)
+    for k, v in gold.items():
+        if k in STATE_KEYS:
+            fin = np.isfinite(v)
+            assert np.array_equal(np.isfinite(got[k]), fin) and np.allclose(got[k][fin], v[fin], rtol=1e-9, atol=1e-12), k
+        else:
+            assert np.array_equal(got[k], v), k
+
+
+def test_oracle_reproduces_round2_golden(oracle):
+    import make_golden
+
+    _check_round2(make_golden.round2_cases(make_golden.OracleSurface))
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_round2_golden():
+    import make_golden
+    from reak_amd import lib as L
+
+    ctx = L.Context(0)
+
+    class HipSurface:
+        def __init__(self, scn):
+            self.scn, self.sc = scn, L.Scene(ctx, scn)
+
+        def birrtstar(self, lo, hi, mi, prm):
+            pl = L.BiRrtStarPlanner(self.sc, prm, L.make_qs_space(self.scn.n_dof, lo, hi, mi))
+            o = pl.solve_planning_query()
+            return [o.num_vertices, o.samples, o.loop_iterations, o.rewires, o.fwd_rewires, o.joins, o.edges_checked], pl.graph()
+
+        def bnb(self, lo, hi, mi, prm, iters):
+            pl = L.RrtStarPlanner(self.sc, prm, L.make_qs_space(self.scn.n_dof, lo, hi, mi))
+            pl.set_branch_and_bound(True)
+            o = pl.solve_planning_query(max_loop_iterations=iters)
+            g = pl.graph()
+            g["removed"] = pl.removed()
+            return [o.num_vertices, o.samples, o.loop_iterations, o.num_solutions, o.rewires, o.edges_checked, o.pruned,
+                    o.skipped], g
+
+        def rrtstar_rl(self, lo, hi, mi, speed, prm):
+            pl = L.RrtStarPlanner(self.sc, prm, L.make_qs_space(self.scn.n_dof, lo, hi, mi, speed_limits=speed))
+            o = pl.solve_planning_query()
+            return [o.num_vertices, o.samples, o.loop_iterations, o.num_solutions, o.rewires, o.edges_checked], pl.graph()
+
+        def rrtstar_dyn(self, prm):
+            pl = L.RrtStarPlanner(self.sc, prm, self.scn.dyn)
+            o = pl.solve_planning_query()
+            return [o.num_vertices, o.samples, o.loop_iterations, o.num_solutions, o.rewires, o.edges_checked], pl.graph()
+
+        def prm_dyn(self, pp):
+            pl = L.PrmPlanner(self.sc, pp, self.scn.dyn)
+            o = pl.solve_planning_query()
+            return [o.num_vertices, o.num_edges, o.samples, o.rejected, o.loop_iterations, o.num_components,
+                    o.edges_checked], pl.graph()
+
+    _check_round2(make_golden.round2_cases(HipSurface))
