@@ -822,9 +822,14 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   if (p->lanes_per_edge == 16 && 2 * p->n_dof > 16) p->lanes_per_edge = 64;  // a 16-lane group holds at most 16 components
   if (scene->host.planar) p->lanes_per_edge = 64;  // planar chains have one mapping (one lane per edge, propagate_planar.hip)
   if (const char* e = getenv("RKH_PROFILE_NN")) p->profile_nn = atoi(e) != 0;
-  // candidates per round = batch_factor * sqrt(n): a single problem is latency-bound (bigger batches, fewer rounds), a
-  // large batch of problems fills the chip anyway and prefers less discarded speculation (measured optimum 1.25)
-  float batch_factor = (n_problems >= 16) ? 1.25f : 2.0f;
+  // candidates per round = batch_factor * sqrt(n) per problem (results do not depend on it).  A round costs about the
+  // same until its edges fill the chip (~64k edges: 2048 resident steer waves of 32), so the factor is what brings a
+  // mid-run round (n = max_vertices / 2) of all problems to that fill -- between 1.25, the measured optimum once the
+  // chip is full anyway (less discarded speculation; 256 problems), and 4 (16 problems: 444k vs 322k expansions/s with
+  // 1.25).  A single problem is bound by the latency of one edge: 2 and 4 measure the same, 2 checks fewer edges.
+  double mid_sqrt_sum = 0.0;
+  for (uint32_t i = 0; i < n_problems; ++i) mid_sqrt_sum += std::sqrt(0.5 * double(prms[i].max_vertices));
+  float batch_factor = float(std::min(n_problems == 1 ? 2.0 : 4.0, std::max(1.25, 65536.0 / mid_sqrt_sum)));
   uint32_t b_min = 8;
   if (const char* e = getenv("RKH_BATCH_FACTOR")) batch_factor = float(atof(e));
   if (const char* e = getenv("RKH_BATCH_MIN")) b_min = std::max(1, atoi(e));
