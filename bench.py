@@ -18,8 +18,9 @@ Extra objects on the JSON line:
                 (profiles/r02_nn_planner_pmc.json).  In the planner a sweep serves hundreds of queries per tree, so the
                 kernel is bound by the (vertex, query) pair arithmetic, not by these bytes: see nn_sweep_mfma_timed.
   nn_sweep_mfma_timed  the same launches against the dense fp32 MFMA peak (24 flops per pair on the matrix cores)
-  nn_sweep_hbm  the fp64 sweep in its HBM-bound regime (tree larger than the 256 MiB Infinity Cache, 8 queries per
-                sweep), measured outside the timed region
+  nn_sweep_hbm  the sweep in its HBM-bound regime (tree larger than the 256 MiB Infinity Cache, 8 queries per sweep, the
+                cloud's hyperbox declared: matrix-core pre-filter in front of the exact fp64 test), measured outside the
+                timed region; beside it 1 / 4 / 32 queries per sweep and the all-fp64 sweep without a declared bound
   nn_sweep_mfma the matrix-core sweep alone on one 1 Mi-row tree
   steer_kernels the dominant kernels of the timed region: share of the step time, edges/s inside the kernel, fp64
                 operation rate against the no-FMA VALU peak with the EXACT operation count of one f-eval as the restated
@@ -77,11 +78,14 @@ class HipEvents:
         return float(ms.value)
 
 
-def nn_sweep_microbench(lib, ctx, events, n_rows, B, reps):
-    """HBM-bound regime of the NN sweep: n_rows x 12 fp64 (> 256 MiB), B queries per sweep."""
+def nn_sweep_microbench(lib, ctx, events, n_rows, B, reps, coord_bound=0.0):
+    """HBM-bound regime of the NN sweep: n_rows x 12 fp64 (> 256 MiB), B queries per sweep.  coord_bound > 0: the cloud's
+    hyperbox is declared (the unit cube here), which lets the sweep run its matrix-core pre-filter (same answers)."""
     D = 12
     nn = lib.HipNeighborSearch(ctx, D, n_rows)
     nn.fill_uniform(n_rows, seed=7)
+    if coord_bound > 0.0:
+        nn.set_coord_bound(coord_bound)
     import torch
 
     q = torch.rand(B, D, dtype=torch.float64, device="cuda")
@@ -102,7 +106,7 @@ def nn_sweep_microbench(lib, ctx, events, n_rows, B, reps):
     pmc = os.path.join(ROOT, "profiles", "r02_nn_sweep_pmc.json")
     if os.path.exists(pmc):  # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (same kernel, same n)
         rec = json.load(open(pmc))
-        if rec.get("n_rows") == n_rows and rec.get("queries_per_sweep") == B:
+        if rec.get("n_rows") == n_rows and rec.get("queries_per_sweep") == B and rec["kernel"].startswith(nn.kernel_name()):
             traffic = rec["hbm_bytes_per_launch"]
     name = nn.kernel_name()
     nn.close()
@@ -640,12 +644,17 @@ def main():
                                             "dense products over structural zeros"}
         # the microbenchmarks and the CPU baselines are single-GPU extras: rank 0 at N = 1 only
         if not args.no_microbench and world == 1:
-            out["nn_sweep_hbm"] = nn_sweep_microbench(lib, ctx, events, 4 * 1024 * 1024, 8, 20)
-            # the same tree with fewer queries per sweep (8 queries are 288 fp64 operations per row: there the sweep is
-            # no longer purely bandwidth-bound)
+            # the cloud's hyperbox (the unit cube) is declared, as a planner's topology does: from 5 queries per sweep on
+            # that selects the matrix-core pre-filter (same answers); up to 4 the register-direct fp64 sweep runs
+            rows = 4 * 1024 * 1024
+            out["nn_sweep_hbm"] = nn_sweep_microbench(lib, ctx, events, rows, 8, 20, coord_bound=1.0)
+            keep = ("kernel", "ms_per_sweep", "achieved", "frac")
             out["nn_sweep_hbm"]["by_queries_per_sweep"] = {
-                str(b): {k: v for k, v in nn_sweep_microbench(lib, ctx, events, 4 * 1024 * 1024, b, 20).items()
-                         if k in ("ms_per_sweep", "achieved", "frac")} for b in (1, 4)}
+                str(b): {k: v for k, v in nn_sweep_microbench(lib, ctx, events, rows, b, 20, coord_bound=1.0).items()
+                         if k in keep} for b in (1, 4, 32)}
+            # without a declared bound every sweep is exact fp64 arithmetic (8 queries: 288 operations per row)
+            out["nn_sweep_hbm"]["no_coordinate_bound"] = {
+                k: v for k, v in nn_sweep_microbench(lib, ctx, events, rows, 8, 20).items() if k in keep}
             out["nn_sweep_mfma"] = nn_mfma_microbench(lib, ctx, events)
         if not args.no_microbench and world == 1:
             out["single_problem"] = [single_problem_rate(lib, scene, scn, 1, 20000),

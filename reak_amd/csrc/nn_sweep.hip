@@ -807,6 +807,267 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
   }
 }
 
+// The matrix-core pre-filter for FEW queries per sweep (at most 32) over a LARGE tree with known coordinate bounds: the
+// HBM-bound regime.  The exact fp64 test costs 3 Dp - 1 VALU operations per (row, query) -- at 8 queries that is 3
+// operations per byte of the tree, and the register-direct fp64 sweep above stops at ~4.5 TB/s -- whereas the estimate
+// |x|^2 - 2 x.q of 32 rows x 32 query slots costs a wave Dp/2 + 1 matrix instructions and ~25 VALU instructions, so
+// the sweep runs at the speed the rows arrive.  No LDS tile and no block barrier in the loop: a wave streams its own
+// 32-row slabs, lane (r, h) = (l & 31, l >> 5) loads HALF of row r (coordinates [h Dp/2, (h + 1) Dp/2): Dp/4 16-byte
+// loads; the wave's loads together cover the slab's cache lines exactly once) and these registers ARE the A operands:
+// the k-index of instruction j is the lane half, so instruction j multiplies coordinate j (lanes 0-31) and Dp/2 + j
+// (lanes 32-63) with B = -2 q^ of the same coordinates.  The order in which the coordinates enter the sum only matters
+// to the rounding, which the band covers.  |x^|^2 enters through one more instruction (A = the lane's half of the sum of
+// squares, B = 1), so no lane ever needs another lane's registers.  Slabs are dealt round-robin to all waves of the grid
+// (at any time the grid reads one moving window of the tree), three slabs of a wave are in flight.
+// Candidates, band and the exact fp64 resolution are those of nn1_sweep_mfma_kernel (per-lane entry list in LDS; the
+// operation chain here has Dp + 2 fused steps and two Dp/2-step partial sums: 4 (Dp + 2) u Dp M'^2 bounds it).
+// Query slots past the batch start from a running minimum of -inf and never record anything.
+// The four waves of a block share their running minimum through one LDS word per query (ordered-integer ds_min when a
+// wave's own minimum improves, read back every slab): a running minimum over ANY rows of the tree keeps the candidate
+// argument intact, fewer entries are recorded, and after the sweep -- one barrier -- only the entries within the band of
+// the BLOCK's minimum are resolved (all coordinates of a row loaded at once: one memory round trip, the waves' tails
+// would otherwise be chains of five).  (Tried: the same word shared by the whole grid in HBM -- every wave polling one
+// cache line made the sweep five times slower.)  Bit-identical results.
+static constexpr int kFewQueries = 32;
+static constexpr int kFewThreads = 256;
+static constexpr int kFewDepth = 3;  // row buffers per wave (4 measured the same: the memory system is the limit)
+template <int DP>
+__global__ __launch_bounds__(kFewThreads, 4) void nn1_few_mfma_kernel(NnArgs single, const NnArgs* __restrict__ table,
+                                                                      int D, uint32_t Bpad, double coord_bound) {
+  constexpr int H = DP / 2;
+  constexpr int PD = kFewDepth;
+  constexpr int kWaves = kFewThreads / 64;
+  __shared__ uint32_t cand_key[kCandCap][kFewThreads];
+  __shared__ uint32_t cand_mask[kCandCap][kFewThreads];
+  __shared__ float cand_m[kCandCap][kFewThreads];
+  __shared__ double red_d[kWaves][kFewQueries];
+  __shared__ uint32_t red_i[kWaves][kFewQueries];
+  __shared__ uint32_t blk_min[kFewQueries];  // seed_encode of the block's running minimum per query slot
+
+  auto uniform64 = [](uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v)), hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+    return (uint64_t(hi) << 32) | lo;
+  };
+  const NnArgs a = table ? table[blockIdx.z] : single;
+  typedef const __attribute__((address_space(1))) double* nn_gdouble_p;
+  typedef const __attribute__((address_space(1))) nn_d2* nn_grow_p;
+  const uint64_t pos = uniform64(reinterpret_cast<uint64_t>(a.pos));
+  const uint64_t n = uniform64(a.d_n ? uint64_t(*a.d_n) : a.n);
+  const uint32_t B = __builtin_amdgcn_readfirstlane(a.d_B ? *a.d_B : a.B);
+  const double* __restrict__ q = reinterpret_cast<const double*>(
+      uniform64(reinterpret_cast<uint64_t>(a.q + (a.d_qoff ? uint64_t(*a.d_qoff) : 0ull) * D)));
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, hi = lane >> 5;
+  const bool live = uint32_t(col) < B;  // this lane's query slot holds a query
+  const uint32_t qsrc = live ? uint32_t(col) : 0u;
+  if (tid < kFewQueries) blk_min[tid] = 0xFFFFFFFFu;  // "none"
+
+  float bop[H];  // B operand of instruction j: -2 q^[h Dp/2 + j] (filled below, behind the first row loads)
+  const double u32 = 5.9604644775390625e-08;  // 2^-24
+  const double Mb = coord_bound * (1.0 + u32);
+  const double e_one = 2.0 * (4.0 * double(DP + 2) * u32 * double(DP) * Mb * Mb + 8.0 * u32 * double(DP) * Mb * Mb +
+                              4.0 * u32 * u32 * Mb * Mb * double(DP));
+  const float band = __double2float_ru(2.0 * e_one + 8.0 * u32 * 3.0 * double(DP) * Mb * Mb);
+
+  // slab `it` of this wave is slab it * step + first of the tree
+  const uint32_t GW = gridDim.x * kWaves, gw = blockIdx.x * kWaves + wave;
+  const uint64_t slabs_total = (n + 31) / 32;
+  const uint64_t first = gw, step = GW;
+  const uint64_t my_count = slabs_total > gw ? (slabs_total - gw + GW - 1) / GW : 0;
+  __syncthreads();  // blk_min is initialised
+
+  double best_d = INFINITY;
+  uint32_t best_i = 0xFFFFFFFFu;
+  float cmin = live ? INFINITY : -INFINITY;
+  int cnt = 0;
+
+  // exact fp64 distance of a row: the operation sequence of nn1_sweep_kernel.  AT_ONCE: every coordinate is loaded
+  // before the first use (one round trip; the end of the sweep), otherwise a few per round trip (inside the sweep the
+  // registers belong to the slabs in flight)
+  auto resolve = [&](uint64_t row, auto at_once) {
+    if (row >= n) return;
+    nn_gdouble_p p = (nn_gdouble_p)(pos + row * (DP * sizeof(double)));
+    const double* qq = q + uint64_t(qsrc) * D;
+    double s;
+    if constexpr (decltype(at_once)::value) {
+      double pv[DP], qv[DP];
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        pv[d] = p[d];
+        qv[d] = d < D ? qq[d] : 0.0;
+      }
+      {
+        const double df = qv[0] - pv[0];
+        s = df * df;
+      }
+#pragma unroll
+      for (int d = 1; d < DP; ++d) {
+        const double df = qv[d] - pv[d];
+        s = s + df * df;
+      }
+    } else {
+      {
+        const double df = qq[0] - p[0];
+        s = df * df;
+      }
+#pragma unroll 3
+      for (int d = 1; d < DP; ++d) {
+        const double df = (d < D ? qq[d] : 0.0) - p[d];
+        s = s + df * df;
+      }
+    }
+    const double dd = sqrt(s);
+    if (lex_less(dd, uint32_t(row), best_d, best_i)) {
+      best_d = dd;
+      best_i = uint32_t(row);
+    }
+  };
+  auto resolve_entry = [&](int k, auto at_once) {
+    uint32_t mask = cand_mask[k][tid];
+    const uint64_t base = (uint64_t(cand_key[k][tid]) * step + first) * 32u + 4u * uint32_t(hi);
+#pragma unroll 1
+    while (mask) {
+      const uint32_t i = uint32_t(__builtin_ctz(mask));
+      mask &= mask - 1;
+      resolve(base + 8u * (i >> 2) + (i & 3u), at_once);
+    }
+  };
+  auto compact = [&](float lim) {
+    int w = 0;
+#pragma unroll 1
+    for (int k = 0; k < cnt; ++k) {
+      const float mm = cand_m[k][tid];
+      if (mm <= lim) {
+        const uint32_t kk = cand_key[k][tid], mk = cand_mask[k][tid];
+        cand_m[w][tid] = mm;
+        cand_key[w][tid] = kk;
+        cand_mask[w][tid] = mk;
+        ++w;
+      }
+    }
+    cnt = w;
+    if (cnt == kCandCap) {
+#pragma unroll 1
+      for (int k = 0; k < cnt; ++k) resolve_entry(k, std::false_type{});
+      cnt = 0;
+    }
+  };
+
+  // half a row per lane; slabs past the wave's last one re-read it (the prefetches are unconditional, see
+  // nn1_stream_kernel), rows past the tree re-read the last row and are replaced below
+  auto fetch = [&](uint64_t it, double (&buf)[H]) {
+    const uint64_t itc = it < my_count ? it : my_count - 1;
+    uint64_t row = (itc * step + first) * 32u + uint32_t(col);
+    if (row >= n) row = n - 1;
+    const uint64_t addr = pos + (row * DP + uint32_t(H * hi)) * sizeof(double);
+    if constexpr (H % 2 == 0) {
+      nn_grow_p src = (nn_grow_p)addr;
+#pragma unroll
+      for (int j = 0; j < H / 2; ++j) {
+        const nn_d2 v = src[j];
+        buf[2 * j] = v.x;
+        buf[2 * j + 1] = v.y;
+      }
+    } else {
+      nn_gdouble_p src = (nn_gdouble_p)addr;
+#pragma unroll
+      for (int j = 0; j < H; ++j) buf[j] = src[j];
+    }
+  };
+  auto process = [&](uint64_t it, const double (&buf)[H]) {
+    const bool ok = (it * step + first) * 32u + uint32_t(col) < n;
+    const float blk = seed_decode(blk_min[col]);  // "none" decodes to NaN
+    float x[H];
+    float nrm = 0.0f;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      // rows past the tree and removed vertices (rows of +inf): a large finite float, estimates ~1e37, never candidates
+      x[j] = (ok && buf[j] < INFINITY) ? float(buf[j]) : 1e18f;
+      nrm = __builtin_fmaf(x[j], x[j], nrm);
+    }
+    rkh_f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(nrm, 1.0f, c, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < H; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], bop[j], c, 0, 0, 0);
+    float m = min3_raw(min3_raw(c[0], c[1], c[2]), min3_raw(c[3], c[4], c[5]), min3_raw(c[6], c[7], c[8]));
+    m = min3_raw(m, min3_raw(c[9], c[10], c[11]), min3_raw(c[12], c[13], c[14]));
+    m = min3_raw(m, c[15], m);
+    const float seen = live ? fminf(cmin, blk) : cmin;  // what was known before this slab (fminf drops the NaN)
+    cmin = min3_raw(seen, m, m);
+    cmin = min_over_halves(cmin);
+    const float lim = cmin + band;
+    if (m <= lim) {
+      if (live && hi == 0 && cmin < seen) atomicMin(&blk_min[col], seed_encode(cmin));
+      if (cnt == kCandCap) compact(lim);
+      uint32_t mask = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mask |= (c[i] <= lim) ? (1u << i) : 0u;
+      cand_key[cnt][tid] = uint32_t(it);
+      cand_mask[cnt][tid] = mask;
+      cand_m[cnt][tid] = m;
+      ++cnt;
+    }
+  };
+
+  if (my_count > 0 && B > 0) {
+    // PD row buffers in turn: PD - 1 slabs are on their way while one is processed
+    double r[PD][H];
+#pragma unroll
+    for (int k = 0; k < PD - 1; ++k) fetch(k, r[k]);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const int d = H * hi + j;
+      bop[j] = d < D ? -2.0f * float(q[uint64_t(qsrc) * D + d]) : 0.0f;
+    }
+    uint64_t it = 0;
+    for (; it + PD <= my_count; it += PD) {
+#pragma unroll
+      for (int k = 0; k < PD; ++k) {
+        fetch(it + k + PD - 1, r[(k + PD - 1) % PD]);
+        process(it + k, r[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PD - 1; ++k)
+      if (it + k < my_count) process(it + k, r[k]);
+    if (live && hi == 0) atomicMin(&blk_min[col], seed_encode(cmin));
+  }
+  __syncthreads();
+  if (live && B > 0) {  // resolve what the block's minimum leaves of the list
+    const float lim = fminf(cmin, seed_decode(blk_min[col])) + band;
+#pragma unroll 1
+    for (int k = 0; k < cnt; ++k)
+      if (cand_m[k][tid] <= lim) resolve_entry(k, std::true_type{});
+  }
+  {  // the two halves of the wave hold different rows of the same 32 query slots
+    const double od = __shfl_xor(best_d, 32, 64);
+    const uint32_t oi = __shfl_xor(best_i, 32, 64);
+    if (lex_less(od, oi, best_d, best_i)) {
+      best_d = od;
+      best_i = oi;
+    }
+  }
+  if (hi == 0) {
+    red_d[wave][col] = best_d;
+    red_i[wave][col] = best_i;
+  }
+  __syncthreads();
+  if (tid < kFewQueries && uint32_t(tid) < B) {
+    double bd = red_d[0][tid];
+    uint32_t bi = red_i[0][tid];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) {
+      if (lex_less(red_d[w][tid], red_i[w][tid], bd, bi)) {
+        bd = red_d[w][tid];
+        bi = red_i[w][tid];
+      }
+    }
+    a.part_dist[uint64_t(blockIdx.x) * Bpad + tid] = bd;
+    a.part_idx[uint64_t(blockIdx.x) * Bpad + tid] = bi;
+  }
+}
+
 // one wave per query: lanes stride over the per-block partials, then a shuffle reduction
 __global__ __launch_bounds__(256) void nn1_reduce_kernel(NnArgs single, const NnArgs* __restrict__ table,
                                                           uint32_t nblocks, uint32_t Bpad) {
@@ -917,12 +1178,36 @@ static uint32_t stream_resident_blocks() {
   return v;
 }
 
+// the few-queries matrix-core sweep: one resident set of blocks, like the register-direct sweep
+template <int DP>
+static uint32_t few_resident_blocks() {
+  static const uint32_t v = [] {
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1024u;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 1024u;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nn1_few_mfma_kernel<DP>, kFewThreads, 0) != hipSuccess ||
+        per_cu <= 0)
+      return 1024u;
+    return uint32_t(per_cu) * uint32_t(cus);
+  }();
+  return v;
+}
+// Which few-queries sweeps take the matrix-core pre-filter (measured on 12-dimensional trees of 16 Ki .. 4 Mi rows,
+// tests/diag_nn_few.sh): from 5 queries on it beats the fp64 sweeps at every size (8 queries: 5.2 against 4.4 TB/s at
+// 4 Mi rows, 32 queries: 5.0 against 1.4); up to 4 queries the register-direct fp64 sweep is as fast or faster (5.8 TB/s
+// at one query) and stays, where it applies (D equal to its padded width).  Trees of a few tiles keep the tiled sweeps.
+static constexpr uint64_t kFewMinRows = 8192;
+static bool few_applies(uint32_t B, int D, int DP, uint64_t n_upper, double coord_bound) {
+  if (!(coord_bound > 0.0) || B > uint32_t(kFewQueries) || DP > 16 || n_upper < kFewMinRows || !mfma_enabled()) return false;
+  return B > 4 || D != DP;
+}
+
 uint32_t nn1_partial_blocks(uint64_t n_upper, uint32_t B, uint32_t n_problems) {
   const uint32_t qb = pick_qb(B);
   const uint32_t gy = (B + qb - 1) / qb;
   const uint32_t np = n_problems ? n_problems : 1;
   const uint32_t a = pick_gx(n_upper, gy * np);
-  const uint32_t b = B <= 8 ? pick_gx_stream(n_upper, np, kStreamBlocksMax) : 0;
+  const uint32_t b = B <= uint32_t(kFewQueries) ? pick_gx_stream(n_upper, np, kStreamBlocksMax) : 0;
   return a > b ? a : b;
 }
 
@@ -937,9 +1222,13 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
                                 hipEvent_t ev1, double coord_bound, const uint32_t* d_yblock_base, bool table_has_seed) {
   const uint32_t qb = pick_qb(B);
   const uint32_t gy = (B + qb - 1) / qb;
-  const bool stream = B <= 8 && D == DP;  // HBM-bound regime: rows straight into registers
+  // few queries over a large tree with known coordinate bounds: matrix-core pre-filter at the speed of HBM
+  const bool few = few_applies(B, D, DP, n_upper, coord_bound);
+  const bool stream = !few && B <= 8 && D == DP;  // HBM-bound regime: rows straight into registers
   uint32_t gx = pick_gx(n_upper, gy * n_problems);
-  if (stream) {
+  if (few) {
+    if constexpr (DP <= 16) gx = pick_gx_stream(n_upper, n_problems, few_resident_blocks<DP>());
+  } else if (stream) {
     const uint32_t resident = B <= 1 ? stream_resident_blocks<DP, 1>()
                                      : (B <= 2 ? stream_resident_blocks<DP, 2>()
                                                : (B <= 4 ? stream_resident_blocks<DP, 4>() : stream_resident_blocks<DP, 8>()));
@@ -954,9 +1243,14 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
   if (ev0) (void)hipEventRecord(ev0, s);
   const bool f32 = coord_bound > 0.0 && qb >= 32;  // compute-bound regime with known coordinate bounds
   const bool mfma = f32 && qb == kMfmaQueries && mfma_enabled() && DP <= 16;
-  g_last_kernel = stream ? "nn1_stream_kernel"
-                         : (mfma ? "nn1_sweep_mfma_kernel" : (f32 ? "nn1_sweep_f32_kernel" : "nn1_sweep_kernel"));
-  if (stream) {
+  g_last_kernel = few ? "nn1_few_mfma_kernel"
+                      : (stream ? "nn1_stream_kernel"
+                                : (mfma ? "nn1_sweep_mfma_kernel" : (f32 ? "nn1_sweep_f32_kernel" : "nn1_sweep_kernel")));
+  if (few) {
+    if constexpr (DP <= 16)
+      hipLaunchKernelGGL((nn1_few_mfma_kernel<DP>), dim3(gx, 1, n_problems), dim3(kFewThreads), 0, s, single, d_table, D,
+                         Bpad, coord_bound);
+  } else if (stream) {
 #define RKH_STREAM(QB) hipLaunchKernelGGL((nn1_stream_kernel<DP, QB>), grid, block, 0, s, single, d_table, Bpad)
     if (B <= 1) { RKH_STREAM(1); }
     else if (B <= 2) { RKH_STREAM(2); }

@@ -470,7 +470,7 @@ struct rkh_planner {
   int wave_fit = 1;          // per-round batch scale chosen on the device (round_begin_kernel); RKH_WAVE_FIT=0: off
   double wave_fill = 0.99;   // target fill of the last pass of steer waves (RKH_WAVE_FILL)
   uint32_t wave_slots = 1024;    // SIMDs of the device = concurrent waves of the two-lanes steer kernel
-  uint32_t lane_threshold = 4500;  // rounds with at least this many edges go to the two-lanes-per-edge kernel
+  uint32_t lane_threshold = 1024;  // rounds with at least this many edges go to the two-lanes-per-edge kernel (one wave-per-edge pass fills the 1024 SIMDs; measured optimum at 4, 16 and 32 problems, tests/diag_lane_threshold.sh)
   uint32_t part_blocks = 0;
   uint64_t max_capacity = 0;
   // device tables (P entries each)

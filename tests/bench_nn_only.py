@@ -10,5 +10,6 @@ from reak_amd import lib  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4 * 1024 * 1024
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+bound = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 ctx = lib.Context(0)
-print(json.dumps(bench.nn_sweep_microbench(lib, ctx, bench.HipEvents(), n, B, 10)))
+print(json.dumps(bench.nn_sweep_microbench(lib, ctx, bench.HipEvents(), n, B, 10, coord_bound=bound)))

@@ -18,10 +18,10 @@ print("steer", d["steer_kernels"]["achieved"], d["steer_kernels"]["frac"])
 PY
 bash tests/prof_short.sh ${TAG} | tail -3
 bash tests/prof_pmc_planner.sh ${TAG} | tail -2
-# HBM-regime sweep (4 Mi x 12, 8 queries): FETCH_SIZE / WRITE_SIZE, separate passes
+# HBM-regime sweep (4 Mi x 12, 8 queries, unit-cube bound declared): FETCH_SIZE / WRITE_SIZE, separate passes
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d /tmp/pmcn_${TAG}_$C -o $TAG -- python $ROOT/tests/bench_nn_only.py > $OUT/${TAG}_nnpmc_$C.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d /tmp/pmcn_${TAG}_$C -o $TAG -- python $ROOT/tests/bench_nn_only.py 4194304 8 1.0 > $OUT/${TAG}_nnpmc_$C.log 2>&1
   echo "$C rc=$?"
 done
 python3 - "$TAG" "$OUT" <<'PY'
@@ -36,14 +36,15 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         k = r["Kernel_Name"].split("(")[0]
         tot[k] += float(r["Counter_Value"]); n[k] += 1
     for k in tot:
-        if "nn1_stream_kernel" in k or "nn1_sweep_kernel" in k: res[c] = (k, tot[k], n[k])
+        if "nn1_few_mfma_kernel" in k: res[c] = (k, tot[k], n[k])
 kname, fetch_kb, nf = res["FETCH_SIZE"]; _, write_kb, nw = res["WRITE_SIZE"]
 per_launch = (2.0 * fetch_kb / nf + write_kb / nw) * 1024.0
 rec = {"kernel": kname.replace("void rkh::", ""), "n_rows": 4194304, "dims": 12, "queries_per_sweep": 8,
        "algorithmic_bytes": 4194304 * 12 * 8, "FETCH_SIZE_KiB_per_launch": fetch_kb / nf, "WRITE_SIZE_KiB_per_launch": write_kb / nw,
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
        "hbm_bytes_per_launch": per_launch, "traffic_over_algorithmic": per_launch / (4194304 * 12 * 8),
-       "command": "rocprofv3 --pmc FETCH_SIZE ... -- python tests/bench_nn_only.py (and a second pass with --pmc WRITE_SIZE); mean over the launches of the kernel"}
+       "coord_bound": 1.0,
+       "command": "rocprofv3 --pmc FETCH_SIZE ... -- python tests/bench_nn_only.py 4194304 8 1.0 (and a second pass with --pmc WRITE_SIZE); mean over the launches of the kernel"}
 json.dump(rec, open(f"{out}/{tag}_nn_sweep_pmc.json", "w"), indent=1)
 print(json.dumps(rec))
 PY

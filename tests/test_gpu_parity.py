@@ -49,10 +49,17 @@ def test_nn1_bit_exact(L, ctx, oracle, D, n, B):
                                            (6, 20000, 200, "nn1_sweep_mfma_kernel"), (3, 5000, 1000, "nn1_sweep_mfma_kernel"),
                                            (16, 9000, 130, "nn1_sweep_mfma_kernel"), (12, 30000, 48, "nn1_sweep_f32_kernel"),
                                            (12, 600000, 200, "nn1_sweep_mfma_kernel"), (6, 8192, 1000, "nn1_sweep_mfma_kernel"),
-                                           (24, 4000, 200, "nn1_sweep_f32_kernel")])
+                                           (24, 4000, 200, "nn1_sweep_f32_kernel"),
+                                           # few queries over a large tree: one wave per 32-row slab, no LDS tile
+                                           (12, 70001, 8, "nn1_few_mfma_kernel"), (12, 65536, 1, "nn1_stream_kernel"),
+                                           (6, 100003, 32, "nn1_few_mfma_kernel"), (3, 131072, 17, "nn1_few_mfma_kernel"),
+                                           (16, 66000, 5, "nn1_few_mfma_kernel"), (7, 80000, 31, "nn1_few_mfma_kernel"),
+                                           (2, 70000, 8, "nn1_few_mfma_kernel"), (12, 8192, 8, "nn1_few_mfma_kernel"),
+                                           (7, 70000, 3, "nn1_few_mfma_kernel"), (12, 8191, 8, "nn1_stream_kernel"),
+                                           (12, 1048577, 32, "nn1_few_mfma_kernel")])
 def test_nn1_single_precision_prefilters_are_bit_exact(L, ctx, oracle, D, n, B, expect):
-    """Sweeps with a coordinate bound run a float pre-filter (fp32 matrix cores above 64 queries, packed fp32 VALU below)
-    in front of the exact fp64 test: indices and distances must not change.  The cloud contains exact duplicates (ties
+    """Sweeps with a coordinate bound run a float pre-filter (fp32 matrix cores above 64 queries and, over trees of at
+    least 8192 rows, for 5 to 32 queries; packed fp32 VALU between) in front of the exact fp64 test: indices and distances must not change.  The cloud contains exact duplicates (ties
     resolve to the lower index), near-duplicates one ulp apart and queries sitting on vertices (distance 0)."""
     rng = np.random.default_rng(7 * D + n + B)
     pts = rng.uniform(-np.pi, np.pi, size=(n, D))
@@ -66,8 +73,8 @@ def test_nn1_single_precision_prefilters_are_bit_exact(L, ctx, oracle, D, n, B, 
     if n > 400:  # more coincident vertices than a lane's candidate list holds, inside one 32-row slab and across slabs
         pts[100:124] = pts[100]
         pts[300:400:7] = pts[100]
-        q[2] = pts[100] + 1e-9
-        q[3] = pts[100]
+        q[2 % B] = pts[100] + 1e-9
+        q[3 % B] = pts[100]
     nn = L.HipNeighborSearch(ctx, D, n + 10)
     nn.added_vertices(pts)
     nn.set_coord_bound(np.pi + 1e-6)
@@ -101,7 +108,7 @@ def test_coordinate_bound_is_checked_where_the_library_holds_the_data(L, ctx):
     assert np.all(idx < 1000)
 
 
-@pytest.mark.parametrize("D,n,bound", [(12, 40000, 0.0), (12, 40000, 3.0), (6, 3000, 3.0), (3, 900, 0.0)])
+@pytest.mark.parametrize("D,n,bound", [(12, 40000, 0.0), (12, 40000, 3.0), (6, 3000, 3.0), (3, 900, 0.0), (12, 70000, 3.0)])
 def test_removed_vertices_are_never_returned(L, ctx, oracle, D, n, bound):
     """any_knn_synchro::removed_vertex: tombstoned rows keep their index and vanish from every sweep (register-direct,
     tiled fp64, packed-fp32 and matrix-core 1-NN; k-NN with radius).  Checked against the oracle's linear search over the
