@@ -1015,10 +1015,16 @@ __global__ __launch_bounds__(kFewThreads, 4) void nn1_few_mfma_kernel(NnArgs sin
     double r[PD][H];
 #pragma unroll
     for (int k = 0; k < PD - 1; ++k) fetch(k, r[k]);
+    {  // all query coordinates in one round trip (unconditional loads at a clamped coordinate, then the select)
+      nn_gdouble_p qg = (nn_gdouble_p)(reinterpret_cast<uint64_t>(q) + uint64_t(qsrc) * D * sizeof(double));
+      double qv[H];
 #pragma unroll
-    for (int j = 0; j < H; ++j) {
-      const int d = H * hi + j;
-      bop[j] = d < D ? -2.0f * float(q[uint64_t(qsrc) * D + d]) : 0.0f;
+      for (int j = 0; j < H; ++j) {
+        const int d = H * hi + j;
+        qv[j] = qg[d < D ? d : D - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < H; ++j) bop[j] = (H * hi + j < D) ? -2.0f * float(qv[j]) : 0.0f;
     }
     uint64_t it = 0;
     for (; it + PD <= my_count; it += PD) {
