@@ -512,6 +512,11 @@ __device__ __forceinline__ float min3_raw(float a, float b, float c) {
   asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// The same through the compiler (v_min3_f32 as well; results of matrix instructions are not re-quieted).  Kernels whose
+// matrix instructions do NOT hold the vector issue for their whole length (the bf16 forms: 8 of 32 cycles) must use
+// this one: the hazard recognizer counts the wait states between a matrix instruction and a VALU read of its result
+// only for instructions it knows, not for inline asm -- the asm form read accumulators that were still being written.
+__device__ __forceinline__ float min3_f(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 // minimum over the two lane halves (lanes l and l ^ 32), one VALU swap instead of an LDS round trip
 __device__ __forceinline__ float min_over_halves(float v) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -807,6 +812,363 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
   }
 }
 
+// ---- the pre-filter on the bf16 matrix cores ---------------------------------------------------------------------------
+// The f32-input matrix instruction runs at the vector rate and does not overlap with VALU work (tests/micro/
+// mfma_valu_overlap.hip); v_mfma_f32_32x32x16_bf16 has 16x its rate and holds the vector issue for 8 of its 32 cycles.
+// A float does not fit a bf16, but the estimate only has to be BOUNDED: every float is split x^ = x_hi + x_lo + r,
+// x_hi = bf16(x^), x_lo = bf16(x^ - x_hi), |r| <= 2^-16 |x^| (bf16 keeps 8 significant bits, round to nearest), and
+//   x^.q^ ~ sum (x_hi + x_lo) q_hi + sum x_hi q_lo      (products of two bf16 are exact in the f32 accumulator)
+// leaves out x_lo q_lo, (x_hi + x_lo) r_q and r_x q^: at most 3.05 * 2^-16 |x^||q^| per coordinate.  |x^|^2 (the float
+// fmaf chain of the lane half) enters as three bf16 pieces against ones, i.e. exactly.  Per lane half the k-slots of a
+// chain are [x_hi | x_lo | x_hi | n_hi n_mid n_lo | 0..] against [-2q_hi | -2q_hi | -2q_lo | 1 1 1 | 0..]: 3 Dp/2 + 3
+// slots, 8 per instruction (3 instructions at Dp = 12 where the f32 form needs 6 of twice the cycles).  Lane
+// (r, h) = (l & 31, l >> 5) holds slots 8h .. 8h+7 of row / query r in each fragment: the half-row layout of
+// nn1_few_mfma_kernel.
+// Error bound (M' = coord_bound (1 + 2^-24)): 2 * 3.05 * 2^-16 Dp M'^2 for the split; the accumulation of the <= 64
+// exact products of a chain in the matrix pipe is not specified to the bit -- taken as 2^-23 relative to the
+// magnitude 3 Dp M'^2 PER PRODUCT SLOT of four instructions (256 roundings; an IEEE f32 sum of them would stay below a
+// quarter of that); the float |x^|^2 chains and the double -> float rounding of the inputs as in the f32 kernel.  E is
+// their sum with a factor 2, the band 2 E plus the rounding of (running minimum + band).
+typedef __bf16 rkh_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 rkh_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rkh_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_bits(float a) {  // round to nearest even (v_cvt_pk_bf16_f32), in the low half
+  const rkh_f2v v = {a, 0.0f};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rkh_bf16x2)) & 0xFFFFu;
+}
+template <int DP>
+__device__ __forceinline__ float bf16_band(double coord_bound) {
+  const double u32 = 5.9604644775390625e-08;  // 2^-24
+  const double Mb = coord_bound * (1.0 + u32);
+  const double dm2 = double(DP) * Mb * Mb;
+  const double e_split = 2.0 * 3.05 * 1.52587890625e-05 * dm2;          // 2^-16
+  const double e_acc = 256.0 * 1.1920928955078125e-07 * 3.0 * dm2;       // 2^-23
+  const double e_norm = double(DP / 2 + 2) * u32 * dm2;
+  const double e_in = 8.0 * u32 * dm2 + 4.0 * u32 * u32 * dm2;
+  const double e_one = 2.0 * (e_split + e_acc + e_norm + e_in);
+  return __double2float_ru(2.0 * e_one + 8.0 * u32 * 3.0 * dm2);
+}
+template <int H>
+struct Bf16Operand {
+  static constexpr int K = 3 * H + 3;       // k-slots of a lane half
+  static constexpr int NI = (K + 7) / 8;    // matrix instructions per chain
+  // slots -> fragments (two bf16 per register, slot 2m in the low half)
+  __device__ static __forceinline__ void pack(const uint32_t (&e)[8 * NI], uint4 (&frag)[NI]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      frag[i].x = e[8 * i + 0] | (e[8 * i + 1] << 16);
+      frag[i].y = e[8 * i + 2] | (e[8 * i + 3] << 16);
+      frag[i].z = e[8 * i + 4] | (e[8 * i + 5] << 16);
+      frag[i].w = e[8 * i + 6] | (e[8 * i + 7] << 16);
+    }
+  }
+  __device__ static __forceinline__ void split(float v, uint32_t& hi, uint32_t& lo) {
+    hi = bf16_bits(v);
+    lo = bf16_bits(v - __uint_as_float(hi << 16));  // the difference is exact
+  }
+  __device__ static __forceinline__ void build_a(const float (&x)[H], float nrm, uint4 (&frag)[NI]) {
+    uint32_t e[8 * NI];
+#pragma unroll
+    for (int k = 0; k < 8 * NI; ++k) e[k] = 0u;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      uint32_t hi, lo;
+      split(x[j], hi, lo);
+      e[j] = hi;
+      e[H + j] = lo;
+      e[2 * H + j] = hi;
+    }
+    const uint32_t n0 = bf16_bits(nrm);
+    const float r1 = nrm - __uint_as_float(n0 << 16);
+    const uint32_t n1 = bf16_bits(r1);
+    const float r2 = r1 - __uint_as_float(n1 << 16);
+    e[3 * H] = n0;
+    e[3 * H + 1] = n1;
+    e[3 * H + 2] = bf16_bits(r2);
+    pack(e, frag);
+  }
+  __device__ static __forceinline__ void build_b(const float (&qm2)[H], uint4 (&frag)[NI]) {  // qm2 = -2 q^
+    uint32_t e[8 * NI];
+#pragma unroll
+    for (int k = 0; k < 8 * NI; ++k) e[k] = 0u;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      uint32_t hi, lo;
+      split(qm2[j], hi, lo);
+      e[j] = hi;
+      e[H + j] = hi;
+      e[2 * H + j] = lo;
+    }
+    e[3 * H] = e[3 * H + 1] = e[3 * H + 2] = 0x3F80u;  // 1.0
+    pack(e, frag);
+  }
+};
+
+// nn1_sweep_mfma_kernel with the estimate on the bf16 matrix cores: same grid, same work items, same entry lists and
+// exact resolution; the tile in LDS holds ready-made A fragments (staged by two half rows per thread), a slab costs a
+// wave NI ds_read_b128 and NI matrix instructions.  A seed left by the f32 sampled pass is a valid running minimum here
+// (it is within the f32 kernel's E, which is below this kernel's, of a true value).
+template <int DP>
+__global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_bf16_kernel(NnArgs single, const NnArgs* __restrict__ table,
+                                                                      int D, uint32_t Bpad, double coord_bound,
+                                                                      const uint32_t* __restrict__ yblock_base,
+                                                                      uint32_t n_problems, uint32_t gx, uint32_t gy) {
+  constexpr int H = DP / 2;
+  constexpr int NI = Bf16Operand<H>::NI;
+  constexpr int kSlabs = kTileRows / 32;
+  // A operands of the tile: fragment i of (row, lane half) -- consecutive rows 16 bytes apart: conflict-free ds_read_b128
+  __shared__ uint4 tileA[NI][2][kTileRows];
+  __shared__ uint32_t cand_key[kCandCap][kMfmaThreads];
+  __shared__ uint32_t cand_mask[kCandCap][kMfmaThreads];
+  __shared__ float cand_m[kCandCap][kMfmaThreads];
+
+  uint32_t bx, by, bz;
+  {
+    const uint32_t L = blockIdx.x;
+    const uint32_t ytot = yblock_base ? yblock_base[n_problems] : gy * n_problems;
+    const uint32_t W = ytot * gx, Wc = (W + 7) >> 3;
+    const uint32_t slot = L >> 3, w = (L & 7) * Wc + slot;
+    if (slot >= Wc || w >= W) return;
+    const uint32_t yy = w / gx;
+    uint32_t p = 0, y0, cnt;
+    if (yblock_base) {
+      uint32_t hi_p = n_problems;  // yblock_base[p] <= yy < yblock_base[hi_p]
+      while (hi_p - p > 1) {
+        const uint32_t mid = (p + hi_p) >> 1;
+        if (yblock_base[mid] <= yy) p = mid;
+        else hi_p = mid;
+      }
+      y0 = yblock_base[p];
+      cnt = yblock_base[p + 1] - y0;
+    } else {
+      p = yy / gy;
+      y0 = p * gy;
+      cnt = gy;
+    }
+    const uint32_t r = w - y0 * gx;
+    bx = r / cnt;
+    by = r - bx * cnt;
+    bz = p;
+  }
+  // everything read from the table entry is block-uniform; said explicitly, it lives in scalar registers
+  auto uniform64 = [](uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v)), hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+    return (uint64_t(hi) << 32) | lo;
+  };
+  const NnArgs a = table ? table[bz] : single;
+  const double* __restrict__ pos = reinterpret_cast<const double*>(uniform64(reinterpret_cast<uint64_t>(a.pos)));
+  const uint64_t n = uniform64(a.d_n ? uint64_t(*a.d_n) : a.n);
+  const uint32_t B = __builtin_amdgcn_readfirstlane(a.d_B ? *a.d_B : a.B);
+  const double* __restrict__ q = reinterpret_cast<const double*>(
+      uniform64(reinterpret_cast<uint64_t>(a.q + (a.d_qoff ? uint64_t(*a.d_qoff) : 0ull) * D)));
+  uint32_t* __restrict__ seed = reinterpret_cast<uint32_t*>(uniform64(reinterpret_cast<uint64_t>(a.seed)));
+  double* __restrict__ part_dist = reinterpret_cast<double*>(uniform64(reinterpret_cast<uint64_t>(a.part_dist)));
+  uint32_t* __restrict__ part_idx = reinterpret_cast<uint32_t*>(uniform64(reinterpret_cast<uint64_t>(a.part_idx)));
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, hi = lane >> 5;
+  const uint32_t qi = by * kMfmaQueries + wave * 32 + col;
+  if (by * kMfmaQueries >= B) return;
+  const uint32_t qsrc = qi < B ? qi : (B - 1);
+
+  uint4 bop[NI];  // B fragments of this lane's query: -2 q^ of the lane half's coordinates (hi, hi, lo), then ones
+  {
+    float qf[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const int d = H * hi + j;
+      qf[j] = -2.0f * float(q[uint64_t(qsrc) * D + (d < D ? d : D - 1)]);
+      qf[j] = d < D ? qf[j] : 0.0f;
+    }
+    Bf16Operand<H>::build_b(qf, bop);
+  }
+  const float band = bf16_band<DP>(coord_bound);
+
+  // the tiles of this block: its contiguous slice of the tree
+  const uint64_t tiles_total = (n + kTileRows - 1) / kTileRows;
+  const uint64_t tiles_per_block = (tiles_total + gx - 1) / gx;
+  const uint64_t t_first = uint64_t(bx) * tiles_per_block, t_step = 1;
+  uint64_t t_end = t_first + tiles_per_block;
+  if (t_end > tiles_total) t_end = tiles_total;
+  const uint64_t t_count = t_end > t_first ? t_end - t_first : 0;
+
+  double best_d = INFINITY;         // champion of the entries resolved so far (list overflow only)
+  uint32_t best_i = 0xFFFFFFFFu;
+  // running minimum of the estimates of this lane's query; NaN ("no seed") is dropped by fminf
+  float cmin = seed ? fminf(INFINITY, seed_decode(seed[qsrc])) : INFINITY;
+  int cnt = 0;                      // entries in the list
+
+  // exact fp64 distance of vertex `row` (global index): the operation sequence of nn1_sweep_kernel
+  auto resolve = [&](uint32_t row) {
+    if (uint64_t(row) >= n) return;  // padding rows of the last tile
+    const double* p = pos + uint64_t(row) * DP;
+    const double* qq = q + uint64_t(qsrc) * D;
+    double s;
+    {
+      const double df = qq[0] - p[0];
+      s = df * df;
+    }
+#pragma unroll 3
+    for (int d = 1; d < DP; ++d) {  // (a few coordinates per memory round trip; fully unrolled it spills into the sweep)
+      const double df = (d < D ? qq[d] : 0.0) - p[d];
+      s = s + df * df;
+    }
+    const double dd = sqrt(s);
+    if (lex_less(dd, row, best_d, best_i)) {
+      best_d = dd;
+      best_i = row;
+    }
+  };
+  // every flagged row of entry k: key = slab index counted from the block's first tile
+  auto resolve_entry = [&](int k) {
+    uint32_t mask = cand_mask[k][tid];
+    const uint32_t base = uint32_t(t_first) * uint32_t(kTileRows) + cand_key[k][tid] * 32u + 4u * uint32_t(hi);
+#pragma unroll 1
+    while (mask) {
+      const uint32_t i = uint32_t(__builtin_ctz(mask));
+      mask &= mask - 1;
+      resolve(base + 8u * (i >> 2) + (i & 3u));
+    }
+  };
+  // drop the entries the current minimum rules out; if the list is still full, resolve it
+  auto compact = [&](float lim) {
+    int w = 0;
+#pragma unroll 1
+    for (int k = 0; k < cnt; ++k) {
+      const float mm = cand_m[k][tid];
+      if (mm <= lim) {
+        const uint32_t kk = cand_key[k][tid], mk = cand_mask[k][tid];
+        cand_m[w][tid] = mm;
+        cand_key[w][tid] = kk;
+        cand_mask[w][tid] = mk;
+        ++w;
+      }
+    }
+    cnt = w;
+    if (cnt == kCandCap) {
+#pragma unroll 1
+      for (int k = 0; k < cnt; ++k) resolve_entry(k);
+      cnt = 0;
+    }
+  };
+
+  // a thread stages two half rows per tile: pairs p = tid and tid + 256, pair p = (row p >> 1, half p & 1)
+  constexpr int PP = 2 * kTileRows / kMfmaThreads;
+  double pf[PP][H];
+  auto fetch = [&](uint64_t t) {
+    const uint64_t row_base = t * kTileRows;
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+      const int pr = tid + j * kMfmaThreads;
+      const uint64_t row = row_base + uint32_t(pr >> 1);
+      const bool ok = row < n;
+      const double* src = pos + (ok ? row : n - 1) * DP + H * (pr & 1);
+#pragma unroll
+      for (int d = 0; d < H; ++d) pf[j][d] = ok ? src[d] : INFINITY;
+    }
+  };
+  // a wave whose 32 query slots all lie past the batch only helps staging the tiles
+  const bool sweeping = by * kMfmaQueries + wave * 32 < B;
+  if (t_count > 0) fetch(t_first);
+  for (uint64_t it = 0; it < t_count; ++it) {
+    // the staging indices are recomputed every tile (an opaque copy of the thread id): hoisted out of the loop they
+    // stay live across the slab loop and push its registers into scratch
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    {
+#pragma unroll
+      for (int j = 0; j < PP; ++j) {
+        const int pr = tl + j * kMfmaThreads;
+        float x[H];
+        float nrm = 0.0f;
+#pragma unroll
+        for (int d = 0; d < H; ++d) {
+          // rows past the end of the tree and removed vertices: a large finite float (estimate ~1e37: never a candidate)
+          x[d] = pf[j][d] < INFINITY ? float(pf[j][d]) : 1e18f;
+          nrm = __builtin_fmaf(x[d], x[d], nrm);
+        }
+        uint4 frag[NI];
+        Bf16Operand<H>::build_a(x, nrm, frag);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) tileA[i][pr & 1][pr >> 1] = frag[i];
+      }
+    }
+    if (it + 1 < t_count) fetch(t_first + (it + 1) * t_step);
+    __syncthreads();
+    if (sweeping) {
+      // operands of slab g: the fragments of (row 32 g + col, this lane half); the chain starts from zero
+      auto load_ops = [&](int g, uint4 (&aop)[NI], rkh_f16v& c) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) aop[i] = tileA[i][hi][32 * g + col];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c[k] = 0.0f;
+      };
+      auto chain = [&](const uint4 (&aop)[NI], rkh_f16v& c) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rkh_bf16x8, aop[i]),
+                                                      __builtin_bit_cast(rkh_bf16x8, bop[i]), c, 0, 0, 0);
+      };
+      // the estimates of slab g are complete: running minimum, and (sweep proper) one entry if a row is within the band
+      auto settle = [&](int g, const rkh_f16v& c) {
+        float m = min3_f(min3_f(c[0], c[1], c[2]), min3_f(c[3], c[4], c[5]), min3_f(c[6], c[7], c[8]));
+        m = min3_f(m, min3_f(c[9], c[10], c[11]), min3_f(c[12], c[13], c[14]));
+        m = __builtin_fminf(m, c[15]);
+        cmin = __builtin_fminf(cmin, m);
+        // over both lane halves: the pair then meets a new minimum as often as ONE sequence of twice the length would
+        cmin = min_over_halves(cmin);
+        const float lim = cmin + band;
+        if (m <= lim) {
+          if (cnt == kCandCap) compact(lim);
+          uint32_t mask = 0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) mask |= (c[i] <= lim) ? (1u << i) : 0u;
+          cand_key[cnt][tid] = uint32_t(it) * uint32_t(kSlabs) + uint32_t(g);
+          cand_mask[cnt][tid] = mask;
+          cand_m[cnt][tid] = m;
+          ++cnt;
+        }
+      };
+      rkh_f16v c0, c1;
+      uint4 a0[NI], a1[NI];
+      load_ops(0, a0, c0);
+      chain(a0, c0);
+#pragma unroll
+      for (int g = 0; g < kSlabs; g += 2) {
+        load_ops(g + 1, a1, c1);
+        chain(a1, c1);
+        settle(g, c0);
+        if (g + 2 < kSlabs) {
+          load_ops(g + 2, a0, c0);
+          chain(a0, c0);
+        }
+        settle(g + 1, c1);
+      }
+    }
+    __syncthreads();
+  }
+  cmin = min_over_halves(cmin);
+  // resolve what the final minimum (of both halves) leaves of the list
+  {
+    const float lim = cmin + band;
+#pragma unroll 1
+    for (int k = 0; k < cnt; ++k)
+      if (cand_m[k][tid] <= lim) resolve_entry(k);
+  }
+  {  // the two halves of the wave hold different rows of the same 32 queries
+    const double od = __shfl_xor(best_d, 32, 64);
+    const uint32_t oi = __shfl_xor(best_i, 32, 64);
+    if (lex_less(od, oi, best_d, best_i)) {
+      best_d = od;
+      best_i = oi;
+    }
+  }
+  if (hi == 0 && qi < B) {
+    part_dist[uint64_t(bx) * Bpad + qi] = best_d;
+    part_idx[uint64_t(bx) * Bpad + qi] = best_i;
+  }
+}
+
 // The matrix-core pre-filter for FEW queries per sweep (at most 32) over a LARGE tree with known coordinate bounds: the
 // HBM-bound regime.  The exact fp64 test costs 3 Dp - 1 VALU operations per (row, query) -- at 8 queries that is 3
 // operations per byte of the tree, and the register-direct fp64 sweep above stops at ~4.5 TB/s -- whereas the estimate
@@ -990,9 +1352,9 @@ __global__ __launch_bounds__(kFewThreads, 4) void nn1_few_mfma_kernel(NnArgs sin
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(nrm, 1.0f, c, 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < H; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], bop[j], c, 0, 0, 0);
-    float m = min3_raw(min3_raw(c[0], c[1], c[2]), min3_raw(c[3], c[4], c[5]), min3_raw(c[6], c[7], c[8]));
-    m = min3_raw(m, min3_raw(c[9], c[10], c[11]), min3_raw(c[12], c[13], c[14]));
-    m = min3_raw(m, c[15], m);
+    float m = min3_f(min3_f(c[0], c[1], c[2]), min3_f(c[3], c[4], c[5]), min3_f(c[6], c[7], c[8]));
+    m = min3_f(m, min3_f(c[9], c[10], c[11]), min3_f(c[12], c[13], c[14]));
+    m = __builtin_fminf(m, c[15]);
     const float seen = live ? fminf(cmin, blk) : cmin;  // what was known before this slab (fminf drops the NaN)
     cmin = min3_raw(seen, m, m);
     cmin = min_over_halves(cmin);
@@ -1124,6 +1486,15 @@ int nn_padded_dims(int D) { return padded_dims(D); }
 static bool mfma_enabled() {
   static const bool on = [] {
     const char* e = getenv("RKH_NN_MFMA");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+// RKH_NN_BF16=0 keeps the f32-input matrix instructions in the many-queries sweep (diagnostics: tests/prof_nn_variants.sh)
+static bool bf16_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("RKH_NN_BF16");
     return !(e && e[0] == '0');
   }();
   return on;
@@ -1275,8 +1646,13 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
         hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP, true>), blocks_for(gxs), dim3(kMfmaThreads), 0, s, single, d_table, D,
                            Bpad, coord_bound, yb, n_problems, gxs, gy);
       }
-      hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP, false>), blocks_for(gx), dim3(kMfmaThreads), 0, s, single, d_table, D,
-                         Bpad, coord_bound, yb, n_problems, gx, gy);
+      if (bf16_enabled()) {
+        g_last_kernel = "nn1_sweep_bf16_kernel";
+        hipLaunchKernelGGL((nn1_sweep_bf16_kernel<DP>), blocks_for(gx), dim3(kMfmaThreads), 0, s, single, d_table, D, Bpad,
+                           coord_bound, yb, n_problems, gx, gy);
+      } else
+        hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP, false>), blocks_for(gx), dim3(kMfmaThreads), 0, s, single, d_table, D,
+                           Bpad, coord_bound, yb, n_problems, gx, gy);
     }
   } else
   switch (qb) {

@@ -1,13 +1,19 @@
 #!/bin/bash
-# NN sweep variants side by side (diagnostic, GPU box): register-direct stream kernel with / without the LDS transpose,
-# matrix-core sweep with different seed strides.
+# many-queries NN sweeps side by side (diagnostic, GPU box): the split-bf16 estimate on the matrix cores against the
+# f32-input matrix instructions (RKH_NN_BF16=0): parity tests, the microbenchmark on large trees, the planner's timed region.
 set -o pipefail
-out=gpurun_out/r02_r_nn
+out=gpurun_out/nn_variants
 mkdir -p $out
-timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "nn1 or coordinate or knn" > $out/tests.log 2>&1 || { tail -30 $out/tests.log; exit 1; }
-tail -3 $out/tests.log
-echo "== stream, direct rows"; timeout -k 10 200 python tests/diag_nn_stream.py > $out/stream_direct.log 2>&1 && grep "n=4194304\|n=16777216" $out/stream_direct.log
-echo "== stream, transposed"; RKH_NN_XPOSE=1 timeout -k 10 200 python tests/diag_nn_stream.py > $out/stream_xpose.log 2>&1 && grep "n=4194304\|n=16777216" $out/stream_xpose.log
-for s in 0 4 8 16; do
-  echo "== mfma, seed stride $s"; RKH_NN_SEED_STRIDE=$s timeout -k 10 200 python tests/diag_nn_mfma.py > $out/mfma_seed$s.log 2>&1 && cat $out/mfma_seed$s.log | grep TFLOP
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "nn1 or coordinate or knn or removed or prefilter" > $out/tests.log 2>&1 || { tail -30 $out/tests.log; exit 1; }
+tail -2 $out/tests.log
+for w in 1 0; do
+  echo "== RKH_NN_BF16=$w"
+  RKH_NN_BF16=$w timeout -k 10 200 python tests/diag_nn_mfma.py > $out/mfma_bf16_$w.log 2>&1 || { tail -5 $out/mfma_bf16_$w.log; exit 1; }
+  grep TFLOP $out/mfma_bf16_$w.log
+  RKH_NN_BF16=$w timeout -k 10 300 python bench.py --no-cpu-baseline --no-microbench > $out/bench_bf16_$w.json 2> $out/bench_bf16_$w.err || { tail -5 $out/bench_bf16_$w.err; exit 1; }
+  python - <<PY
+import json
+d = json.load(open("$out/bench_bf16_$w.json"))
+print("value %.3fM  ms/step %.0f  nn timed: %s %.1f TF-equivalent" % (d["value"] / 1e6, d["ms_per_step"], d["nn_sweep_mfma_timed"]["kernel"], d["nn_sweep_mfma_timed"]["achieved"]))
+PY
 done
