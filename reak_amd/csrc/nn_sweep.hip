@@ -1491,6 +1491,10 @@ static bool mfma_enabled() {
   return on;
 }
 
+// The split-bf16 band is ~100x the f32 one: in few dimensions, where the nearest neighbours of a dense cloud sit close
+// together, it lets more rows through to the exact test than the cheaper instructions save (6-D, 25 000 x 1000, the
+// reference's published configuration: 42 us against 36) -- from 8 padded dimensions on the bf16 form is used.
+static constexpr int kBf16MinDims = 8;
 // RKH_NN_BF16=0 keeps the f32-input matrix instructions in the many-queries sweep (diagnostics: tests/prof_nn_variants.sh)
 static bool bf16_enabled() {
   static const bool on = [] {
@@ -1500,13 +1504,15 @@ static bool bf16_enabled() {
   return on;
 }
 
-static uint32_t pick_qb(uint32_t B) {
+static uint32_t pick_qb(uint32_t B, bool bounded = false) {
   // queries per block: the smallest padded query count wins (a block computes all its QB slots); ties go to the larger
-  // block (fewer re-reads of the tiles)
+  // block (fewer re-reads of the tiles).  With a coordinate bound 33..64 queries already take the matrix-core block of
+  // 128 (half of it padding, and still three times faster than the packed-fp32 pre-filter of a 64-query block: 51 against
+  // 147 us at 1 Mi rows); the row-slice count does not depend on this choice (one query block either way).
   if (B <= 8) return 8;
   if (B <= 16) return 16;
   if (B <= 32) return 32;
-  if (B <= 64) return 64;
+  if (B <= 64 && !(bounded && mfma_enabled() && bf16_enabled())) return 64;
   if (mfma_enabled()) return kMfmaQueries;
   const uint32_t pad128 = (B + 127) / 128 * 128, pad256 = (B + 255) / 256 * 256;
   return pad128 < pad256 ? 128 : 256;
@@ -1597,7 +1603,7 @@ template <int DP>
 static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
                                 uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0,
                                 hipEvent_t ev1, double coord_bound, const uint32_t* d_yblock_base, bool table_has_seed) {
-  const uint32_t qb = pick_qb(B);
+  const uint32_t qb = pick_qb(B, coord_bound > 0.0 && DP >= kBf16MinDims && DP <= 16);
   const uint32_t gy = (B + qb - 1) / qb;
   // few queries over a large tree with known coordinate bounds: matrix-core pre-filter at the speed of HBM
   const bool few = few_applies(B, D, DP, n_upper, coord_bound);
@@ -1646,7 +1652,7 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
         hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP, true>), blocks_for(gxs), dim3(kMfmaThreads), 0, s, single, d_table, D,
                            Bpad, coord_bound, yb, n_problems, gxs, gy);
       }
-      if (bf16_enabled()) {
+      if (bf16_enabled() && DP >= kBf16MinDims) {
         g_last_kernel = "nn1_sweep_bf16_kernel";
         hipLaunchKernelGGL((nn1_sweep_bf16_kernel<DP>), blocks_for(gx), dim3(kMfmaThreads), 0, s, single, d_table, D, Bpad,
                            coord_bound, yb, n_problems, gx, gy);

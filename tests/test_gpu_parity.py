@@ -46,9 +46,9 @@ def test_nn1_bit_exact(L, ctx, oracle, D, n, B):
 
 
 @pytest.mark.parametrize("D,n,B,expect", [(12, 30000, 300, "nn1_sweep_bf16_kernel"), (12, 777, 129, "nn1_sweep_bf16_kernel"),
-                                           (6, 20000, 200, "nn1_sweep_bf16_kernel"), (3, 5000, 1000, "nn1_sweep_bf16_kernel"),
-                                           (16, 9000, 130, "nn1_sweep_bf16_kernel"), (12, 30000, 48, "nn1_sweep_f32_kernel"),
-                                           (12, 600000, 200, "nn1_sweep_bf16_kernel"), (6, 8192, 1000, "nn1_sweep_bf16_kernel"),
+                                           (6, 20000, 200, "nn1_sweep_mfma_kernel"), (3, 5000, 1000, "nn1_sweep_mfma_kernel"),
+                                           (16, 9000, 130, "nn1_sweep_bf16_kernel"), (12, 30000, 48, "nn1_sweep_bf16_kernel"), (24, 4000, 48, "nn1_sweep_f32_kernel"), (7, 5000, 64, "nn1_sweep_bf16_kernel"), (8, 40000, 500, "nn1_sweep_bf16_kernel"),
+                                           (12, 600000, 200, "nn1_sweep_bf16_kernel"), (6, 8192, 1000, "nn1_sweep_mfma_kernel"),
                                            (24, 4000, 200, "nn1_sweep_f32_kernel"),
                                            # few queries over a large tree: one wave per 32-row slab, no LDS tile
                                            (12, 70001, 8, "nn1_few_mfma_kernel"), (12, 65536, 1, "nn1_stream_kernel"),
