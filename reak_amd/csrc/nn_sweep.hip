@@ -747,12 +747,12 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
       };
       // the estimates of slab g are complete: running minimum, and (sweep proper) one entry if a row is within the band
       auto settle = [&](int g, const rkh_f16v& c) {
-        // (v_min3 spelled out: fminf would first quiet every operand, one more VALU operation per estimate; the
-        // estimates are finite by construction)
-        float m = min3_raw(min3_raw(c[0], c[1], c[2]), min3_raw(c[3], c[4], c[5]), min3_raw(c[6], c[7], c[8]));
-        m = min3_raw(m, min3_raw(c[9], c[10], c[11]), min3_raw(c[12], c[13], c[14]));
-        m = min3_raw(m, c[15], m);
-        cmin = min3_raw(cmin, m, m);
+        // (through the compiler, so that the wait states between a matrix instruction and the VALU reads of its result
+        // are counted: see min3_f)
+        float m = min3_f(min3_f(c[0], c[1], c[2]), min3_f(c[3], c[4], c[5]), min3_f(c[6], c[7], c[8]));
+        m = min3_f(m, min3_f(c[9], c[10], c[11]), min3_f(c[12], c[13], c[14]));
+        m = __builtin_fminf(m, c[15]);
+        cmin = __builtin_fminf(cmin, m);
         if (SEED) return;
         // over both lane halves: the pair then meets a new minimum as often as ONE sequence of twice the length would
         cmin = min_over_halves(cmin);
