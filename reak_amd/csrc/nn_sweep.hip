@@ -829,6 +829,13 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_mfma_kernel(NnArgs 
 // magnitude 3 Dp M'^2 PER PRODUCT SLOT of four instructions (256 roundings; an IEEE f32 sum of them would stay below a
 // quarter of that); the float |x^|^2 chains and the double -> float rounding of the inputs as in the f32 kernel.  E is
 // their sum with a factor 2, the band 2 E plus the rounding of (running minimum + band).
+#ifndef RKH_BF16_PIPELINED
+#define RKH_BF16_PIPELINED 0
+#endif
+#ifndef RKH_BF16_CAP
+#define RKH_BF16_CAP 4
+#endif
+static constexpr int kBf16Cap = RKH_BF16_CAP;  // entries per lane of the bf16 sweep (LDS: a fourth block per CU)
 typedef __bf16 rkh_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 rkh_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float rkh_f2v __attribute__((ext_vector_type(2)));
@@ -918,9 +925,9 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_bf16_kernel(NnArgs 
   constexpr int kSlabs = kTileRows / 32;
   // A operands of the tile: fragment i of (row, lane half) -- consecutive rows 16 bytes apart: conflict-free ds_read_b128
   __shared__ uint4 tileA[NI][2][kTileRows];
-  __shared__ uint32_t cand_key[kCandCap][kMfmaThreads];
-  __shared__ uint32_t cand_mask[kCandCap][kMfmaThreads];
-  __shared__ float cand_m[kCandCap][kMfmaThreads];
+  __shared__ uint32_t cand_key[kBf16Cap][kMfmaThreads];
+  __shared__ uint32_t cand_mask[kBf16Cap][kMfmaThreads];
+  __shared__ float cand_m[kBf16Cap][kMfmaThreads];
 
   uint32_t bx, by, bz;
   {
@@ -1045,7 +1052,7 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_bf16_kernel(NnArgs 
       }
     }
     cnt = w;
-    if (cnt == kCandCap) {
+    if (cnt == kBf16Cap) {
 #pragma unroll 1
       for (int k = 0; k < cnt; ++k) resolve_entry(k);
       cnt = 0;
@@ -1119,7 +1126,7 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_bf16_kernel(NnArgs 
         cmin = min_over_halves(cmin);
         const float lim = cmin + band;
         if (m <= lim) {
-          if (cnt == kCandCap) compact(lim);
+          if (cnt == kBf16Cap) compact(lim);
           uint32_t mask = 0;
 #pragma unroll
           for (int i = 0; i < 16; ++i) mask |= (c[i] <= lim) ? (1u << i) : 0u;
@@ -1129,6 +1136,7 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_bf16_kernel(NnArgs 
           ++cnt;
         }
       };
+#if RKH_BF16_PIPELINED
       rkh_f16v c0, c1;
       uint4 a0[NI], a1[NI];
       load_ops(0, a0, c0);
@@ -1144,6 +1152,18 @@ __global__ __launch_bounds__(kMfmaThreads, 4) void nn1_sweep_bf16_kernel(NnArgs 
         }
         settle(g + 1, c1);
       }
+#else
+      // one accumulator: the bf16 matrix instructions overlap with the VALU work of the SIMD's other waves, and the
+      // registers of a second accumulator are worth a fourth wave per SIMD
+#pragma unroll
+      for (int g = 0; g < kSlabs; ++g) {
+        rkh_f16v c0;
+        uint4 a0[NI];
+        load_ops(g, a0, c0);
+        chain(a0, c0);
+        settle(g, c0);
+      }
+#endif
     }
     __syncthreads();
   }
