@@ -93,8 +93,8 @@ rkh_status rkh_nn_queryk_async(rkh_nn* nn, const double* d_q, uint32_t B, uint32
 /* Promise that every |coordinate| of the stored vertices and of all later queries is <= bound (for a hyperbox_topology:
  * the largest |corner coordinate|, ctrl/topologies/hyperbox_topology.hpp:97-103).  Sweeps of 5 or more queries then run a
  * single-precision pre-filter (the fp32 matrix instructions for 5..32 queries over at least 8192 vertices and for more
- * than 64 queries, packed fp32 VALU between) in front of the exact fp64 test; results stay bit-identical.  bound = 0
- * (default) switches the pre-filters off.
+ * than 32 queries, as a split-bf16 estimate from 7 dimensions on) in front of the exact fp64 test; results stay
+ * bit-identical.  bound = 0 (default) switches the pre-filters off, and so does a bound outside [1e-6, 1e6].
  * The promise is checked where the library holds the data on the host: rkh_nn_append and rkh_nn_query1 return
  * RKH_ERR_BAD_ARG for a coordinate beyond the bound, and so does this call if rows already stored exceed it.  Queries
  * handed over in HBM (rkh_nn_query1_async) are the caller's responsibility: a query outside the bound may return a

@@ -1511,10 +1511,17 @@ static bool mfma_enabled() {
   return on;
 }
 
-// The split-bf16 band is ~100x the f32 one: in few dimensions, where the nearest neighbours of a dense cloud sit close
-// together, it lets more rows through to the exact test than the cheaper instructions save (6-D, 25 000 x 1000, the
-// reference's published configuration: 42 us against 36) -- from 8 padded dimensions on the bf16 form is used.
-static constexpr int kBf16MinDims = 8;
+// The split-bf16 band is ~100x the f32 one: in very few dimensions, where the nearest neighbours of a dense cloud sit
+// close together, it lets more rows through to the exact test than the cheaper instructions save (unit cube, 1 Mi x 1024
+// queries, tests/diag_nn_lowdim.py: 3-D 159 against 154 us, 65 536 x 384: 27 against 23; 4-D 30 against 33; 6-D 123
+// against 199) -- from 6 padded dimensions on the bf16 form is used.
+static int bf16_min_dims() {  // RKH_NN_BF16_MIN_DIMS overrides (diagnostics)
+  static const int v = [] {
+    const char* e = getenv("RKH_NN_BF16_MIN_DIMS");
+    return e ? atoi(e) : 6;
+  }();
+  return v;
+}
 // RKH_NN_BF16=0 keeps the f32-input matrix instructions in the many-queries sweep (diagnostics: tests/prof_nn_variants.sh)
 static bool bf16_enabled() {
   static const bool on = [] {
@@ -1623,7 +1630,7 @@ template <int DP>
 static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
                                 uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0,
                                 hipEvent_t ev1, double coord_bound, const uint32_t* d_yblock_base, bool table_has_seed) {
-  const uint32_t qb = pick_qb(B, coord_bound > 0.0 && DP >= kBf16MinDims && DP <= 16);
+  const uint32_t qb = pick_qb(B, coord_bound > 0.0 && DP >= bf16_min_dims() && DP <= 16);
   const uint32_t gy = (B + qb - 1) / qb;
   // few queries over a large tree with known coordinate bounds: matrix-core pre-filter at the speed of HBM
   const bool few = few_applies(B, D, DP, n_upper, coord_bound);
@@ -1672,7 +1679,7 @@ static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, cons
         hipLaunchKernelGGL((nn1_sweep_mfma_kernel<DP, true>), blocks_for(gxs), dim3(kMfmaThreads), 0, s, single, d_table, D,
                            Bpad, coord_bound, yb, n_problems, gxs, gy);
       }
-      if (bf16_enabled() && DP >= kBf16MinDims) {
+      if (bf16_enabled() && DP >= bf16_min_dims()) {
         g_last_kernel = "nn1_sweep_bf16_kernel";
         hipLaunchKernelGGL((nn1_sweep_bf16_kernel<DP>), blocks_for(gx), dim3(kMfmaThreads), 0, s, single, d_table, D, Bpad,
                            coord_bound, yb, n_problems, gx, gy);
@@ -1703,6 +1710,10 @@ rkh_status launch_nn1(hipStream_t s, int D, const NnArgs& single, const NnArgs* 
                       uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0, hipEvent_t ev1,
                       double coord_bound, const uint32_t* d_yblock_base, bool table_has_seed) {
   if (B == 0 || n_problems == 0) return RKH_OK;
+  // the error analysis of the pre-filters is relative to the bound: it assumes that neither the float products nor the
+  // bf16 pieces leave the normal range (and that 1e18, the stand-in for rows that must never qualify, is far outside
+  // the cloud).  Clouds scaled beyond that are swept by the exact kernels.
+  if (!(coord_bound >= 1e-6 && coord_bound <= 1e6)) coord_bound = 0.0;
   switch (padded_dims(D)) {
 #define RKH_CASE(DP) \
   case DP: return launch_nn1_dp<DP>(s, D, single, d_table, n_problems, n_upper, B, part_capacity_blocks, ev0, ev1, coord_bound, \

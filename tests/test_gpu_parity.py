@@ -46,9 +46,9 @@ def test_nn1_bit_exact(L, ctx, oracle, D, n, B):
 
 
 @pytest.mark.parametrize("D,n,B,expect", [(12, 30000, 300, "nn1_sweep_bf16_kernel"), (12, 777, 129, "nn1_sweep_bf16_kernel"),
-                                           (6, 20000, 200, "nn1_sweep_mfma_kernel"), (3, 5000, 1000, "nn1_sweep_mfma_kernel"),
+                                           (6, 20000, 200, "nn1_sweep_bf16_kernel"), (3, 5000, 1000, "nn1_sweep_mfma_kernel"),
                                            (16, 9000, 130, "nn1_sweep_bf16_kernel"), (12, 30000, 48, "nn1_sweep_bf16_kernel"), (24, 4000, 48, "nn1_sweep_f32_kernel"), (7, 5000, 64, "nn1_sweep_bf16_kernel"), (8, 40000, 500, "nn1_sweep_bf16_kernel"),
-                                           (12, 600000, 200, "nn1_sweep_bf16_kernel"), (6, 8192, 1000, "nn1_sweep_mfma_kernel"),
+                                           (12, 600000, 200, "nn1_sweep_bf16_kernel"), (6, 8192, 1000, "nn1_sweep_bf16_kernel"),
                                            (24, 4000, 200, "nn1_sweep_f32_kernel"),
                                            # few queries over a large tree: one wave per 32-row slab, no LDS tile
                                            (12, 70001, 8, "nn1_few_mfma_kernel"), (12, 65536, 1, "nn1_stream_kernel"),
@@ -83,6 +83,22 @@ def test_nn1_single_precision_prefilters_are_bit_exact(L, ctx, oracle, D, n, B, 
     ridx, rdist = oracle.nn1(q, pts)
     assert np.array_equal(idx, ridx)
     assert np.array_equal(dist, rdist)
+
+
+@pytest.mark.parametrize("scale", [1e-9, 1e9])
+def test_prefilters_step_aside_for_extreme_scales(L, ctx, oracle, scale):
+    """The pre-filters' error analysis assumes float products and bf16 pieces in the normal range: clouds with a coordinate
+    bound outside [1e-6, 1e6] are swept by the exact fp64 kernels."""
+    rng = np.random.default_rng(77)
+    pts = rng.uniform(-1, 1, size=(20000, 12)) * scale
+    q = rng.uniform(-1, 1, size=(300, 12)) * scale
+    nn = L.HipNeighborSearch(ctx, 12, 20000)
+    nn.added_vertices(pts)
+    nn.set_coord_bound(scale)
+    idx, dist = nn.nearest(q)
+    assert nn.kernel_name() == "nn1_sweep_kernel"
+    ridx, rdist = oracle.nn1(q, pts)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
 
 
 def test_coordinate_bound_is_checked_where_the_library_holds_the_data(L, ctx):
