@@ -91,10 +91,14 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
   __shared__ uint32_t s_scan[3][2 * kCache + 1];
   const bool cached = P <= kCache;
   const uint32_t tid = threadIdx.x;
+  // With the wave fit on, a problem's candidates are a whole number of 32-edge steer waves: every (problem, candidates)
+  // segment of the steer grid otherwise ends in a wave that is half empty on average (256 such waves per round of ~2700).
+  const bool wave_round = fit_fill > 0.0f && epw > 1u;
   auto batch_of = [&](const PlannerState* st, float sc) -> uint32_t {
     if (st->done) return 0u;
     const float want = sc * st->batch_factor * sqrtf(float(st->n));
     uint32_t B = uint32_t(want);
+    if (wave_round && B >= epw) B -= B % epw;  // whole steer waves: no half-empty last wave per problem
     if (B < st->b_min) B = st->b_min;
     if (B > st->b_max) B = st->b_max;
     const uint32_t avail = st->samples_ready - st->s0;
@@ -117,6 +121,7 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
   auto batch_cached = [&](uint32_t i, float sc) -> uint32_t {  // same value as batch_of(probs[i].st, sc)
     const float want = sc * s_bf[i] * s_sq[i];
     uint32_t B = uint32_t(want);
+    if (wave_round && B >= epw) B -= B % epw;
     if (B < s_bmin[i]) B = s_bmin[i];
     if (B > s_bcap[i]) B = s_bcap[i];
     return B;
