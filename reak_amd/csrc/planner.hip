@@ -72,6 +72,7 @@ struct ProblemDev {  // device pointers of one problem
 // counter of this round's parity and block 0 clears the other one for the next round; the two steer kernels of the
 // round compare the sum with their threshold (see launch_edges).
 constexpr uint32_t kProfRounds = 8192;  // profiled rounds per planner (RKH_PROFILE_NN)
+constexpr uint32_t kProbeGranule = 32;  // goal probes ride in whole steer waves when the wave fit is on (commit_kernel)
 // One block for all problems.  Batch sizes: B = scale * batch_factor * sqrt(n) (results do not depend on them).  With
 // fit_fill > 0 the scale of the round is chosen here, from the exact counts: the two-lanes steer kernel runs one wave of
 // 32 edges per SIMD (`slots` waves at a time), so the steer time of a round is its number of waves divided by `slots`,
@@ -255,7 +256,11 @@ __global__ __launch_bounds__(256) void fixup_kernel(const ProblemDev* __restrict
 
 // One 256-thread block per problem: commit candidates [0, F) in order (prefix scan of the accept flags),
 // honouring the vertex budget of keep_going() (motion_planner_base.hpp:355-374).
-__global__ __launch_bounds__(256) void commit_kernel(const ProblemDev* __restrict__ probs, int D, int DP) {
+// probe_granule: goal probes ride in the next steer launch in whole groups of this many (32 = one steer wave of the
+// two-lanes mapping: a (problem, probes) segment of the grid then has no half-empty last wave; what is left over waits
+// for the vertices of the next round, the last ones for flush_probes; 1 = every pending probe rides along).
+__global__ __launch_bounds__(256) void commit_kernel(const ProblemDev* __restrict__ probs, int D, int DP,
+                                                      uint32_t probe_granule) {
   __shared__ uint32_t scan[256];
   __shared__ uint32_t carry;
   __shared__ uint32_t cut;  // number of candidates actually consumed
@@ -305,10 +310,13 @@ __global__ __launch_bounds__(256) void commit_kernel(const ProblemDev* __restric
   if (threadIdx.x == 0) {
     const uint32_t added = carry < budget ? carry : budget;
     st->n = n0 + added;
-    // the propagate launch of this round also ran the goal probes that were pending: [n_before, n_before+n_new)
-    st->probed_n = st->n_before + st->n_new;
-    st->n_new = added;  // this round's vertices are probed by the next launch
-    st->n_before = n0;
+    // the propagate launch of this round also ran the first n_new of the pending goal probes: [n_before, n_before+n_new)
+    const uint32_t first_pending = st->n_before + st->n_new;
+    st->probed_n = first_pending;
+    st->n_before = first_pending;
+    // the next launch takes the pending ones (this round's vertices included) in whole granules
+    const uint32_t pending = n0 + added - first_pending;
+    st->n_new = pending - pending % probe_granule;
     st->s0 = s0 + cut;
     st->fixup_cut += (st->B - F);
     if (st->n >= st->max_total) st->done = 1;
@@ -397,6 +405,13 @@ struct GoalSeg {
 __global__ __launch_bounds__(256) void gather_goal_dist_kernel(const GoalSeg* __restrict__ tab, double* __restrict__ out) {
   const GoalSeg g = tab[blockIdx.x];
   for (uint64_t i = threadIdx.x; i < g.count; i += 256) out[g.dst_off + i] = g.src[i];
+}
+
+// before the flush launch: every pending probe rides, whatever the granule
+__global__ void probes_take_all_kernel(const ProblemDev* __restrict__ probs) {
+  if (threadIdx.x != 0) return;
+  PlannerState* st = probs[blockIdx.x].st;
+  st->n_new = st->n - st->n_before;
 }
 
 __global__ void probes_flushed_kernel(const ProblemDev* __restrict__ probs) {
@@ -605,7 +620,8 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
 
 // goal probes still pending after the last enqueued round
 rkh_status flush_probes(rkh_planner* p) {
-  rkh_status st = launch_edges(p, p->b_max, 0, p->d_io_probe, nullptr);
+  hipLaunchKernelGGL(probes_take_all_kernel, dim3(p->P), dim3(64), 0, p->stream, p->d_probs);
+  rkh_status st = launch_edges(p, p->b_max + kProbeGranule, 0, p->d_io_probe, nullptr);
   if (st != RKH_OK) return st;
   hipLaunchKernelGGL(probes_flushed_kernel, dim3(p->P), dim3(64), 0, p->stream, p->d_probs);
   RKH_HIP(hipGetLastError());
@@ -647,7 +663,7 @@ rkh_status enqueue_round(rkh_planner* p) {
     p->n_ub[i] = std::min<uint64_t>(p->n_ub[i] + b, uint64_t(hs.max_total));
   }
   const uint32_t probe_ub = p->prev_batch_ub ? p->prev_batch_ub : p->b_max;
-  p->prev_batch_ub = batch_ub;
+  p->prev_batch_ub = batch_ub + kProbeGranule;  // next round's probes: this round's vertices + what was left over
   p->round_parity ^= 1u;
   hipLaunchKernelGGL(round_begin_kernel, dim3(1), dim3(256), 0, s, p->d_probs, p->P, slot, p->d_sel, p->round_parity,
                      fit ? float(p->wave_fill) : 0.0f, p->wave_slots, p->d_wave_base, p->d_nn_base, nn1_mfma_queries(),
@@ -674,7 +690,7 @@ rkh_status enqueue_round(rkh_planner* p) {
     default: set_error("planner: unsupported state dimension"); return RKH_ERR_UNSUPPORTED;
   }
   // 4. commit the valid prefix
-  hipLaunchKernelGGL(commit_kernel, dim3(p->P), dim3(256), 0, s, p->d_probs, p->D, p->DP);
+  hipLaunchKernelGGL(commit_kernel, dim3(p->P), dim3(256), 0, s, p->d_probs, p->D, p->DP, fit ? kProbeGranule : 1u);
   RKH_HIP(hipGetLastError());
   return RKH_OK;
 }
@@ -895,8 +911,8 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     RKH_HIP(hipMalloc(&q.d_x_out, uint64_t(p->b_max) * D * sizeof(double)));
     RKH_HIP(hipMalloc(&q.d_steps, p->b_max * sizeof(uint32_t)));
     RKH_HIP(hipMalloc(&q.d_accept, p->b_max));
-    RKH_HIP(hipMalloc(&q.d_probe_x, uint64_t(p->b_max) * D * sizeof(double)));
-    RKH_HIP(hipMalloc(&q.d_probe_steps, p->b_max * sizeof(uint32_t)));
+    RKH_HIP(hipMalloc(&q.d_probe_x, uint64_t(p->b_max + kProbeGranule) * D * sizeof(double)));
+    RKH_HIP(hipMalloc(&q.d_probe_steps, (p->b_max + kProbeGranule) * sizeof(uint32_t)));
     RKH_HIP(hipMalloc(&q.d_goal, D * sizeof(double)));
     RKH_HIP(hipMalloc(&q.d_part_dist, uint64_t(p->part_blocks) * p->b_max * sizeof(double)));
     // one more row than the partials need: NnArgs::seed (sampled minima of the matrix-core sweep, "none" = all ones)
@@ -969,7 +985,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     gp.src_stride = DP;
     gp.tgt = q.d_goal;
     gp.tgt_stride = 0;
-    gp.B = p->b_max;
+    gp.B = p->b_max + kProbeGranule;
     gp.d_B = &dst->n_new;
     gp.x_out = q.d_probe_x;
     gp.steps_free = q.d_probe_steps;
