@@ -843,14 +843,18 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   if (p->lanes_per_edge == 16 && 2 * p->n_dof > 16) p->lanes_per_edge = 64;  // a 16-lane group holds at most 16 components
   if (scene->host.planar) p->lanes_per_edge = 64;  // planar chains have one mapping (one lane per edge, propagate_planar.hip)
   if (const char* e = getenv("RKH_PROFILE_NN")) p->profile_nn = atoi(e) != 0;
-  // candidates per round = batch_factor * sqrt(n) per problem (results do not depend on it).  A round costs about the
-  // same until its edges fill the chip (~64k edges: 2048 resident steer waves of 32), so the factor is what brings a
-  // mid-run round (n = max_vertices / 2) of all problems to that fill -- between 1.25, the measured optimum once the
-  // chip is full anyway (less discarded speculation; 256 problems), and 4 (16 problems: 444k vs 322k expansions/s with
-  // 1.25).  A single problem is bound by the latency of one edge: 2 and 4 measure the same, 2 checks fewer edges.
+  // candidates per round = batch_factor * sqrt(n) per problem (results do not depend on it).  More candidates per
+  // round mean fewer rounds but more discarded speculation (0.89 of the propagated edges are committed at 1.25, 0.72 at
+  // 2, 0.55 at 3, 0.45 at 4), and a round is only cheap to enlarge while the chip is not full.  Measured optimum
+  // (tests/diag_bench_sweep.sh, tests/diag_single.py): 1.25 for 256 problems x 100 000 vertices (5.6 M expansions/s),
+  // 2 for 32 ... 128 problems (64 x 100 000: 3.03 M against 2.86 at 1.25 and 2.51 at 4), 4 for 16 (444 k against 322 k
+  // at 1.25), 2 = 4 for a single problem (bound by the latency of one edge; 2 checks fewer edges).  The rule: what
+  // brings a mid-run round (n = max_vertices / 2) of all problems to ~32 k edges -- one 32-edge steer wave per SIMD --
+  // within [1.25, 2], up to 4 for at most 16 problems.
   double mid_sqrt_sum = 0.0;
   for (uint32_t i = 0; i < n_problems; ++i) mid_sqrt_sum += std::sqrt(0.5 * double(prms[i].max_vertices));
-  float batch_factor = float(std::min(n_problems == 1 ? 2.0 : 4.0, std::max(1.25, 65536.0 / mid_sqrt_sum)));
+  const double factor_cap = n_problems == 1 ? 2.0 : (n_problems <= 16 ? 4.0 : 2.0);
+  float batch_factor = float(std::min(factor_cap, std::max(1.25, 32768.0 / mid_sqrt_sum)));
   uint32_t b_min = 8;
   if (const char* e = getenv("RKH_BATCH_FACTOR")) batch_factor = float(atof(e));
   if (const char* e = getenv("RKH_BATCH_MIN")) b_min = std::max(1, atoi(e));
