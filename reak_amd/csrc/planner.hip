@@ -407,6 +407,52 @@ __global__ __launch_bounds__(256) void gather_goal_dist_kernel(const GoalSeg* __
   for (uint64_t i = threadIdx.x; i < g.count; i += 256) out[g.dst_off + i] = g.src[i];
 }
 
+// Phase boundary of a split steer launch (launch_edges): the edges of a (problem, candidates | probes) segment whose
+// first `k_split` steps were all free go on, their ids are written to the segment's list (any order: edges are
+// independent and their results are indexed by the edge).  One block per segment.  Runs only when the two-lanes
+// mapping ran the first phase (the same gate); otherwise the lists are empty and the second launch finds no work.
+__global__ __launch_bounds__(256) void phase_compact_kernel(const EdgeIO* __restrict__ tab_a, const EdgeIO* __restrict__ tab_b,
+                                                             const EdgeIO* __restrict__ tab2_a,
+                                                             const EdgeIO* __restrict__ tab2_b, uint32_t k_split,
+                                                             uint32_t* __restrict__ cnt2, KernelGate gate) {
+  __shared__ uint32_t s_cnt;
+  const uint32_t prob = blockIdx.x, g = blockIdx.y;
+  const EdgeIO io = g ? tab_b[prob] : tab_a[prob];
+  uint32_t* ids = const_cast<uint32_t*>((g ? tab2_b[prob] : tab2_a[prob]).edge_ids);
+  if (threadIdx.x == 0) s_cnt = 0u;
+  __syncthreads();
+  bool run = true;
+  if (gate.count) {
+    const uint32_t c = *gate.count;
+    run = c >= gate.lo && c < gate.hi;
+  }
+  const uint32_t B = run ? (io.d_B ? *io.d_B : io.B) : 0u;
+  const int lane = threadIdx.x & 63;
+  for (uint32_t base = 0; base < B; base += 256) {
+    const uint32_t e = base + threadIdx.x;
+    const bool on = e < B && io.steps_free[e] == k_split;
+    const unsigned long long m = __ballot(on);
+    uint32_t off = 0;
+    if (lane == 0 && m) off = atomicAdd(&s_cnt, uint32_t(__popcll(m)));
+    off = __shfl(off, 0, 64);
+    if (on) ids[off + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = e;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) cnt2[2 * prob + g] = s_cnt;
+}
+
+// exclusive prefix of the second phase's working waves per segment (the KernelGate::wave_base of its launch)
+__global__ void phase_scan_kernel(const uint32_t* __restrict__ cnt2, uint32_t n_segments, uint32_t epw,
+                                  uint32_t* __restrict__ wave_base2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t acc = 0;
+  wave_base2[0] = 0;
+  for (uint32_t k = 0; k < n_segments; ++k) {
+    acc += (cnt2[k] + epw - 1u) / epw;
+    wave_base2[k + 1] = acc;
+  }
+}
+
 // before the flush launch: every pending probe rides, whatever the granule
 __global__ void probes_take_all_kernel(const ProblemDev* __restrict__ probs) {
   if (threadIdx.x != 0) return;
@@ -445,6 +491,8 @@ struct Problem {  // host view of one planning problem
   uint8_t* d_accept = nullptr;
   double* d_probe_x = nullptr;
   uint32_t* d_probe_steps = nullptr;
+  uint32_t* d_ids_c = nullptr;  // survivors of the first steer phase: candidates, goal probes (launch_edges)
+  uint32_t* d_ids_p = nullptr;
   double* d_goal = nullptr;
   double* d_part_dist = nullptr;
   uint32_t* d_part_idx = nullptr;
@@ -499,6 +547,12 @@ struct rkh_planner {
   NnArgs* d_nn_args = nullptr;
   EdgeIO* d_io_steer = nullptr;
   EdgeIO* d_io_probe = nullptr;
+  // second phase of a split steer launch (launch_edges): the same records with the survivors' lists
+  EdgeIO* d_io_steer2 = nullptr;
+  EdgeIO* d_io_probe2 = nullptr;
+  uint32_t* d_cnt2 = nullptr;        // [2 P] survivors per (problem, candidates | probes) segment
+  uint32_t* d_wave_base2 = nullptr;  // [2 P + 1] prefix of their waves
+  uint32_t steer_split = 5;          // steps of the first phase (RKH_STEER_SPLIT; 0 = one launch for the whole edge)
   // segment tables of the sample generator: [0] what the enqueued rounds need, [1] the next call's share, generated
   // while the GPU works on the rounds just enqueued
   double* d_bounds = nullptr;  // lower[D], upper[D] of the sampled hyperbox
@@ -613,9 +667,33 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
                                    p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, 64, tab_a, tab_b, p->P,
                                    nullptr, gate_wave);
   if (st != RKH_OK) return st;
+  // The two-lanes mapping in two phases when the round is a regular one: half of the edges of a round end within a few
+  // steps (tests/diag_edge_lifetimes.py) and leave their lanes idle for the rest of their wave, so the first
+  // steer_split steps run for every edge, the survivors are compacted per segment and only they run the remaining
+  // steps -- in fewer waves.  Same arithmetic per edge, same results.
+  const bool split = compact && p->d_wave_base && p->d_io_steer2 && p->lane_variant == 2 && p->steer_split > 0 &&
+                     int(p->steer_split) < p->dyn.n_steps && tab_a == p->d_io_steer && tab_b == p->d_io_probe;
+  if (!split)
+    return launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
+                            p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b,
+                            p->P, p->d_lane_ws, gate_lane);
+  KernelGate g1 = gate_lane;
+  g1.step1 = p->steer_split;
+  st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
+                        p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b, p->P,
+                        p->d_lane_ws, g1);
+  if (st != RKH_OK) return st;
+  hipLaunchKernelGGL(phase_compact_kernel, dim3(p->P, 2), dim3(256), 0, p->stream, p->d_io_steer, p->d_io_probe,
+                     p->d_io_steer2, p->d_io_probe2, p->steer_split, p->d_cnt2, gate_lane);
+  hipLaunchKernelGGL(phase_scan_kernel, dim3(1), dim3(64), 0, p->stream, p->d_cnt2, 2 * p->P,
+                     lane_kernel_edges_per_wave(), p->d_wave_base2);
+  KernelGate g2 = gate_lane;
+  g2.wave_base = p->d_wave_base2;
+  g2.n_segments = 2 * p->P;
+  g2.step0 = p->steer_split;
   return launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                          p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b, p->P,
-                          p->d_lane_ws, gate_lane);
+                          p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, p->d_io_steer2,
+                          p->d_io_probe2, p->P, p->d_lane_ws, g2);
 }
 
 // goal probes still pending after the last enqueued round
@@ -698,7 +776,7 @@ rkh_status enqueue_round(rkh_planner* p) {
 void free_problem(Problem& q) {
   void* bufs[] = {q.d_tree, q.d_parent, q.d_node_sample, q.d_goal_dist, q.d_samples, q.d_nn_seq, q.d_accept_log,
                   q.d_nn_idx, q.d_nn_dist, q.d_x_out, q.d_steps, q.d_accept, q.d_probe_x, q.d_probe_steps, q.d_goal,
-                  q.d_part_dist, q.d_part_idx, q.d_round_n, q.d_mt};
+                  q.d_part_dist, q.d_part_idx, q.d_round_n, q.d_mt, q.d_ids_c, q.d_ids_p};
   for (void* b : bufs) (void)hipFree(b);
 }
 
@@ -731,6 +809,7 @@ rkh_status grow_sample_buffers(rkh_planner* p, uint32_t i, uint64_t new_cap) {
   RKH_HIP(hipMemcpy(&p->d_probs[i].accept_log, &na, sizeof(na), hipMemcpyHostToDevice));
   RKH_HIP(hipMemcpy(&p->d_nn_args[i].q, &cs, sizeof(cs), hipMemcpyHostToDevice));
   RKH_HIP(hipMemcpy(&p->d_io_steer[i].tgt, &cs, sizeof(cs), hipMemcpyHostToDevice));
+  if (p->d_io_steer2) RKH_HIP(hipMemcpy(&p->d_io_steer2[i].tgt, &cs, sizeof(cs), hipMemcpyHostToDevice));
   return RKH_OK;
 }
 
@@ -817,6 +896,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   }
   if (const char* e = getenv("RKH_LANE_VARIANT")) p->lane_variant = (atoi(e) == 1) ? 1 : 2;
   if (const char* e = getenv("RKH_WAVE_FIT")) p->wave_fit = atoi(e);
+  if (const char* e = getenv("RKH_STEER_SPLIT")) p->steer_split = uint32_t(std::max(0, atoi(e)));
   if (const char* e = getenv("RKH_WAVE_FILL")) p->wave_fill = atof(e);
   {
     hipDeviceProp_t prop;
@@ -1002,6 +1082,28 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   RKH_HIP(hipMemcpy(p->d_nn_args, hn.data(), P * sizeof(NnArgs), hipMemcpyHostToDevice));
   RKH_HIP(hipMemcpy(p->d_io_steer, hio.data(), P * sizeof(EdgeIO), hipMemcpyHostToDevice));
   RKH_HIP(hipMemcpy(p->d_io_probe, hgp.data(), P * sizeof(EdgeIO), hipMemcpyHostToDevice));
+  if (p->d_wave_base && !p->quasi_static) {  // second phase of a split steer launch: the same edges through the survivors' lists
+    RKH_HIP(hipMalloc(&p->d_io_steer2, P * sizeof(EdgeIO)));
+    RKH_HIP(hipMalloc(&p->d_io_probe2, P * sizeof(EdgeIO)));
+    RKH_HIP(hipMalloc(&p->d_cnt2, 2 * size_t(P) * sizeof(uint32_t)));
+    RKH_HIP(hipMemset(p->d_cnt2, 0, 2 * size_t(P) * sizeof(uint32_t)));
+    RKH_HIP(hipMalloc(&p->d_wave_base2, (2 * size_t(P) + 1) * sizeof(uint32_t)));
+    RKH_HIP(hipMemset(p->d_wave_base2, 0, (2 * size_t(P) + 1) * sizeof(uint32_t)));
+    std::vector<EdgeIO> hio2 = hio, hgp2 = hgp;
+    for (uint32_t i = 0; i < P; ++i) {
+      Problem& q = p->prob[i];
+      RKH_HIP(hipMalloc(&q.d_ids_c, size_t(p->b_max) * sizeof(uint32_t)));
+      RKH_HIP(hipMalloc(&q.d_ids_p, size_t(p->b_max + kProbeGranule) * sizeof(uint32_t)));
+      hio2[i].edge_ids = q.d_ids_c;
+      hio2[i].resume = hio[i].x_out;
+      hio2[i].d_B = p->d_cnt2 + 2 * i;
+      hgp2[i].edge_ids = q.d_ids_p;
+      hgp2[i].resume = hgp[i].x_out;
+      hgp2[i].d_B = p->d_cnt2 + 2 * i + 1;
+    }
+    RKH_HIP(hipMemcpy(p->d_io_steer2, hio2.data(), P * sizeof(EdgeIO), hipMemcpyHostToDevice));
+    RKH_HIP(hipMemcpy(p->d_io_probe2, hgp2.data(), P * sizeof(EdgeIO), hipMemcpyHostToDevice));
+  }
   *out = p;
   return RKH_OK;
 }
@@ -1038,6 +1140,10 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   (void)hipFree(p->d_nn_args);
   (void)hipFree(p->d_io_steer);
   (void)hipFree(p->d_io_probe);
+  (void)hipFree(p->d_io_steer2);
+  (void)hipFree(p->d_io_probe2);
+  (void)hipFree(p->d_cnt2);
+  (void)hipFree(p->d_wave_base2);
   for (auto& sg : p->staging) {
     if (sg.pending) (void)hipEventSynchronize(sg.done);
     if (sg.h_tab) (void)hipHostFree(sg.h_tab);

@@ -725,7 +725,9 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_kernel(PairArgs) {
     edge_valid = e < B;
   }
   const bool writer = edge_valid && h == 0;  // the lane that exports the edge's results
-  const uint32_t ec = edge_valid ? e : e0;    // idle slots shadow the wave's first edge, results discarded
+  const uint32_t slot_c = edge_valid ? e : e0;  // idle slots shadow the wave's first edge, results discarded
+  // the edge this slot stands for: itself, or (later phases of a split launch) an entry of the survivors' list
+  const uint32_t ec = edge_io()->edge_ids ? edge_io()->edge_ids[slot_c] : slot_c;
   PairWsRef ws;
   ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(
       pair_args()->ws_all + (uint64_t(blockIdx.y) * gridDim.x + blockIdx.x) * uint64_t(W_::SLOTS * 64), 0,
@@ -738,25 +740,28 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_kernel(PairArgs) {
     const EdgeIO* io = edge_io();
     const uint32_t si = source_row(io);
     const uint64_t trow = (io->d_tgt_off ? uint64_t(*io->d_tgt_off) : 0ull) + ec;
-    const double* __restrict__ a_row = io->src + uint64_t(si) * io->src_stride;
+    // a later phase of a split launch starts from the state the phase before left in its x_out
+    const double* __restrict__ a_row = io->resume ? io->resume + uint64_t(ec) * D : io->src + uint64_t(si) * io->src_stride;
     const double* __restrict__ b_row = io->tgt + trow * io->tgt_stride;
-    double* __restrict__ record = writer ? io->record : nullptr;
+    double* __restrict__ record = (writer && !io->resume) ? io->record : nullptr;
     const int record_stride = io->record_stride;
 #pragma unroll 1
     for (int d = 0; d < D; ++d) {
       const double av = a_row[d];
       ws_st(ws, W_::X + d, av);
       ws_st(ws, W_::B + d, b_row[d]);
-      if (record) record[(uint64_t(e) * record_stride + 0) * D + d] = av;
+      if (record) record[(uint64_t(ec) * record_stride + 0) * D + d] = av;
     }
   }
 
-  uint32_t n_free = 0;
+  const int k_first = int(pair_args()->gate.step0);
+  uint32_t n_free = edge_io()->resume ? uint32_t(k_first) : 0u;  // survivors of the phase before: all its steps were free
   bool singular = false;
   bool alive = edge_valid;
-  const int n_steps = pair_args()->dyn.n_steps;
+  const int n_steps = (pair_args()->gate.step1 < uint32_t(pair_args()->dyn.n_steps)) ? int(pair_args()->gate.step1)
+                                                                                   : pair_args()->dyn.n_steps;
 #pragma unroll 1
-  for (int k = 0; k < n_steps; ++k) {
+  for (int k = k_first; k < n_steps; ++k) {
     // distance(x_current, x_goal) > goal_proximity_threshold (exact left-to-right sum, vect_distance_metrics.hpp:126-137)
     {
       double s = 0.0;
@@ -860,7 +865,7 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_kernel(PairArgs) {
       for (int d = 0; d < D; ++d) {
         const double xv = RKH_LD(L_::XE + d);
         ws_st(ws, W_::X + d, xv);
-        if (record) record[(uint64_t(e) * record_stride + n_free) * D + d] = xv;
+        if (record) record[(uint64_t(ec) * record_stride + n_free) * D + d] = xv;
       }
     }
   }
@@ -872,20 +877,20 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_kernel(PairArgs) {
 #pragma unroll 1
   for (int d = 0; d < D; ++d) {
     const double xv = ws_ld(ws, W_::X + d), av = a_row[d], bv = ws_ld(ws, W_::B + d);
-    if (writer) io->x_out[uint64_t(e) * D + d] = xv;
+    if (writer) io->x_out[uint64_t(ec) * D + d] = xv;
     const double d_ar = av - xv, d_ab = av - bv, d_rb = xv - bv;
     s_ar = s_ar + d_ar * d_ar;
     s_ab = s_ab + d_ab * d_ab;
     s_rb = s_rb + d_rb * d_rb;
   }
-  if (writer) io->steps_free[e] = n_free;
+  if (writer) io->steps_free[ec] = n_free;
   if (io->mode != EDGE_PLAIN && writer) {
     const double n_ar = sqrt(s_ar), n_ab = sqrt(s_ab), n_rb = sqrt(s_rb);
     if (io->mode == EDGE_STEER_ACCEPT) {
       // planning_visitor_base::steer_towards_position (planning_visitors.hpp:349-360)
       const double best_case = io->best_case ? io->best_case[ec] : n_ab;
       const bool ok = (!isinf(n_ar)) && (n_ar < 2.0 * best_case) && (n_ar > io->steer_tol * best_case);
-      io->accept[e] = ok ? 1 : 0;
+      io->accept[ec] = ok ? 1 : 0;
     } else {
       // C_free distance used by the goal probe (MEAQR_topology.hpp:995-1003)
       io->goal_dist[si - 1] = (n_ab * 0.05 > n_rb) ? n_ab : INFINITY;

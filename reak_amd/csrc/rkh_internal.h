@@ -260,6 +260,10 @@ struct EdgeIO {  // inputs / outputs of one propagate launch (all device pointer
   uint8_t* accept = nullptr;
   double* goal_dist = nullptr;         // indexed by source row - 1
   int* err_flag = nullptr;
+  // second and later phases of a split launch (two-lanes kernel): slot s of the launch is edge edge_ids[s], which
+  // resumes from row edge_ids[s] of `resume` (the x_out of the phase before) with KernelGate::step0 steps behind it
+  const uint32_t* edge_ids = nullptr;
+  const double* resume = nullptr;
 };
 
 // A steer kernel with a gate runs only if lo <= *count < hi (read on the device); count == nullptr: always.
@@ -272,6 +276,8 @@ struct KernelGate {
   // whatever the per-problem counts are (a (wave, problem) grid leaves holes that land unevenly on the XCDs).
   const uint32_t* wave_base = nullptr;
   uint32_t n_segments = 0;
+  // the steps [step0, min(step1, n_steps)) of every edge (two-lanes kernel; the whole edge by default)
+  uint32_t step0 = 0, step1 = 0xFFFFFFFFu;
 };
 rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                             int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges,
