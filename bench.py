@@ -301,6 +301,29 @@ def feval_ops(scn, samples=32):
     return {k: v / samples for k, v in acc.items()}
 
 
+def steer_occupancy():
+    """Resource usage of the steer kernels as the built code objects state it (tools/kernel_resources.py reads the
+    AMDGPU metadata of reak_amd/librkh.so; tests/test_kernel_resources.py pins the same figures)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_resources as kr
+
+        res = kr.kernel_resources()
+        out = {}
+        for k in ("rkh::propagate_pair_step_kernel<6>", "rkh::propagate_pair_kernel<6>", "rkh::propagate_kernel<6, 64>"):
+            d = res[k]
+            lds_waves = (160 * 1024 // d["group_segment_fixed_size"]) if d["group_segment_fixed_size"] else 32
+            out[k.replace("rkh::", "")] = {"vgpr": d["vgpr_count"], "vgpr_spills": d["vgpr_spill_count"],
+                                           "scratch_bytes": d["private_segment_fixed_size"],
+                                           "lds_bytes": d["group_segment_fixed_size"],
+                                           "waves_per_simd": min(kr.waves_per_simd(d), max(1, lds_waves // 4))}
+        out["mapping"] = ("32 edges per wave (two adjacent lanes per edge); every launch of the step-wise form packs the "
+                          "live edges of all problems into full waves")
+        return out
+    except Exception as e:  # the llvm tools are part of the ROCm image; without them the figures are simply not quoted
+        return {"unavailable": repr(e)}
+
+
 def nn_planner_traffic(problems, max_vertices):
     """HBM bytes per launch of the planner-regime NN sweep from the committed PMC passes, if they match this run."""
     path = os.path.join(ROOT, "profiles", "r02_nn_planner_pmc.json")
@@ -473,7 +496,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--problems", type=int, default=int(os.environ.get("RKH_BENCH_PROBLEMS", "256")))
+    ap.add_argument("--problems", type=int, default=int(os.environ.get("RKH_BENCH_PROBLEMS", "512")))
     ap.add_argument("--max-vertices", type=int, default=100000)
     ap.add_argument("--groups", type=int, default=int(os.environ.get("RKH_BENCH_GROUPS", "1")),
                     help="planner handles (HIP streams) the problems of a GPU are split over; 2 overlaps one group's "
@@ -563,16 +586,17 @@ def main():
         prof = [pl.nn_profile()]
         nn_pairs = pl.nn_pairs()
         steer_ms, steer_launches = pl.steer_profile()
+        steer_steps = pl.steer_steps()
         nn_kernel[0] = lib.load().rkh_nn_kernel_name().decode()
         pl.close()
         return {"seconds": t1 - t0, "nodes": nodes, "edges": edges, "spec": spec, "rounds": rounds, "best": best,
                 "nn_ms": sum(p[0] for p in prof), "nn_bytes": sum(p[1] for p in prof), "nn_launches": sum(p[2] for p in prof),
-                "nn_pairs": nn_pairs, "steer_ms": steer_ms, "steer_launches": steer_launches}
+                "nn_pairs": nn_pairs, "steer_ms": steer_ms, "steer_launches": steer_launches, "steer_steps": steer_steps}
 
     for w in range(args.warmup):
         run_step(1000 + w, False)
     tot = {"seconds": 0.0, "nodes": 0, "edges": 0, "spec": 0, "rounds": 0, "nn_ms": 0.0, "nn_bytes": 0, "nn_launches": 0,
-           "nn_pairs": 0, "steer_ms": 0.0, "steer_launches": 0}
+           "nn_pairs": 0, "steer_ms": 0.0, "steer_launches": 0, "steer_steps": 0}
     best = float("inf")
     if dist is not None:
         dist.barrier()
@@ -649,22 +673,30 @@ def main():
                 out[k]["note"] = "INCOMPLETE: only the first profiled_rounds rounds were timed (profile_coverage); " + out[k]["note"]
         if tot["steer_ms"] > 0 and profiled_all:
             fe = feval_ops(scn)
-            ops_per_edge = 20 * 4 * fe["useful"]
-            rate = tot["spec"] * ops_per_edge / (tot["steer_ms"] * 1e-3) / 1e12
-            out["steer_kernels"] = {"kernels": "propagate_pair_kernel (large rounds) + propagate_kernel (small rounds)",
+            n_steps = 20
+            # EXECUTED work: the kernels count the RK4 steps they integrate (an edge stops at its first state that is not
+            # free, MEAQR_topology.hpp:550-559: 11-12 of its 20 steps on average), 4 f-evals each.  `launched` prices every
+            # propagated edge at its full 20 steps -- what rounds 1-2 reported as `achieved`.
+            rate = tot["steer_steps"] * 4 * fe["useful"] / (tot["steer_ms"] * 1e-3) / 1e12
+            rate_launched = (tot["spec"] + tot["nodes"]) * n_steps * 4 * fe["useful"] / (tot["steer_ms"] * 1e-3) / 1e12
+            out["steer_kernels"] = {"kernels": "propagate_pair_step_kernel (one launch per RK4 step over the live edges of "
+                                               "all problems; large rounds) + propagate_pair_kernel / propagate_kernel "
+                                               "(whole-edge launches; small rounds)",
                                     "bound": "fp64_valu", "share_of_step_time": tot["steer_ms"] * 1e-3 / tot["seconds"],
                                     "avg_round_ms": tot["steer_ms"] / max(1, tot["steer_launches"]),
                                     "edges_per_s_in_kernel": tot["spec"] / (tot["steer_ms"] * 1e-3),
+                                    "executed_steps": tot["steer_steps"],
+                                    "executed_steps_per_edge": tot["steer_steps"] / max(1, tot["spec"] + tot["nodes"]),
                                     "f_eval_ops": fe,
                                     "achieved": rate, "peak": 39.3, "unit": "Tops/s (fp64, no FMA)", "frac": rate / 39.3,
+                                    "launched": {"achieved": rate_launched, "frac": rate_launched / 39.3,
+                                                 "note": "every propagated edge (candidates + goal probes) priced at 20 steps: "
+                                                         "not executed work; rounds 1-2 quoted this for the candidates"},
                                     "frac_counting_the_reference_dense_products": rate / 39.3 * fe["all"] / fe["useful"],
-                                    "occupancy": "propagate_pair_kernel: 32 edges per wave (two adjacent lanes per edge), 220 "
-                                                 "VGPRs, 0 scratch, 20.3 KB LDS per wave = 8 waves per CU = two per SIMD "
-                                                 "(2048 per GPU); waves packed in dispatch order over the 8 XCDs, batch "
-                                                 "sizes fitted to whole passes of the machine",
-                                    "note": "f-eval operations only (proximity tests excluded); rank-0 launches of the "
-                                            "timed region; `useful` operations of the reference's f-eval, i.e. without its "
-                                            "dense products over structural zeros"}
+                                    "occupancy": steer_occupancy(),
+                                    "note": "executed f-eval operations only (proximity tests excluded; edges = candidates + "
+                                            "goal probes); rank-0 launches of the timed region; `useful` operations of the "
+                                            "reference's f-eval, i.e. without its dense products over structural zeros"}
         # the microbenchmarks and the CPU baselines are single-GPU extras: rank 0 at N = 1 only
         if not args.no_microbench and world == 1:
             # the cloud's hyperbox (the unit cube) is declared, as a planner's topology does: from 5 queries per sweep on

@@ -38,6 +38,11 @@ rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* to
 rkh_status rkh_planner_nn_pairs(rkh_planner* p, uint64_t* pairs);
 /* Same switch: HIP events around the steer launches (both kernel mappings) of every round: total time, rounds. */
 rkh_status rkh_planner_steer_profile(rkh_planner* p, double* total_ms, uint64_t* launches);
+/* Always on: RK4 steps the steer kernels of this planner integrated so far, over all edges (a step counts when it
+ * starts from a live edge, the step that ends the edge included; steps skipped because the edge had ended do not).
+ * The executed work of the steer launches -- an edge is launched for n_steps but stops at its first state that is not
+ * free (MEAQR_topology.hpp:550-559).  (The first-generation lane kernel, RKH_LANE_VARIANT=1, does not count.) */
+rkh_status rkh_planner_steer_steps(rkh_planner* p, uint64_t* executed_steps);
 
 #ifdef __cplusplus
 }

@@ -82,8 +82,11 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
                                                            uint32_t round_slot, uint32_t* __restrict__ sel, uint32_t parity,
                                                            float fit_fill, uint32_t slots, uint32_t* __restrict__ wave_base,
                                                            uint32_t* __restrict__ nn_base, uint32_t nn_queries,
-                                                           uint32_t* __restrict__ edge_base, uint32_t epw) {
+                                                           uint32_t* __restrict__ edge_base, uint32_t epw,
+                                                           uint32_t* __restrict__ step_cnt) {
   __shared__ unsigned int s_waves;
+  // live-edge counters of the step-wise steer launches of this round (launch_propagate_pair_steps)
+  if (step_cnt && threadIdx.x <= uint32_t(kMaxSteps)) step_cnt[threadIdx.x] = 0u;
   // per-problem inputs of the batch formula, cached once (the bisection below evaluates it ten times per problem) and the
   // three count arrays, scanned in LDS; problems beyond the cache capacity fall back to global memory
   constexpr uint32_t kCache = 1024;
@@ -553,6 +556,17 @@ struct rkh_planner {
   uint32_t* d_cnt2 = nullptr;        // [2 P] survivors per (problem, candidates | probes) segment
   uint32_t* d_wave_base2 = nullptr;  // [2 P + 1] prefix of their waves
   uint32_t steer_split = 5;          // steps of the first phase (RKH_STEER_SPLIT; 0 = one launch for the whole edge)
+  // Step-wise steer launches (propagate_pair_step_kernel, the default; RKH_STEER_STEPWISE=0: the two-phase launch above):
+  // one launch per RK4 step over the live edges of all problems, survivors handed on through two ping-pong lists.
+  int steer_stepwise = 1;
+  uint2* d_step_list[2] = {nullptr, nullptr};  // (segment, edge) of the edges alive after step k (k odd / even)
+  uint32_t* d_step_cnt = nullptr;              // [kMaxSteps + 1] live edges entering step k (cleared by round_begin_kernel)
+  unsigned long long* d_steps_exec = nullptr;  // edge-steps integrated by the steer kernels (diagnostics: rkh_planner_steer_steps)
+  uint32_t step_blocks_cap = 0;                // grid bound of a step launch (its blocks stride over the chunks beyond it)
+  // rounds below this many edges keep the single whole-edge launch of the two-lanes mapping (RKH_STEER_SPLIT_MIN_EDGES;
+  // default: what leaves every SIMD at most one 32-edge wave -- such a round gains nothing from shedding waves)
+  uint32_t split_min_edges = 0;
+  uint64_t sum_batch_ub = 0, prev_sum_batch_ub = 0;  // host-side bounds on the candidates of this / the previous round, all problems
   // segment tables of the sample generator: [0] what the enqueued rounds need, [1] the next call's share, generated
   // while the GPU works on the rounds just enqueued
   double* d_bounds = nullptr;  // lower[D], upper[D] of the sampled hyperbox
@@ -657,6 +671,7 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
   // the one that is not chosen exits at once.  Small rounds -> one wave per edge (latency), large -> 32 edges per wave.
   KernelGate gate_wave{p->d_sel + p->round_parity, 0u, p->lane_threshold};
   KernelGate gate_lane{p->d_sel + p->round_parity, p->lane_threshold, 0xFFFFFFFFu};
+  gate_wave.steps_exec = gate_lane.steps_exec = p->d_steps_exec;
   if (compact && p->d_wave_base) {  // a regular round: (candidates, probes) segments as round_begin_kernel counted them
     gate_lane.wave_base = p->d_wave_base;
     gate_lane.n_segments = 2 * p->P;
@@ -671,23 +686,39 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
   // steps (tests/diag_edge_lifetimes.py) and leave their lanes idle for the rest of their wave, so the first
   // steer_split steps run for every edge, the survivors are compacted per segment and only they run the remaining
   // steps -- in fewer waves.  Same arithmetic per edge, same results.
-  const bool split = compact && p->d_wave_base && p->d_io_steer2 && p->lane_variant == 2 && p->steer_split > 0 &&
-                     int(p->steer_split) < p->dyn.n_steps && tab_a == p->d_io_steer && tab_b == p->d_io_probe;
+  const bool stepwise = p->steer_stepwise && p->d_step_cnt;
+  const bool split = compact && p->d_wave_base && p->d_io_steer2 && p->lane_variant == 2 && p->dyn.n_steps > 1 &&
+                     (stepwise || (p->steer_split > 0 && int(p->steer_split) < p->dyn.n_steps)) &&
+                     tab_a == p->d_io_steer && tab_b == p->d_io_probe;
   if (!split)
     return launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
                             p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b,
                             p->P, p->d_lane_ws, gate_lane);
-  // ... when the round holds at least one pass of steer waves; below that the two extra launches and the second tail
-  // cost more than the idle lanes (64 problems x 100 000: 2.94 against 3.04 M expansions/s): such rounds take one launch
-  const uint32_t split_edges = p->wave_slots * lane_kernel_edges_per_wave();
+  // ... when the round is large enough; below that the extra launches and tails cost more than the idle lanes (64
+  // problems x 100 000 with the two-phase launch: 2.94 against 3.04 M expansions/s): such rounds take one launch
+  const uint32_t split_edges = p->split_min_edges;
+  // host-side bound on the edges of this round (candidates + pending probes of all problems)
+  const uint64_t edges_ub = std::min<uint64_t>(p->sum_batch_ub + p->prev_sum_batch_ub + uint64_t(p->P) * kProbeGranule,
+                                               uint64_t(grid_a + grid_b) * p->P);
   if (split_edges > gate_lane.lo) {
     KernelGate whole = gate_lane;
     whole.hi = split_edges;
-    st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                          p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b,
-                          p->P, p->d_lane_ws, whole);
-    if (st != RKH_OK) return st;
+    whole.steps_exec = p->d_steps_exec;
+    if (edges_ub >= whole.lo) {  // (a round that cannot reach the gate needs no launch at all)
+      st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
+                            p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b,
+                            p->P, p->d_lane_ws, whole);
+      if (st != RKH_OK) return st;
+    }
     gate_lane.lo = split_edges;
+  }
+  if (edges_ub < gate_lane.lo) return RKH_OK;
+  if (stepwise) {
+    const uint32_t epw = pair_kernel_edges_per_wave();
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((edges_ub + epw - 1) / epw, p->step_blocks_cap));
+    return launch_propagate_pair_steps(p->stream, p->n_dof, p->scene->d_scene, p->dyn, tab_a, tab_b, p->P,
+                                       p->d_wave_base + (2 * p->P + 1), p->d_step_list[0], p->d_step_list[1],
+                                       p->d_step_cnt, p->d_lane_ws, blocks, gate_lane, p->d_steps_exec);
   }
   KernelGate g1 = gate_lane;
   g1.step1 = p->steer_split;
@@ -698,7 +729,8 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
   hipLaunchKernelGGL(phase_compact_kernel, dim3(p->P, 2), dim3(256), 0, p->stream, p->d_io_steer, p->d_io_probe,
                      p->d_io_steer2, p->d_io_probe2, p->steer_split, p->d_cnt2, gate_lane);
   hipLaunchKernelGGL(phase_scan_kernel, dim3(1), dim3(64), 0, p->stream, p->d_cnt2, 2 * p->P,
-                     lane_kernel_edges_per_wave(), p->d_wave_base2);
+                     pair_kernel_edges_per_wave(), p->d_wave_base2);
+  RKH_HIP(hipGetLastError());
   KernelGate g2 = gate_lane;
   g2.wave_base = p->d_wave_base2;
   g2.n_segments = 2 * p->P;
@@ -746,10 +778,13 @@ rkh_status enqueue_round(rkh_planner* p) {
   const float scale = fit ? 1.4f : 1.0f;
   // launch sizes of this round from the host-side bounds
   uint32_t batch_ub = 1;
+  p->prev_sum_batch_ub = p->sum_batch_ub ? p->sum_batch_ub : uint64_t(p->b_max) * p->P;
+  p->sum_batch_ub = 0;
   for (uint32_t i = 0; i < p->P; ++i) {
     const PlannerState& hs = p->prob[i].h_state;
     const uint32_t b = batch_upper_bound(hs, p->n_ub[i], scale);
     batch_ub = std::max(batch_ub, b);
+    p->sum_batch_ub += b;
     p->n_ub[i] = std::min<uint64_t>(p->n_ub[i] + b, uint64_t(hs.max_total));
   }
   const uint32_t probe_ub = p->prev_batch_ub ? p->prev_batch_ub : p->b_max;
@@ -757,7 +792,8 @@ rkh_status enqueue_round(rkh_planner* p) {
   p->round_parity ^= 1u;
   hipLaunchKernelGGL(round_begin_kernel, dim3(1), dim3(256), 0, s, p->d_probs, p->P, slot, p->d_sel, p->round_parity,
                      fit ? float(p->wave_fill) : 0.0f, p->wave_slots, p->d_wave_base, p->d_nn_base, nn1_mfma_queries(),
-                     p->d_wave_base ? p->d_wave_base + (2 * p->P + 1) : nullptr, lane_kernel_edges_per_wave());
+                     p->d_wave_base ? p->d_wave_base + (2 * p->P + 1) : nullptr, lane_kernel_edges_per_wave(),
+                     p->d_step_cnt);
   // 1. NN sweep of every problem's samples over its snapshot
   rkh_status st = launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, batch_ub, p->part_blocks, ev0, ev1,
                              p->coord_bound, p->d_nn_base, true);
@@ -910,6 +946,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   if (const char* e = getenv("RKH_WAVE_FIT")) p->wave_fit = atoi(e);
   if (const char* e = getenv("RKH_STEER_SPLIT")) p->steer_split = uint32_t(std::max(0, atoi(e)));
   if (const char* e = getenv("RKH_WAVE_FILL")) p->wave_fill = atof(e);
+  if (const char* e = getenv("RKH_STEER_STEPWISE")) p->steer_stepwise = atoi(e);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, scene->ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -917,6 +954,10 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
                                                                                  : lane_kernel_waves_per_cu(scene->host.n_dof));
     if (getenv("RKH_VERBOSE")) fprintf(stderr, "rkh planner: %d CUs, %u resident steer waves\n", prop.multiProcessorCount, p->wave_slots);
   }
+  // whole-edge launches below: step-wise, one 32-edge wave per SIMD; two-phase, one pass of steer waves (its optimum)
+  p->split_min_edges = (p->steer_stepwise ? p->wave_slots / 2 : p->wave_slots) * pair_kernel_edges_per_wave();
+  if (const char* e = getenv("RKH_STEER_SPLIT_MIN_EDGES")) p->split_min_edges = uint32_t(std::max(0, atoi(e)));
+  p->step_blocks_cap = 2 * p->wave_slots;
   if (const char* e = getenv("RKH_BATCH_MAX")) p->b_max = std::max(8, atoi(e));
   p->b_max = std::min<uint32_t>(p->b_max, 4096);
   if (const char* e = getenv("RKH_LANE_THRESHOLD")) p->lane_threshold = uint32_t(std::max(0, atoi(e)));
@@ -969,6 +1010,8 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   RKH_HIP(hipMemset(p->d_nn_base, 0, (size_t(P) + 1) * sizeof(uint32_t)));
   RKH_HIP(hipMalloc(&p->d_sel, 2 * sizeof(uint32_t)));
   RKH_HIP(hipMemset(p->d_sel, 0, 2 * sizeof(uint32_t)));
+  RKH_HIP(hipMalloc(&p->d_steps_exec, sizeof(unsigned long long)));
+  RKH_HIP(hipMemset(p->d_steps_exec, 0, sizeof(unsigned long long)));
   for (uint32_t i = 0; i < P; ++i) {
     const uint64_t cap = (uint64_t(prms[i].max_vertices) + 1 + 255) / 256 * 256;
     p->max_capacity = std::max(p->max_capacity, cap);
@@ -1101,6 +1144,17 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     RKH_HIP(hipMemset(p->d_cnt2, 0, 2 * size_t(P) * sizeof(uint32_t)));
     RKH_HIP(hipMalloc(&p->d_wave_base2, (2 * size_t(P) + 1) * sizeof(uint32_t)));
     RKH_HIP(hipMemset(p->d_wave_base2, 0, (2 * size_t(P) + 1) * sizeof(uint32_t)));
+    if (p->steer_stepwise && p->lane_variant == 2) {
+      const size_t cap = size_t(P) * (2 * size_t(p->b_max) + kProbeGranule);
+      for (auto& l : p->d_step_list) RKH_HIP(hipMalloc(&l, cap * sizeof(uint2)));
+      RKH_HIP(hipMalloc(&p->d_step_cnt, (kMaxSteps + 1) * sizeof(uint32_t)));
+      RKH_HIP(hipMemset(p->d_step_cnt, 0, (kMaxSteps + 1) * sizeof(uint32_t)));
+      // the step kernel's blocks take their RK4 workspace out of the two-lanes workspace
+      if (propagate_pair_step_workspace_bytes(p->n_dof, p->step_blocks_cap) >
+          propagate_pairs_workspace_bytes(p->n_dof, p->b_max, p->b_max, P))
+        p->step_blocks_cap = uint32_t(propagate_pairs_workspace_bytes(p->n_dof, p->b_max, p->b_max, P) /
+                                      propagate_pair_step_workspace_bytes(p->n_dof, 1));
+    }
     std::vector<EdgeIO> hio2 = hio, hgp2 = hgp;
     for (uint32_t i = 0; i < P; ++i) {
       Problem& q = p->prob[i];
@@ -1156,6 +1210,10 @@ rkh_status rkh_planner_destroy(rkh_planner* p) {
   (void)hipFree(p->d_io_probe2);
   (void)hipFree(p->d_cnt2);
   (void)hipFree(p->d_wave_base2);
+  (void)hipFree(p->d_step_list[0]);
+  (void)hipFree(p->d_step_list[1]);
+  (void)hipFree(p->d_step_cnt);
+  (void)hipFree(p->d_steps_exec);
   for (auto& sg : p->staging) {
     if (sg.pending) (void)hipEventSynchronize(sg.done);
     if (sg.h_tab) (void)hipHostFree(sg.h_tab);
@@ -1232,6 +1290,17 @@ rkh_status rkh_planner_steer_profile(rkh_planner* p, double* total_ms, uint64_t*
     *total_ms += ms;
     *launches += 1;
   }
+  return RKH_OK;
+}
+
+rkh_status rkh_planner_steer_steps(rkh_planner* p, uint64_t* executed_steps) {
+  if (!p || !executed_steps) return RKH_ERR_BAD_ARG;
+  *executed_steps = 0;
+  if (!p->d_steps_exec) return RKH_OK;
+  RKH_HIP(hipStreamSynchronize(p->stream));
+  unsigned long long v = 0;
+  RKH_HIP(hipMemcpy(&v, p->d_steps_exec, sizeof(v), hipMemcpyDeviceToHost));
+  *executed_steps = v;
   return RKH_OK;
 }
 

@@ -707,6 +707,7 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
   uint32_t n_free = 0;
   bool singular = false;   // a live edge met a singular mass matrix
   bool alive = true;       // this edge is still stepping
+  uint32_t n_exec = 0;     // steps integrated for this edge (KernelGate::steps_exec)
   if (record && gl < D) record[(uint64_t(e) * record_stride + 0) * D + gl] = x;
 
   // steps of this edge: the launch's schedule, or (EdgeIO::frac) the edge's own travel fraction cut with the comparison
@@ -744,6 +745,7 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
     const double dist = group_norm<N>(ws, x - b_d, gl);
     if (!(dist > dyn.goal_tol)) alive = false;
     if (!__any(alive)) break;
+    if (alive) ++n_exec;
     // PD law, zero-order hold over the step
     if (gl < D) ws.x[gl] = x;
     __syncthreads();
@@ -814,6 +816,7 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
   if (singular && gl == 0 && edge_valid) atomicExch(io.err_flag, int(RKH_ERR_SINGULAR));
   if (edge_valid && gl < D) io.x_out[uint64_t(e) * D + gl] = x;
   if (edge_valid && gl == 0) io.steps_free[e] = n_free;
+  if (gate.steps_exec && edge_valid && gl == 0 && n_exec) atomicAdd(gate.steps_exec, (unsigned long long)n_exec);
   if (io.mode != EDGE_PLAIN) {
     const double n_ar = group_norm<N>(ws, a_d - x, gl);
     const double n_ab = group_norm<N>(ws, a_d - b_d, gl);

@@ -473,7 +473,7 @@ RKH_DI void pair_drain_q1(ScenePtr sc, PairLds<N>& lds) {
           const double gz = fabs(crel.z) - fabs(trel.z) * hl - 0.5 * bx.d2;
           golden = !(fmax(gx, fmax(gy, gz)) > cc.d1 + 1e-9);
         } else if (rt != PR_NONE) {
-          const double d = a_first ? pair_distance(rt, A, Bv) : pair_distance(rt, Bv, A);
+          const double d = a_first ? pair_distance<false>(rt, A, Bv) : pair_distance<false>(rt, Bv, A);
           if (d < 0.0) lds.hit[e] = 1u;
         }
       }
@@ -758,6 +758,7 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_kernel(PairArgs) {
   uint32_t n_free = edge_io()->resume ? uint32_t(k_first) : 0u;  // survivors of the phase before: all its steps were free
   bool singular = false;
   bool alive = edge_valid;
+  uint32_t n_exec = 0;  // steps integrated for this edge (KernelGate::steps_exec)
   const int n_steps = (pair_args()->gate.step1 < uint32_t(pair_args()->dyn.n_steps)) ? int(pair_args()->gate.step1)
                                                                                    : pair_args()->dyn.n_steps;
 #pragma unroll 1
@@ -775,6 +776,7 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_kernel(PairArgs) {
       if (!(sqrt(s) > pair_args()->dyn.goal_tol)) alive = false;
     }
     if (!__any(alive)) break;
+    if (alive) ++n_exec;
     // PD law, zero-order hold over the step
     {
       PairArgP A = pair_args();
@@ -884,6 +886,12 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_kernel(PairArgs) {
     s_rb = s_rb + d_rb * d_rb;
   }
   if (writer) io->steps_free[ec] = n_free;
+  if (pair_args()->gate.steps_exec) {
+    uint32_t tot = writer ? n_exec : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    if (lane == 0 && tot) atomicAdd(pair_args()->gate.steps_exec, (unsigned long long)tot);
+  }
   if (io->mode != EDGE_PLAIN && writer) {
     const double n_ar = sqrt(s_ar), n_ab = sqrt(s_ab), n_rb = sqrt(s_rb);
     if (io->mode == EDGE_STEER_ACCEPT) {
@@ -896,6 +904,328 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_kernel(PairArgs) {
       io->goal_dist[si - 1] = (n_ab * 0.05 > n_rb) ? n_ab : INFINITY;
     }
   }
+}
+
+// ---- one RK4 step per launch --------------------------------------------------------------------------------------
+// The same edge arithmetic as propagate_pair_kernel, cut at every step of the steer loop (MEAQR_topology.hpp:503-565:
+// integrate one step, test is_free, stop at the first state that is not free).  The edges of a planner round are
+// short-lived (tests/diag_edge_lifetimes.py: a candidate survives 9.7 of its 20 steps on average, 21 % end in the
+// first), and a wave that carries an edge through all of its steps keeps the lanes of the edges that ended idle: about
+// half of the lane-steps of propagate_pair_kernel do nothing.  Here a launch advances every LIVE edge of the round by
+// one step, 32 per wave whatever (problem, candidates | probes) segment they belong to, and appends the survivors to
+// the list the next launch reads (one atomic per wave; the order of a list is irrelevant -- edges are independent and
+// their results are indexed by the edge): every wave of every launch is full except the last one.  Between two steps
+// an edge lives in its x_out row (the state after its last free step), so the launch of step k reads 2 D doubles per
+// edge and writes D.  Step 0 has no list: entry i of the round is found by bisection in the exclusive prefix of the
+// segments' edge counts (round_begin_kernel's edge_base).
+struct PairStepArgs {
+  const SceneDev* sc;
+  DynDev dyn;
+  const EdgeIO* tab_a;        // candidates of problem p
+  const EdgeIO* tab_b;        // goal probes of problem p
+  double* ws_all;             // RK4 stage vectors, PairStepWs slots x 64 lanes per block of the grid
+  KernelGate gate;            // count / lo / hi: the planner's per-round choice between the mappings
+  const uint32_t* edge_base;  // [n_segments + 1] exclusive prefix of the edges per segment (segment 2p + g)
+  uint32_t n_segments;
+  uint32_t step;              // k: this launch integrates step k of every live edge
+  const uint2* list_in;       // k > 0: (segment, edge) of the edges that are still alive
+  const uint32_t* cnt_in;     //        their number
+  uint2* list_out;            // survivors of this step
+  uint32_t* cnt_out;
+  unsigned long long* steps_exec;  // optional: + the number of edge-steps this launch integrated
+};
+typedef const __attribute__((address_space(4))) PairStepArgs* PairStepArgP;
+RKH_DI PairStepArgP pair_step_args() {
+  PairStepArgP a = (PairStepArgP)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(a));
+  return a;
+}
+template <int N>
+struct PairStepWs {  // per-lane private RK4 values (this lane's joints: 2 components each)
+  enum : int { R = (N + 1) / 2, W = 0, KA = 2 * R, K3 = 4 * R, SLOTS = 6 * R };
+};
+
+template <int N>
+__global__ __launch_bounds__(64, 2) void propagate_pair_step_kernel(PairStepArgs) {
+  __shared__ PairLds<N> lds;
+  typedef PairLayout<N> L_;
+  typedef PairStepWs<N> W_;
+  constexpr int R = L_::R;
+  constexpr int D = 2 * N;
+  const int lane = threadIdx.x;
+  const int h = lane & 1;
+  const int el = lane >> 1;
+  uint32_t n_total;
+  {
+    PairStepArgP A = pair_step_args();
+    if (A->gate.count) {
+      const uint32_t c = *A->gate.count;
+      if (c < A->gate.lo || c >= A->gate.hi) return;
+    }
+    n_total = A->step == 0u ? A->edge_base[A->n_segments] : *A->cnt_in;
+  }
+  if (blockIdx.x * uint32_t(kPairEdges) >= n_total) return;
+  const ScenePtr sc = (ScenePtr)pair_step_args()->sc;
+  if (threadIdx.x < 3 * (N + 1)) {
+    const int jj = threadIdx.x / 3;
+    lds.axis[jj][threadIdx.x % 3] = sc->joints[jj < N ? jj : N - 1].axis[threadIdx.x % 3];
+  }
+  __syncthreads();
+  PairWsRef ws;
+  ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(pair_step_args()->ws_all + uint64_t(blockIdx.x) * uint64_t(W_::SLOTS * 64), 0,
+                                              W_::SLOTS * 512, 0x00020000);
+  ws.voff = lane * 8;
+  const int k = int(pair_step_args()->step);
+#pragma unroll 1
+  for (uint32_t chunk = blockIdx.x; chunk * uint32_t(kPairEdges) < n_total; chunk += gridDim.x) {
+    const uint32_t i0 = chunk * uint32_t(kPairEdges);
+    const bool edge_valid = i0 + uint32_t(el) < n_total;
+    const uint32_t ic = edge_valid ? i0 + uint32_t(el) : i0;  // idle slots shadow the chunk's first edge, results discarded
+    uint32_t seg, ec;
+    if (k == 0) {
+      const uint32_t* eb = pair_step_args()->edge_base;
+      uint32_t lo = 0, hi = pair_step_args()->n_segments;  // eb[lo] <= ic < eb[hi]
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (eb[mid] <= ic) lo = mid;
+        else hi = mid;
+      }
+      seg = lo;
+      ec = ic - eb[lo];
+    } else {
+      const uint2 ent = pair_step_args()->list_in[ic];
+      seg = ent.x;
+      ec = ent.y;
+    }
+    const bool writer = edge_valid && h == 0;  // the lane that exports the edge's results
+    auto edge_io = [&]() -> const EdgeIO* {
+      PairStepArgP A = pair_step_args();
+      return ((seg & 1u) ? A->tab_b : A->tab_a) + (seg >> 1);
+    };
+    auto source_row = [&](const EdgeIO* io) -> uint32_t {
+      return io->src_idx ? io->src_idx[ec] : ((io->d_src_first ? *io->d_src_first : 0u) + ec);
+    };
+    auto target_row = [&](const EdgeIO* io) -> const double* {
+      return io->tgt + ((io->d_tgt_off ? uint64_t(*io->d_tgt_off) : 0ull) + ec) * io->tgt_stride;
+    };
+    // the state the edge has reached (its source row, or what the step before left in x_out), the steer target, and
+    // distance(x_current, x_goal) > goal_proximity_threshold (exact left-to-right sum, vect_distance_metrics.hpp:126-137)
+    bool alive = edge_valid;
+    {
+      const EdgeIO* io = edge_io();
+      const double* __restrict__ a_row = k ? io->x_out + uint64_t(ec) * D : io->src + uint64_t(source_row(io)) * io->src_stride;
+      const double* __restrict__ b_row = target_row(io);
+      double* __restrict__ first = (k == 0 && writer) ? io->x_out + uint64_t(ec) * D : nullptr;
+      double* __restrict__ record = (k == 0 && writer) ? io->record : nullptr;
+      const int record_stride = io->record_stride;
+      double s = 0.0;
+#pragma unroll 1
+      for (int d = 0; d < D; ++d) {
+        const double xv = a_row[d];
+        RKH_LD(L_::XE + d) = xv;  // both lanes of the edge write the same value
+        if (first) first[d] = xv;  // an edge that ends in its first step stays at its source
+        if (record) record[(uint64_t(ec) * record_stride + 0) * D + d] = xv;
+        const double df = xv - b_row[d];
+        s = s + df * df;
+      }
+      if (!(sqrt(s) > pair_step_args()->dyn.goal_tol)) alive = false;
+    }
+    bool singular = false;
+    if (__any(alive)) {
+      if (pair_step_args()->steps_exec) {
+        const unsigned long long m = __ballot(alive && h == 0);
+        if (lane == 0) atomicAdd(pair_step_args()->steps_exec, (unsigned long long)__popcll(m));
+      }
+      // PD law, zero-order hold over the step
+      {
+        PairStepArgP A = pair_step_args();
+        const double kp = A->dyn.kp, kd = A->dyn.kd, u_max = A->dyn.u_max;
+        const double* __restrict__ b_row = target_row(edge_io());
+#pragma unroll 1
+        for (int j = 0; j < N; ++j) {
+          double v = kp * (b_row[2 * j] - RKH_LD(L_::XE + 2 * j)) + kd * (b_row[2 * j + 1] - RKH_LD(L_::XE + 2 * j + 1));
+          if (v > u_max) v = u_max;
+          else if (v < -u_max) v = -u_max;
+          RKH_LD(L_::U + j) = v;
+        }
+      }
+      // runge_kutta4_integrate_impl (runge_kutta4_integrator_sys.hpp:53-97), see propagate_pair_kernel
+      bool sing_now = false;
+      const int n_evals = 4 * int(pair_step_args()->dyn.inner[k]);
+#pragma unroll 1
+      for (int ev = 0; ev < n_evals; ++ev) {
+        double qdd[N];
+        pair_state_derivative<N>(sc, lds, el, h, qdd, sing_now);
+        const int stage = ev & 3;
+        const double h_dt = pair_step_args()->dyn.dt;
+#pragma unroll
+        for (int jr = 0; jr < R; ++jr) {
+          const int j = 2 * jr + h;
+          const bool jv = j < N;
+          const int jc = jv ? j : 2 * jr;
+          double qdd_odd = qdd[2 * jr + 1 < N ? 2 * jr + 1 : 2 * jr];
+          asm volatile("" : "+v"(qdd_odd));
+          const double qdd_j = h ? qdd_odd : qdd[2 * jr];
+          const double xq = RKH_LD(L_::XE + 2 * jc), xqd = RKH_LD(L_::XE + 2 * jc + 1);
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int sl = 2 * jr + half;  // this lane's private slot
+            const double xv = half ? xqd : xq;
+            const double dp = half ? qdd_j : xqd;
+            double xn;
+            if (stage == 0) {
+              const double k1 = h_dt * dp;
+              ws_st(ws, W_::W + sl, xv);
+              ws_st(ws, W_::KA + sl, k1);
+              xn = xv + 0.5 * k1;
+            } else if (stage == 1) {
+              const double k2 = h_dt * dp;
+              const double k1 = ws_ld(ws, W_::KA + sl);
+              ws_st(ws, W_::KA + sl, (1.0 / 6.0) * k1 + (2.0 / 6.0) * k2);
+              xn = ws_ld(ws, W_::W + sl) + 0.5 * k2;
+            } else if (stage == 2) {
+              const double k3v = h_dt * dp;
+              ws_st(ws, W_::K3 + sl, k3v);
+              xn = ws_ld(ws, W_::W + sl) + k3v;
+            } else {
+              xn = xv + ((ws_ld(ws, W_::KA + sl) + (h_dt / 6.0) * dp) - (2.0 / 3.0) * ws_ld(ws, W_::K3 + sl));
+            }
+            if (jv) RKH_LD(L_::XE + 2 * jc + half) = xn;
+          }
+        }
+      }
+      if (sing_now && alive) {
+        singular = true;
+        alive = false;
+      }
+      // is_free(x_next): hyperbox bounds (hyperbox_topology.hpp:178-189), then proximity
+      {
+        PairStepArgP A = pair_step_args();
+        bool oob = false;
+#pragma unroll 1
+        for (int d = 0; d < D; ++d) {
+          const double lo = A->dyn.lower[d], hi = A->dyn.upper[d], xv = RKH_LD(L_::XE + d);
+          if (lo < hi) oob = oob || (xv < lo) || (xv > hi);
+          else oob = oob || (xv > lo) || (xv < hi);
+        }
+        if (oob) alive = false;
+      }
+      if (__any(alive)) {
+        if (!pair_proximity_free<N>(sc, lds, el, h, alive)) alive = false;
+      }
+    }
+    // ---- the step's outcome: alive = step k was free (the edge stands at the new state), else it stays where it was
+    const int n_steps = pair_step_args()->dyn.n_steps;
+    const bool go_on = alive && (k + 1 < n_steps);
+    const bool finished = edge_valid && !go_on;
+    const uint32_t n_free = uint32_t(k) + (alive ? 1u : 0u);
+    if (alive) {
+      const EdgeIO* io = edge_io();
+      double* __restrict__ xo = writer ? io->x_out + uint64_t(ec) * D : nullptr;
+      double* __restrict__ record = writer ? io->record : nullptr;
+      const int record_stride = io->record_stride;
+      if (xo) {
+#pragma unroll 1
+        for (int d = 0; d < D; ++d) {
+          const double xv = RKH_LD(L_::XE + d);
+          xo[d] = xv;
+          if (record) record[(uint64_t(ec) * record_stride + n_free) * D + d] = xv;
+        }
+      }
+    }
+    {  // survivors -> the next launch's list
+      const unsigned long long m = __ballot(go_on && h == 0);
+      if (m) {
+        PairStepArgP A = pair_step_args();
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(A->cnt_out, uint32_t(__popcll(m)));
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+        if (go_on && h == 0) A->list_out[base + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = make_uint2(seg, ec);
+      }
+    }
+    if (__any(finished)) {  // accept test / goal probe of the edges that end here
+      const EdgeIO* io = edge_io();
+      if (singular && writer) atomicExch(io->err_flag, int(RKH_ERR_SINGULAR));
+      const uint32_t si = source_row(io);
+      const double* __restrict__ a_row = io->src + uint64_t(si) * io->src_stride;
+      const double* __restrict__ b_row = target_row(io);
+      const double* __restrict__ x_row = io->x_out + uint64_t(ec) * D;  // written above (alive) or by an earlier step
+      double s_ar = 0.0, s_ab = 0.0, s_rb = 0.0;
+#pragma unroll 1
+      for (int d = 0; d < D; ++d) {
+        const double av = a_row[d], bv = b_row[d];
+        const double xv = alive ? RKH_LD(L_::XE + d) : (k ? x_row[d] : av);
+        const double d_ar = av - xv, d_ab = av - bv, d_rb = xv - bv;
+        s_ar = s_ar + d_ar * d_ar;
+        s_ab = s_ab + d_ab * d_ab;
+        s_rb = s_rb + d_rb * d_rb;
+      }
+      if (finished && writer) {
+        io->steps_free[ec] = n_free;
+        if (io->mode != EDGE_PLAIN) {
+          const double n_ar = sqrt(s_ar), n_ab = sqrt(s_ab), n_rb = sqrt(s_rb);
+          if (io->mode == EDGE_STEER_ACCEPT) {
+            // planning_visitor_base::steer_towards_position (planning_visitors.hpp:349-360)
+            const double best_case = io->best_case ? io->best_case[ec] : n_ab;
+            const bool ok = (!isinf(n_ar)) && (n_ar < 2.0 * best_case) && (n_ar > io->steer_tol * best_case);
+            io->accept[ec] = ok ? 1 : 0;
+          } else {
+            // C_free distance used by the goal probe (MEAQR_topology.hpp:995-1003)
+            io->goal_dist[si - 1] = (n_ab * 0.05 > n_rb) ? n_ab : INFINITY;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int N>
+static void launch_pair_step_t(hipStream_t s, const PairStepArgs& args, uint32_t blocks) {
+  hipLaunchKernelGGL((propagate_pair_step_kernel<N>), dim3(blocks), dim3(64), 0, s, args);
+}
+
+size_t propagate_pair_step_workspace_bytes(int n_dof, uint32_t blocks) {
+  return size_t(blocks) * size_t(6 * ((n_dof + 1) / 2)) * 64 * sizeof(double);
+}
+
+// One launch per step k = 0 .. n_steps-1 over two ping-pong lists; d_cnt[k] = live edges entering step k (d_cnt[1 ..]
+// must be zero when step 0 starts: round_begin_kernel clears them).  `blocks` bounds the grid; a launch with more
+// live chunks than blocks strides over them.
+rkh_status launch_propagate_pair_steps(hipStream_t s, int n_dof, const SceneDev* d_scene, const DynDev& dyn,
+                                       const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems,
+                                       const uint32_t* d_edge_base, uint2* d_list0, uint2* d_list1, uint32_t* d_cnt,
+                                       double* d_ws, uint32_t blocks, KernelGate gate, unsigned long long* d_steps_exec) {
+  if (blocks == 0 || n_problems == 0) return RKH_OK;
+  PairStepArgs args;
+  args.sc = d_scene;
+  args.dyn = dyn;
+  args.tab_a = tab_a;
+  args.tab_b = tab_b;
+  args.ws_all = d_ws;
+  args.gate = gate;
+  args.edge_base = d_edge_base;
+  args.n_segments = 2 * n_problems;
+  args.steps_exec = d_steps_exec;
+  for (int k = 0; k < dyn.n_steps; ++k) {
+    args.step = uint32_t(k);
+    args.list_in = (k & 1) ? d_list1 : d_list0;
+    args.list_out = (k & 1) ? d_list0 : d_list1;
+    args.cnt_in = d_cnt + k;
+    args.cnt_out = d_cnt + k + 1;
+    switch (n_dof) {
+      case 1: launch_pair_step_t<1>(s, args, blocks); break;
+      case 2: launch_pair_step_t<2>(s, args, blocks); break;
+      case 3: launch_pair_step_t<3>(s, args, blocks); break;
+      case 4: launch_pair_step_t<4>(s, args, blocks); break;
+      case 6: launch_pair_step_t<6>(s, args, blocks); break;
+      case 7: launch_pair_step_t<7>(s, args, blocks); break;
+      default:
+        set_error("propagate: chains with this number of joints are not instantiated (1,2,3,4,6,7)");
+        return RKH_ERR_UNSUPPORTED;
+    }
+  }
+  RKH_HIP(hipGetLastError());
+  return RKH_OK;
 }
 
 // Diagnostic kernel (not on the product path): `iters` back-to-back f-evals + proximity tests of kPairEdges states per

@@ -322,8 +322,13 @@ RKH_DI GjkShape to_gjk(const ShapeG& s, const double* mesh_pool) {
 }
 
 // (shape1, shape2) are already in the routine's own argument order; mesh_pool: the scene's vertex pool (GJK pairs only)
+// GJK = false: kernels that never see mesh scenes (scene_fits_lane_kernel) leave the support-map query out -- its
+// run-time-indexed simplex arrays are the only thing in this header that needs a private (scratch) segment
+template <bool GJK = true>
 RKH_DI double pair_distance(int routine, const ShapeG& s1, const ShapeG& s2, const double* mesh_pool = nullptr) {
-  if (routine == PR_GJK) return gjk_distance(to_gjk(s1, mesh_pool), to_gjk(s2, mesh_pool));
+  if (GJK) {
+    if (routine == PR_GJK) return gjk_distance(to_gjk(s1, mesh_pool), to_gjk(s2, mesh_pool));
+  }
   switch (routine) {
     case PR_SPHERE_SPHERE: return dist_sphere_sphere(s1, s2);
     case PR_SPHERE_CCYL: return dist_sphere_ccyl(s1, s2);

@@ -278,6 +278,9 @@ struct KernelGate {
   uint32_t n_segments = 0;
   // the steps [step0, min(step1, n_steps)) of every edge (two-lanes kernel; the whole edge by default)
   uint32_t step0 = 0, step1 = 0xFFFFFFFFu;
+  // optional diagnostics: the kernel adds the edge-steps it integrated (steps that began with a live edge, the one that
+  // ended it included) -- the executed work of a launch, as opposed to n_steps per launched edge
+  unsigned long long* steps_exec = nullptr;
 };
 rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                             int n_pairs, const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges,
@@ -324,6 +327,12 @@ rkh_status launch_state_derivative_planar(hipStream_t s, int n_dof, const SceneD
 rkh_status launch_propagate_pairs(hipStream_t s, int n_dof, const SceneDev* d_scene, const DynDev& dyn, const EdgeIO& io,
                                   uint32_t grid_edges, const EdgeIO* io_b, uint32_t grid_b, const EdgeIO* tab_a,
                                   const EdgeIO* tab_b, uint32_t n_problems, double* d_ws, KernelGate gate = KernelGate());
+// the same mapping, one launch per RK4 step over the live edges of all problems (see propagate_pair_step_kernel)
+size_t propagate_pair_step_workspace_bytes(int n_dof, uint32_t blocks);
+rkh_status launch_propagate_pair_steps(hipStream_t s, int n_dof, const SceneDev* d_scene, const DynDev& dyn,
+                                       const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems,
+                                       const uint32_t* d_edge_base, uint2* d_list0, uint2* d_list1, uint32_t* d_cnt,
+                                       double* d_ws, uint32_t blocks, KernelGate gate, unsigned long long* d_steps_exec);
 uint32_t pair_kernel_waves_per_cu(int n_dof);
 uint32_t pair_kernel_edges_per_wave();
 rkh_status launch_pair_cycles(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, const double* d_u,

@@ -72,7 +72,7 @@ EXPORTS = [
     "rkh_scene_create", "rkh_scene_create_with_meshes", "rkh_diag_gjk_distance", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
-    "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_create_batch", "rkh_birrtstar_create_qs_batch", "rkh_birrtstar_solve",
+    "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_planner_steer_steps", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_create_batch", "rkh_birrtstar_create_qs_batch", "rkh_birrtstar_solve",
     "rkh_birrtstar_get_graph", "rkh_rrtstar_set_branch_and_bound", "rkh_rrtstar_get_removed", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
     "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_create_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph", "rkh_birrt_create_qs_batch", "rkh_birrt_destroy", "rkh_birrt_solve", "rkh_birrt_get_trees", "rkh_planner_get_solution", "rkh_rrtstar_get_solution", "rkh_birrt_get_solution",
 ]
@@ -168,6 +168,7 @@ def load():
     lib.rkh_planner_nn_profile.argtypes = [vp, dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.rkh_planner_nn_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.rkh_planner_steer_profile.argtypes = [vp, dp, C.POINTER(C.c_uint64)]
+    lib.rkh_planner_steer_steps.argtypes = [vp, C.POINTER(C.c_uint64)]
     _lib = lib
     return lib
 
@@ -439,6 +440,12 @@ class RrtPlanner:
         _check(self.lib.rkh_planner_steer_profile(self.h, C.byref(ms), C.byref(ln)))
         return ms.value, ln.value
 
+    def steer_steps(self):
+        """RK4 steps the steer kernels integrated so far (executed work, not n_steps per launched edge)."""
+        n = C.c_uint64()
+        _check(self.lib.rkh_planner_steer_steps(self.h, C.byref(n)))
+        return n.value
+
     def tree(self, problem=0):
         st = self.all_stats[problem]
         nv, it, D = int(st.num_vertices), int(st.iterations), self.D
@@ -531,6 +538,9 @@ class RrtPlannerPool:
     def steer_profile(self):
         prof = [pl.steer_profile() for pl in self.planners]
         return sum(p[0] for p in prof), sum(p[1] for p in prof)
+
+    def steer_steps(self):
+        return sum(pl.steer_steps() for pl in self.planners)
 
     def close(self):
         for pl in self.planners:

@@ -1388,3 +1388,45 @@ def test_planner_pool_splits_a_batch_without_changing_results(L, ctx, oracle, c2
         assert one.solution(i)[1] == pool.solution(i)[1]
     pool.close()
     one.close()
+
+
+def test_stepwise_and_two_phase_steer_launches_do_not_change_results(L, ctx, oracle, c2, monkeypatch):
+    """The steer launch of a large round in its three forms -- one launch for the whole edge, two phases with a compaction
+    of the survivors between them, one launch per RK4 step over the live edges of all problems (the default) -- runs the
+    same arithmetic per edge.  The round sizes at which the planner switches between them are far above what a test can
+    afford (32 k / 65 k edges), so RKH_STEER_SPLIT_MIN_EDGES = 0 sends every round of the two-lanes mapping (>= 1024 edges)
+    through the form under test.  Trees, NN sequences, accept bits, goal probes and counters must be identical across
+    the forms, equal to the oracle's, and the executed-step counter must agree with the free-step counts."""
+    prms = [c2.rrt_params(seed=70 + i, max_vertices=2500) for i in range(40)]
+    picks = (0, 17, 39)
+    runs = {}
+    for name, env in (("whole", {"RKH_STEER_SPLIT": "0", "RKH_STEER_STEPWISE": "0"}),
+                      ("two_phase", {"RKH_STEER_STEPWISE": "0", "RKH_STEER_SPLIT": "5", "RKH_STEER_SPLIT_MIN_EDGES": "0"}),
+                      ("stepwise", {"RKH_STEER_STEPWISE": "1", "RKH_STEER_SPLIT_MIN_EDGES": "0"})):
+        for k in ("RKH_STEER_SPLIT", "RKH_STEER_STEPWISE", "RKH_STEER_SPLIT_MIN_EDGES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = L.RrtPlanner(L.Scene(ctx, c2), prms)
+        pl.solve_planning_query()
+        runs[name] = {"stats": [(int(s.num_vertices), int(s.iterations), int(s.edges_checked), int(s.num_solutions),
+                                 float(s.best_cost)) for s in pl.all_stats],
+                      "trees": [pl.tree(i) for i in picks], "steps": pl.steer_steps(),
+                      "spec": sum(int(s.edges_speculated) for s in pl.all_stats)}
+        pl.close()
+    for name in ("two_phase", "stepwise"):
+        assert runs[name]["stats"] == runs["whole"]["stats"], name
+        for a, b in zip(runs[name]["trees"], runs["whole"]["trees"]):
+            for key in ("parent", "nn_seq", "accept", "pos", "goal_dist"):
+                assert np.array_equal(a[key], b[key]), (name, key)
+    # executed work: every form integrates the same steps (a step counts when it starts from a live edge), fewer than
+    # the 20 per propagated edge the launches are sized for
+    assert runs["stepwise"]["steps"] == runs["whole"]["steps"] == runs["two_phase"]["steps"]
+    assert 0 < runs["stepwise"]["steps"] < 20 * 2 * runs["stepwise"]["spec"]
+    osc = oracle.OracleScene(c2, fast=True)
+    rc, ro, rt = osc.rrt_dyn(prms[17])
+    t = runs["stepwise"]["trees"][1]
+    assert runs["stepwise"]["stats"][17][:3] == (ro.num_vertices, ro.iterations, ro.edges_checked)
+    for key in ("parent", "nn_seq", "accept"):
+        assert np.array_equal(t[key], rt[key]), key
+    assert np.allclose(t["pos"], rt["pos"], rtol=STATE_RTOL, atol=1e-12)
