@@ -31,6 +31,13 @@ rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double
 rkh_status rkh_diag_gjk_distance(rkh_ctx* ctx, const rkh_shape* a, const rkh_shape* b, uint32_t n,
                                  const double* mesh_vertices, uint32_t n_mesh_vertices, double* dist);
 
+/* The planner-regime 1-NN sweep (half-precision mirror of the vertex rows + exact resolution of the one or two rows the
+ * estimate leaves, reak_amd/csrc/nn_mirror.hip) on a caller's point cloud: n points [n][D], B queries [B][D], every
+ * |coordinate| <= coord_bound (1e-3 .. 32), D <= 12.  idx / dist: the nearest point of each query, first minimum wins
+ * (min_dist_linear_search, topological_search.hpp:95-118), bit-identical to the fp64 sweeps. */
+rkh_status rkh_diag_nn_mirror_query(rkh_ctx* ctx, const double* pts, uint64_t n, int D, const double* q, uint32_t B,
+                                    double coord_bound, uint32_t* idx, double* dist);
+
 /* With RKH_PROFILE_NN=1 in the environment at rkh_planner_create, every round brackets its NN sweep kernel with
  * HIP events on the planner stream: total kernel time, algorithmic bytes (n*D*8 per sweep) and launch count. */
 rkh_status rkh_planner_nn_profile(rkh_planner* p, double* total_ms, uint64_t* total_bytes, uint64_t* launches);

@@ -29,6 +29,7 @@
 #include <cstring>
 #include <random>
 
+#include "nn_mirror.h"
 #include "rkh_internal.h"
 
 namespace rkh {
@@ -66,6 +67,8 @@ struct ProblemDev {  // device pointers of one problem
   double* x_out;
   uint8_t* accept;
   uint32_t* round_n;  // profiling: vertex count at the start of each round (may be null)
+  uint4* mirror;      // half-precision mirror of the tree rows (nn_mirror.h), or null
+  uint32_t* dx_max_bits;  // its running maximum of |x - x_h|
 };
 
 // sel: {edge counter of even rounds, of odd rounds}.  Every problem adds its candidates + pending goal probes to the
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(256) void commit_kernel(const ProblemDev* __restric
         if (a) {
           const uint32_t row = n0 + incl - 1;
           for (int d = 0; d < DP; ++d) pr.tree[uint64_t(row) * DP + d] = d < D ? pr.x_out[uint64_t(b) * D + d] : 0.0;
+          if (pr.mirror) mirror_store_row(pr.mirror, row, pr.x_out + uint64_t(b) * D, D, pr.dx_max_bits);
           pr.parent[row] = pr.nn_idx[b];
           pr.node_sample[row] = s0 + b;
         }
@@ -494,6 +498,8 @@ struct Problem {  // host view of one planning problem
   uint8_t* d_accept = nullptr;
   double* d_probe_x = nullptr;
   uint32_t* d_probe_steps = nullptr;
+  void* d_mirror = nullptr;        // half-precision mirror of d_tree (nn_mirror.h)
+  void* d_cand = nullptr;          // per-query scratch of the mirror sweep (nn1_mirror_carve), then one word: dx_max_bits
   uint32_t* d_ids_c = nullptr;  // survivors of the first steer phase: candidates, goal probes (launch_edges)
   uint32_t* d_ids_p = nullptr;
   double* d_goal = nullptr;
@@ -558,6 +564,8 @@ struct rkh_planner {
   uint32_t steer_split = 5;          // steps of the first phase (RKH_STEER_SPLIT; 0 = one launch for the whole edge)
   // Step-wise steer launches (propagate_pair_step_kernel, the default; RKH_STEER_STEPWISE=0: the two-phase launch above):
   // one launch per RK4 step over the live edges of all problems, survivors handed on through two ping-pong lists.
+  bool nn_mirror = false;  // the NN search of a round runs over the trees' half-precision mirrors (nn_mirror.hip)
+  double x_norm_bound = 0.0;  // >= |x| of every vertex (hyperbox corners, start states)
   int steer_stepwise = 1;
   uint2* d_step_list[2] = {nullptr, nullptr};  // (segment, edge) of the edges alive after step k (k odd / even)
   uint32_t* d_step_cnt = nullptr;              // [kMaxSteps + 1] live edges entering step k (cleared by round_begin_kernel)
@@ -566,6 +574,7 @@ struct rkh_planner {
   // rounds below this many edges keep the single whole-edge launch of the two-lanes mapping (RKH_STEER_SPLIT_MIN_EDGES;
   // default: what leaves every SIMD at most one 32-edge wave -- such a round gains nothing from shedding waves)
   uint32_t split_min_edges = 0;
+  uint64_t max_n_ub = 1;  // largest vertex-count bound over the problems (sizes the mirror sweep's row slices)
   uint64_t sum_batch_ub = 0, prev_sum_batch_ub = 0;  // host-side bounds on the candidates of this / the previous round, all problems
   // segment tables of the sample generator: [0] what the enqueued rounds need, [1] the next call's share, generated
   // while the GPU works on the rounds just enqueued
@@ -780,23 +789,29 @@ rkh_status enqueue_round(rkh_planner* p) {
   uint32_t batch_ub = 1;
   p->prev_sum_batch_ub = p->sum_batch_ub ? p->sum_batch_ub : uint64_t(p->b_max) * p->P;
   p->sum_batch_ub = 0;
+  p->max_n_ub = 1;
   for (uint32_t i = 0; i < p->P; ++i) {
     const PlannerState& hs = p->prob[i].h_state;
     const uint32_t b = batch_upper_bound(hs, p->n_ub[i], scale);
     batch_ub = std::max(batch_ub, b);
     p->sum_batch_ub += b;
+    p->max_n_ub = std::max(p->max_n_ub, p->n_ub[i]);
     p->n_ub[i] = std::min<uint64_t>(p->n_ub[i] + b, uint64_t(hs.max_total));
   }
   const uint32_t probe_ub = p->prev_batch_ub ? p->prev_batch_ub : p->b_max;
   p->prev_batch_ub = batch_ub + kProbeGranule;  // next round's probes: this round's vertices + what was left over
   p->round_parity ^= 1u;
   hipLaunchKernelGGL(round_begin_kernel, dim3(1), dim3(256), 0, s, p->d_probs, p->P, slot, p->d_sel, p->round_parity,
-                     fit ? float(p->wave_fill) : 0.0f, p->wave_slots, p->d_wave_base, p->d_nn_base, nn1_mfma_queries(),
+                     fit ? float(p->wave_fill) : 0.0f, p->wave_slots, p->d_wave_base, p->d_nn_base,
+                     p->nn_mirror ? nn1_mirror_queries() : nn1_mfma_queries(),
                      p->d_wave_base ? p->d_wave_base + (2 * p->P + 1) : nullptr, lane_kernel_edges_per_wave(),
                      p->d_step_cnt);
   // 1. NN sweep of every problem's samples over its snapshot
-  rkh_status st = launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, batch_ub, p->part_blocks, ev0, ev1,
-                             p->coord_bound, p->d_nn_base, true);
+  rkh_status st = p->nn_mirror
+                      ? launch_nn1_mirror(s, p->D, p->d_nn_args, p->P, p->max_n_ub, batch_ub, p->x_norm_bound, p->d_nn_base,
+                                          ev0, ev1)
+                      : launch_nn1(s, p->D, NnArgs(), p->d_nn_args, p->P, p->max_capacity, batch_ub, p->part_blocks, ev0,
+                                   ev1, p->coord_bound, p->d_nn_base, true);
   if (st != RKH_OK) return st;
   // 2. speculative steer of all candidates + the goal probes of the vertices the previous round committed
   if (ev0) (void)hipEventRecord(p->ev_steer[2 * slot], s);
@@ -824,7 +839,7 @@ rkh_status enqueue_round(rkh_planner* p) {
 void free_problem(Problem& q) {
   void* bufs[] = {q.d_tree, q.d_parent, q.d_node_sample, q.d_goal_dist, q.d_samples, q.d_nn_seq, q.d_accept_log,
                   q.d_nn_idx, q.d_nn_dist, q.d_x_out, q.d_steps, q.d_accept, q.d_probe_x, q.d_probe_steps, q.d_goal,
-                  q.d_part_dist, q.d_part_idx, q.d_round_n, q.d_mt, q.d_ids_c, q.d_ids_p};
+                  q.d_part_dist, q.d_part_idx, q.d_round_n, q.d_mt, q.d_ids_c, q.d_ids_p, q.d_mirror, q.d_cand};
   for (void* b : bufs) (void)hipFree(b);
 }
 
@@ -958,6 +973,10 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   p->split_min_edges = (p->steer_stepwise ? p->wave_slots / 2 : p->wave_slots) * pair_kernel_edges_per_wave();
   if (const char* e = getenv("RKH_STEER_SPLIT_MIN_EDGES")) p->split_min_edges = uint32_t(std::max(0, atoi(e)));
   p->step_blocks_cap = 2 * p->wave_slots;
+  // Many problems per planner: a round's candidates per problem stay within ONE query block of the mirror sweep (a
+  // second block re-reads the whole tree for a handful of queries; 512 problems x 100 000: 7.45 -> 7.62 M expansions/s).
+  // The batch rule only reaches the cap late in a run (1.25 sqrt(n) = 384 at n = 94 k) or through the wave fit's scale.
+  if (nn1_mirror_applies(p->D, p->coord_bound) && n_problems >= 64) p->b_max = std::min(p->b_max, nn1_mirror_queries());
   if (const char* e = getenv("RKH_BATCH_MAX")) p->b_max = std::max(8, atoi(e));
   p->b_max = std::min<uint32_t>(p->b_max, 4096);
   if (const char* e = getenv("RKH_LANE_THRESHOLD")) p->lane_threshold = uint32_t(std::max(0, atoi(e)));
@@ -991,6 +1010,13 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   uint32_t b_min = 8;
   if (const char* e = getenv("RKH_BATCH_FACTOR")) batch_factor = float(atof(e));
   if (const char* e = getenv("RKH_BATCH_MIN")) b_min = std::max(1, atoi(e));
+  p->nn_mirror = nn1_mirror_applies(p->D, p->coord_bound);
+  for (int d = 0; d < p->D; ++d) {
+    double m = std::max(std::fabs(p->lower[d]), std::fabs(p->upper[d]));
+    for (uint32_t i = 0; i < n_problems; ++i) m = std::max(m, std::fabs(prms[i].start[d]));
+    p->x_norm_bound += m * m;
+  }
+  p->x_norm_bound = std::sqrt(p->x_norm_bound) * (1.0 + 1e-9);
   const uint32_t P = n_problems;
   p->prob.resize(P);
   RKH_HIP(hipMalloc(&p->d_states, P * sizeof(PlannerState)));
@@ -1058,10 +1084,23 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     RKH_HIP(hipMalloc(&q.d_part_idx, uint64_t(p->part_blocks + 1) * p->b_max * sizeof(uint32_t)));
     RKH_HIP(hipMemset(q.d_part_idx + uint64_t(p->part_blocks) * p->b_max, 0xFF, uint64_t(p->b_max) * sizeof(uint32_t)));
     if (p->profile_nn) RKH_HIP(hipMalloc(&q.d_round_n, 2 * rkh_planner::kProfMax * sizeof(uint32_t)));
+    if (p->nn_mirror) {
+      RKH_HIP(hipMalloc(&q.d_mirror, nn1_mirror_bytes(q.capacity)));
+      rkh_status ms = launch_mirror_fill(p->stream, q.d_mirror, q.capacity);
+      if (ms != RKH_OK) return ms;
+      const size_t cand_bytes = nn1_mirror_query_bytes() * p->b_max + 256;
+      RKH_HIP(hipMalloc(&q.d_cand, cand_bytes));
+      RKH_HIP(hipMemsetAsync(q.d_cand, 0, cand_bytes, p->stream));
+    }
     // root vertex = query start (create_root, rrt_path_planner.tpp:131-133)
     std::vector<double> row(DP, 0.0);
     for (int d = 0; d < D; ++d) row[d] = prms[i].start[d];
     RKH_HIP(hipMemcpy(q.d_tree, row.data(), DP * sizeof(double), hipMemcpyHostToDevice));
+    if (p->nn_mirror) {
+      uint32_t* dxw = reinterpret_cast<uint32_t*>(static_cast<char*>(q.d_cand) + nn1_mirror_query_bytes() * p->b_max);
+      rkh_status ms = launch_mirror_build(p->stream, q.d_mirror, q.d_tree, 1, D, DP, dxw);
+      if (ms != RKH_OK) return ms;
+    }
     const uint32_t no_parent = 0xFFFFFFFFu;
     RKH_HIP(hipMemcpy(q.d_parent, &no_parent, sizeof(uint32_t), hipMemcpyHostToDevice));
     RKH_HIP(hipMemcpy(q.d_goal, prms[i].goal, D * sizeof(double), hipMemcpyHostToDevice));
@@ -1090,6 +1129,9 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     pd.x_out = q.d_x_out;
     pd.accept = q.d_accept;
     pd.round_n = q.d_round_n;
+    pd.mirror = static_cast<uint4*>(q.d_mirror);
+    pd.dx_max_bits = q.d_cand ? reinterpret_cast<uint32_t*>(static_cast<char*>(q.d_cand) + nn1_mirror_query_bytes() * p->b_max)
+                              : nullptr;
     NnArgs& na = hn[i];
     na.pos = q.d_tree;
     na.d_n = &dst->n;
@@ -1102,6 +1144,11 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     na.seed = q.d_part_idx + uint64_t(p->part_blocks) * p->b_max;
     na.idx = q.d_nn_idx;
     na.dist = q.d_nn_dist;
+    na.mirror = q.d_mirror;
+    if (q.d_cand) {
+      nn1_mirror_carve(q.d_cand, p->b_max, &na);
+      na.dx_max_bits = pd.dx_max_bits;
+    }
     EdgeIO& io = hio[i];
     io.src = q.d_tree;
     io.src_idx = q.d_nn_idx;

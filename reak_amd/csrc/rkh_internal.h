@@ -49,7 +49,32 @@ struct NnArgs {  // one 1-NN problem: tree rows, queries, outputs (device pointe
   uint32_t* idx = nullptr;             // [B] results
   double* dist = nullptr;
   uint32_t* seed = nullptr;            // [B] optional: matrix-core sweeps start from a sampled minimum (all 0xFF between sweeps)
+  // planner-regime sweep over the half-precision mirror of the tree (nn_mirror.hip)
+  const void* mirror = nullptr;          // [ceil(capacity / 32)] slabs of 1 KB, nn_mirror.h
+  const uint32_t* dx_max_bits = nullptr; // max over the rows of |x - x_h| (bits of a float)
+  uint4* qfrag = nullptr;                // [B][2] B operands of the round's queries
+  double* qinfo = nullptr;               // [B][3] |q_h|^2, |q - q_h|, |q|
+  float* thr = nullptr;                  // [B] smallest estimate + band
+  uint32_t* cand_cnt = nullptr;          // [B] rows at or below thr (zero between sweeps)
+  uint32_t* cand_rows = nullptr;         // [B][nn1_mirror_cand_cap()]
+  float* est = nullptr;                  // [nn1_mirror_max_slices()][est_stride] smallest estimate per (row slice, query)
+  uint32_t est_stride = 0;
 };
+// nn_mirror.hip
+uint32_t nn1_mirror_queries();
+uint32_t nn1_mirror_cand_cap();
+uint32_t nn1_mirror_max_slices();
+size_t nn1_mirror_bytes(uint64_t capacity_rows);
+size_t nn1_mirror_query_bytes();
+void nn1_mirror_carve(void* base, uint32_t b_max, NnArgs* a);
+bool nn1_mirror_applies(int D, double coord_bound);
+rkh_status launch_mirror_fill(hipStream_t s, void* d_mirror, uint64_t capacity_rows);
+rkh_status launch_mirror_build(hipStream_t s, void* d_mirror, const double* d_pos, uint64_t n, int D, int DP,
+                               uint32_t* d_dx_max_bits);
+rkh_status launch_nn1_mirror(hipStream_t s, int D, const NnArgs* d_table, uint32_t n_problems, uint64_t n_upper,
+                             uint32_t B_upper, double x_norm_bound, const uint32_t* d_yblock_base, hipEvent_t ev0,
+                             hipEvent_t ev1);
+int nn_padded_dims(int D);
 rkh_status launch_nn1(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,
                       uint64_t n_upper, uint32_t B, uint32_t part_capacity_blocks, hipEvent_t ev0 = nullptr,
                       hipEvent_t ev1 = nullptr, double coord_bound = 0.0, const uint32_t* d_yblock_base = nullptr,

@@ -72,7 +72,7 @@ EXPORTS = [
     "rkh_scene_create", "rkh_scene_create_with_meshes", "rkh_diag_gjk_distance", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
-    "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_planner_steer_steps", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_create_batch", "rkh_birrtstar_create_qs_batch", "rkh_birrtstar_solve",
+    "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_planner_steer_steps", "rkh_diag_nn_mirror_query", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_create_batch", "rkh_birrtstar_create_qs_batch", "rkh_birrtstar_solve",
     "rkh_birrtstar_get_graph", "rkh_rrtstar_set_branch_and_bound", "rkh_rrtstar_get_removed", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
     "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_create_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph", "rkh_birrt_create_qs_batch", "rkh_birrt_destroy", "rkh_birrt_solve", "rkh_birrt_get_trees", "rkh_planner_get_solution", "rkh_rrtstar_get_solution", "rkh_birrt_get_solution",
 ]
@@ -169,6 +169,7 @@ def load():
     lib.rkh_planner_nn_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.rkh_planner_steer_profile.argtypes = [vp, dp, C.POINTER(C.c_uint64)]
     lib.rkh_planner_steer_steps.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.rkh_diag_nn_mirror_query.argtypes = [vp, dp, C.c_uint64, C.c_int, dp, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), dp]
     _lib = lib
     return lib
 
@@ -282,6 +283,20 @@ def gjk_distance(ctx, a, b, mesh_vertices=None):
     out = np.zeros(n)
     _check(ctx.lib.rkh_diag_gjk_distance(ctx.h, aa, bb, n, T.dptr(verts) if len(verts) else None, len(verts), T.dptr(out)))
     return out
+
+
+def nn_mirror_query(ctx, pts, q, coord_bound):
+    """1-NN of every query through the planner-regime sweep (half-precision mirror + exact resolution,
+    rkh_diag_nn_mirror_query): (index, distance) arrays."""
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    n, D = pts.shape
+    B = q.shape[0]
+    idx = np.zeros(B, dtype=np.uint32)
+    dist = np.zeros(B)
+    _check(ctx.lib.rkh_diag_nn_mirror_query(ctx.h, T.dptr(pts), n, D, T.dptr(q), B, float(coord_bound), T.u32ptr(idx),
+                                            T.dptr(dist)))
+    return idx, dist
 
 
 class Scene:

@@ -85,6 +85,38 @@ def test_nn1_single_precision_prefilters_are_bit_exact(L, ctx, oracle, D, n, B, 
     assert np.array_equal(dist, rdist)
 
 
+@pytest.mark.parametrize("D,n,B,bound", [(12, 30000, 300, np.pi), (12, 777, 129, np.pi), (12, 1, 5, np.pi), (12, 33, 1, 3.0),
+                                         (6, 100000, 500, np.pi), (3, 5000, 1000, 1.0), (2, 300, 37, 0.5), (7, 5000, 64, 2.0),
+                                         (12, 65536, 385, 30.0), (12, 200000, 777, np.pi), (8, 40000, 32, 0.01)])
+def test_nn1_mirror_sweep_is_bit_exact(L, ctx, oracle, D, n, B, bound):
+    """The planner-regime sweep (nn_mirror.hip): one half-precision matrix instruction per 32 x 32 (vertex, query) pairs
+    over the stored mirror of the rows selects the rows whose fp64 distance is evaluated -- index and distance must be
+    those of the linear search.  The cloud contains exact duplicates (ties resolve to the lower index), near-duplicates
+    one ulp apart, queries sitting on vertices, queries 1e-9 away from duplicated vertices, and more coincident vertices
+    than a query's candidate list holds (the resolve kernel's exact scan); sizes cover one row, partial slabs, several
+    query blocks (B > 384) and coordinate bounds from 0.01 to 30."""
+    rng = np.random.default_rng(11 * D + n + B)
+    pts = rng.uniform(-bound, bound, size=(n, D))
+    q = rng.uniform(-bound, bound, size=(B, D))
+    if n >= 100:
+        dup = rng.integers(0, n // 2, size=n // 50)
+        pts[n // 2 + np.arange(len(dup))] = pts[dup]                       # exact duplicates at higher indices
+        near = rng.integers(0, n // 2, size=n // 50)
+        pts[n - 1 - np.arange(len(near))] = np.clip(np.nextafter(pts[near], np.inf), -bound, bound)  # one ulp away
+        q[::7] = pts[rng.integers(0, n, size=len(q[::7]))]                 # queries on vertices
+        q[1::7] = np.clip(pts[dup[rng.integers(0, len(dup), size=len(q[1::7]))]] + rng.normal(0, 1e-9 * bound, size=(len(q[1::7]), D)),
+                          -bound, bound)
+    if n > 400:  # 24 + 15 coincident vertices: beyond the 16 candidate rows a query keeps
+        pts[100:124] = pts[100]
+        pts[300:400:7] = pts[100]
+        q[2 % B] = np.clip(pts[100] + 1e-9 * bound, -bound, bound)
+        q[3 % B] = pts[100]
+    idx, dist = L.nn_mirror_query(ctx, pts, q, bound)
+    ridx, rdist = oracle.nn1(q, pts)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(dist, rdist)
+
+
 @pytest.mark.parametrize("scale", [1e-9, 1e9])
 def test_prefilters_step_aside_for_extreme_scales(L, ctx, oracle, scale):
     """The pre-filters' error analysis assumes float products and bf16 pieces in the normal range: clouds with a coordinate

@@ -54,7 +54,7 @@ def code_objects(so_path, arch="gfx950"):
 def _demangle(names):
     r = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
     out = r.stdout.splitlines() if r.returncode == 0 else names
-    return [re.sub(r"^void\s+", "", re.sub(r"\(.*$", "", d)) for d in out]
+    return [re.sub(r"^void\s+", "", re.sub(r"\(.*$", "", d.replace("(anonymous namespace)::", ""))) for d in out]
 
 
 def kernel_resources(so_path=None):

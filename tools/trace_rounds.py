@@ -16,7 +16,7 @@ print(f"{len(rows)} kernel launches, {len(starts)} rounds")
 
 
 def short(n):
-    n = n.replace("rkh::", "")
+    n = n.replace("rkh::", "").replace("(anonymous namespace)::", "")
     return n.split("(")[0][:60]
 
 
