@@ -370,39 +370,44 @@ def c3_rrtstar_rate(lib, ctx, events, P=16, max_vertices=20000, knn_n=1 << 20):
     ed = sum(int(s.edges_checked) for s in pl.all_stats)
     rw = sum(int(s.rewires) for s in pl.all_stats)
     pl.close()
-    D = 6
-    nn = lib.HipNeighborSearch(ctx, D, knn_n)
-    nn.fill_uniform(knn_n, seed=3)
-    logn = int(np.floor(np.log2(knn_n))) + 1
-    k, radius = 4 * logn, 3.0 * (logn / knn_n) ** (1.0 / D)
-    B = 8
-    q = torch.rand(B, D, dtype=torch.float64, device="cuda")
-    idx = torch.zeros(B, k, dtype=torch.int32, device="cuda")
-    dist = torch.zeros(B, k, dtype=torch.float64, device="cuda")
-    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    call = lambda: lib._check(nn.lib.rkh_nn_queryk_async(nn.h, q.data_ptr(), B, k, float(radius), idx.data_ptr(),
-                                                         dist.data_ptr(), cnt.data_ptr()))
-    for _ in range(3):
-        call()
-    ctx.synchronize()
-    a, b = events.create(), events.create()
-    events.record(a, ctx.stream)
-    reps = 20
-    for _ in range(reps):
-        call()
-    events.record(b, ctx.stream)
-    ctx.synchronize()
-    ms = events.elapsed_ms(a, b) / reps
-    nn.close()
-    gbps = knn_n * D * 8 / (ms * 1e-3) / 1e9
+    def knn_sweep(D):
+        nn = lib.HipNeighborSearch(ctx, D, knn_n)
+        nn.fill_uniform(knn_n, seed=3)
+        logn = int(np.floor(np.log2(knn_n))) + 1
+        k, radius = 4 * logn, 3.0 * (logn / knn_n) ** (1.0 / D)
+        B = 8
+        q = torch.rand(B, D, dtype=torch.float64, device="cuda")
+        idx = torch.zeros(B, k, dtype=torch.int32, device="cuda")
+        dist = torch.zeros(B, k, dtype=torch.float64, device="cuda")
+        cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        call = lambda: lib._check(nn.lib.rkh_nn_queryk_async(nn.h, q.data_ptr(), B, k, float(radius), idx.data_ptr(),
+                                                             dist.data_ptr(), cnt.data_ptr()))
+        for _ in range(3):
+            call()
+        ctx.synchronize()
+        a, b = events.create(), events.create()
+        events.record(a, ctx.stream)
+        reps = 20
+        for _ in range(reps):
+            call()
+        events.record(b, ctx.stream)
+        ctx.synchronize()
+        ms = events.elapsed_ms(a, b) / reps
+        nn.close()
+        gbps = knn_n * D * 8 / (ms * 1e-3) / 1e9
+        return {"n": knn_n, "dims": D, "k": k, "queries_per_sweep": B, "us_per_batch": ms * 1e3, "bound": "hbm",
+                "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                "tree_bytes": knn_n * D * 8,
+                "note": "algorithmic bytes n * D * 8 per batch (the kernel makes two passes over the rows: bound sweep + "
+                        "collect sweep)"}
+
     return {"workload": "C3: 6-DOF chain, RRT* (quasi-static space), star_neighborhood k-NN rewiring", "problems": P,
             "max_vertices": max_vertices, "iterations_per_s": it / dt, "edges_collision_checked_per_s": ed / dt,
             "rewires": rw, "seconds": dt,
-            "knn_sweep": {"n": knn_n, "dims": D, "k": k, "queries_per_sweep": B, "us_per_batch": ms * 1e3,
-                          "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
-                          "note": "algorithmic bytes n * D * 8 per batch (the kernel makes two passes over the rows: bound "
-                                  "sweep + collect sweep; at 1 Mi x 6 the 48 MB tree is Infinity-Cache resident)"}}
+            # 6-D: the quasi-static space the RRT* above plans in (48 MB tree, Infinity-Cache resident); 12-D: the state
+            # space of the same chain (q, qd) -- the 96 MB tree SURVEY 8(a3)/(d) sizes C3 at
+            "knn_sweep": knn_sweep(6), "knn_sweep_d12": knn_sweep(12)}
 
 
 def c4_prm_rate(lib, ctx, P=16, max_vertices=1500):

@@ -18,13 +18,18 @@
 //   KNN synchro                                 R/ctrl/path_planning/any_knn_synchro.hpp:69-84            hip_knn_synchro
 //   steerable C_free topology                   R/ctrl/path_planning/steerable_space_concept.hpp:78-93    kte_dynamic_free_space
 //   proximity (findMinimumDistance)             R/geometry/proximity/proximity_finder_3D.hpp:49-82        hip_proxy_query_pair
-//   planner entry (solve_planning_query)        R/ctrl/path_planning/motion_planner_base.hpp:102          hip_rrt_planner
+//   planner entry (solve_planning_query)        R/ctrl/path_planning/motion_planner_base.hpp:102          hip_rrt_planner, hip_rrtstar_planner,
+//                                                                                                           hip_prm_planner, hip_birrt_planner
+//   quasi-static C_free topology                R/ctrl/topologies/manip_free_workspace.hpp:113-300        manip_quasi_static_free_space
+//   the global generator                        R/core/base/global_rng.hpp:44-54                          get_global_rng / global_rng_seed
 #ifndef RKH_ADAPTORS_HPP
 #define RKH_ADAPTORS_HPP
 
 #include <cmath>
 #include <cstddef>
+#include <algorithm>
 #include <cstdint>
+#include <functional>
 #include <iterator>
 #include <limits>
 #include <memory>
@@ -90,6 +95,10 @@ struct hip_linear_neighbor_search {
     uint32_t idx = 0;
     double d = 0.0;
     check(rkh_nn_query1(nn.get(), &p[0], 1, &idx, &d));
+    // an empty (or fully removed) store answers 0xFFFFFFFF: min_dist_linear_search then returns its initial
+    // `result`, a default-constructed descriptor = boost::graph_traits<Graph>::null_vertex() (:98-100); the graph
+    // supplies it through the free function null_vertex(g)
+    if (idx == 0xFFFFFFFFu) return null_vertex(g);
     return vertex(std::size_t(idx), g);
   }
   // OutIt operator()(p, out, g, space, position, max_neighbors = 1, radius = inf) const
@@ -136,23 +145,66 @@ struct hip_knn_synchro {
     check(rkh_nn_append(nn.get(), &p[0], 1));
   }
   // The device store is append-only with tombstones: row numbers = order of the added_vertex calls, so the graph's
-  // vertex descriptor must convert to that number (vecS / pooled vertex lists: the descriptor is the index; a graph
-  // that re-uses the holes of removed vertices has to map descriptors to insertion numbers in `index_of`).
+  // vertex descriptor must convert to that number.  vecBC vertex lists: the descriptor IS that index while nothing is
+  // removed.  poolBC storage (rrtstar_path_planner.tpp:102-103) re-uses the hole of a removed vertex for the next
+  // add_vertex (lazy_connector.hpp:359-364 removes unconnectable vertices; branch and bound prunes): from the first
+  // removal on, descriptor != insertion number.  The mapping a maintainer keeps beside this synchro is
+  //     insertion_number[descriptor]  (set in added_vertex: = count of added_vertex calls so far; read in removed_vertex)
+  //     descriptor_of[insertion_number]  (for the NNFinder: vertex(idx, g) above becomes descriptor_of[idx])
+  // -- `index_of` below is that hook (identity by default).  BGL-Extra is not part of the reference tree, so the hole
+  // order itself is "parity unpinned" (DESIGN.md section 2): results are identical up to this renaming of vertices.
+  std::function<uint64_t(uint64_t)> index_of;
   template <typename Vertex>
   void removed_vertex(Vertex u, Graph& g) const {
     (void)g;
-    check(rkh_nn_remove(nn.get(), static_cast<uint64_t>(u)));
+    const uint64_t d = static_cast<uint64_t>(u);
+    check(rkh_nn_remove(nn.get(), index_of ? index_of(d) : d));
   }
 };
 
+// ---- the global generator (R/core/base/global_rng.hpp:44-54) ----------------------------------------------------------
+// ReaK's samplers draw from one process-global boost::mt19937 (bit-identical to std::mt19937).  The device planners
+// generate their sample stream from a SEED (rkh_rrt_params::seed), so the adaptors need to know the seed the engine was
+// last given: seed it through global_rng_seed(s) (= get_global_rng().seed(s)); a planner entry checks that the engine
+// still is mt19937(s) -- nothing was drawn since -- and, after planning, advances it by the draws the planner consumed,
+// so that host code drawing afterwards continues the same stream the sequential planner would have left.
+inline std::mt19937& get_global_rng() {
+  static std::mt19937 instance;  // default seed 5489, like the reference's never-seeded engine
+  return instance;
+}
+inline uint32_t& global_rng_last_seed() {
+  static uint32_t s = std::mt19937::default_seed;
+  return s;
+}
+inline void global_rng_seed(uint32_t s) {
+  get_global_rng().seed(s);
+  global_rng_last_seed() = s;
+}
+inline uint32_t global_rng_fresh_seed() {  // the seed the device planners take; throws if draws were made since it was set
+  if (!(get_global_rng() == std::mt19937(global_rng_last_seed())))
+    throw unsupported_error("the device planners start from a freshly seeded global generator: call rkh::global_rng_seed(s) "
+                            "right before solve_planning_query");
+  return global_rng_last_seed();
+}
+
 // ---- super-space: hyperbox_topology< vect_n<double> > with the euclidean metric ---------------------------------
-// (R/ctrl/topologies/hyperbox_topology.hpp:97-103,178-189; vect_distance_metrics.hpp:113-137).  random_point draws
-// from the engine it is given -- ReaK uses the global mt19937 (global_rng.hpp:44-54), D draws of
-// uniform_01<mt19937&, double> = eng() * 2^-32 per point.
+// (R/ctrl/topologies/hyperbox_topology.hpp:97-103,178-189; vect_distance_metrics.hpp:113-137; the Topology / MetricSpace
+// / PointDistribution concepts of metric_space_concept.hpp:86-223).  random_point() draws from the global mt19937,
+// D draws of uniform_01<mt19937&, double> = eng() * 2^-32 per point.
+struct distance_metric_t {};  // tag of get(distance_metric, space) (metric_space_concept.hpp:60-62)
+static const distance_metric_t distance_metric = distance_metric_t();
+template <typename Space>
+struct bound_distance_metric {  // what get(distance_metric, space) returns: d(a, b, space)
+  template <typename Point>
+  double operator()(const Point& a, const Point& b, const Space& s) const { return s.distance(a, b); }
+  template <typename Point>
+  double operator()(const Point& dp, const Space& s) const { return s.norm(dp); }
+};
 template <typename Point>
 struct hyperbox_super_space {
   Point lower, upper;
   typedef Point point_type;
+  typedef Point point_difference_type;
   template <typename Engine>
   Point random_point(Engine& eng) const {
     Point p(lower);
@@ -165,13 +217,39 @@ struct hyperbox_super_space {
     }
     return p;
   }
-  double distance(const Point& a, const Point& b) const {  // euclidean_distance_metric: left-to-right sum, then sqrt
+  Point random_point() const { return random_point(get_global_rng()); }
+  double norm(const Point& dp) const {  // euclidean_distance_metric: left-to-right sum, then sqrt
+    double s = 0.0;
+    for (std::size_t i = 0; i < dp.size(); ++i) s += dp[i] * dp[i];
+    return std::sqrt(s);
+  }
+  double distance(const Point& a, const Point& b) const {
     double s = 0.0;
     for (std::size_t i = 0; i < a.size(); ++i) {
       const double d = a[i] - b[i];
       s += d * d;
     }
     return std::sqrt(s);
+  }
+  Point difference(const Point& a, const Point& b) const {  // a - b (vector_topology.hpp)
+    Point r(a);
+    for (std::size_t i = 0; i < a.size(); ++i) r[i] = a[i] - b[i];
+    return r;
+  }
+  Point origin() const {  // hyperbox_topology::origin: the centre of the box
+    Point r(lower);
+    for (std::size_t i = 0; i < lower.size(); ++i) r[i] = (lower[i] + upper[i]) * 0.5;
+    return r;
+  }
+  Point adjust(const Point& a, const Point& dp) const {
+    Point r(a);
+    for (std::size_t i = 0; i < a.size(); ++i) r[i] = a[i] + dp[i];
+    return r;
+  }
+  Point move_position_toward(const Point& a, double fraction, const Point& b) const {  // a + (b - a) * fraction
+    Point r(a);
+    for (std::size_t i = 0; i < a.size(); ++i) r[i] = a[i] + (b[i] - a[i]) * fraction;
+    return r;
   }
   bool is_in_bounds(const Point& p) const {
     for (std::size_t i = 0; i < p.size(); ++i) {
@@ -184,12 +262,17 @@ struct hyperbox_super_space {
     return true;
   }
 };
+template <typename Point>
+bound_distance_metric<hyperbox_super_space<Point> > get(distance_metric_t, const hyperbox_super_space<Point>&) {
+  return bound_distance_metric<hyperbox_super_space<Point> >();
+}
 
 // ---- steerable C_free topology ---------------------------------------------------------------------------------------
-// Models SubSpaceConcept (get_super_space), MetricSpace (distance, move_position_toward), is_free, and
-// SteerableSpaceConcept: std::pair<point_type, steer_record_type> steer_position_toward(a, fraction, b)
-// (steerable_space_concept.hpp:78-93; the loop shape of examples/misc/MEAQR_topology.hpp:503-565 with the PD law of
-// rkh_dyn_space).  Points are value types holding 2 n_dof doubles (q, qd interleaved, kte_nl_system.hpp:190-193).
+// Models SubSpaceConcept (get_super_space), Topology (difference / origin / adjust), MetricSpace (distance, get(distance_
+// metric, .), move_position_toward), PointDistribution (random_point), is_free, and SteerableSpaceConcept:
+// std::pair<point_type, steer_record_type> steer_position_toward(a, fraction, b) (steerable_space_concept.hpp:78-93; the
+// loop shape of examples/misc/MEAQR_topology.hpp:503-565 with the PD law of rkh_dyn_space).  Points are value types
+// holding 2 n_dof doubles (q, qd interleaved, kte_nl_system.hpp:190-193).
 template <typename Point = std::vector<double> >
 class kte_dynamic_free_space {
  public:
@@ -210,6 +293,7 @@ class kte_dynamic_free_space {
   const super_space_type& get_super_space() const { return m_super; }
   const rkh_dyn_space& dyn_space() const { return m_sp; }
   const std::shared_ptr<rkh_scene>& scene() const { return m_scene; }
+  std::size_t dimensions() const { return 2 * std::size_t(m_sp.n_dof); }
 
   // manip_free_workspace.hpp:79-99,154-156: bounds, then "any proxy pair closer than 0 -> colliding"
   bool is_free(const Point& p) const {
@@ -241,18 +325,92 @@ class kte_dynamic_free_space {
     const double dab = m_super.distance(a, b);
     return (dab * 0.05 > m_super.distance(r, b)) ? dab : std::numeric_limits<double>::infinity();
   }
+  double norm(const Point& dp) const { return m_super.norm(dp); }
+  // Topology concept on the sub-space: forwarded to the super-space, adjust through the free-space motion like the
+  // reference's sub-spaces do (no_obstacle_space.hpp:166-168: move_position_toward(p, 1.0, super.adjust(p, dp)))
+  Point difference(const Point& a, const Point& b) const { return m_super.difference(a, b); }
+  Point origin() const { return m_super.origin(); }
+  Point adjust(const Point& a, const Point& dp) const { return move_position_toward(a, 1.0, m_super.adjust(a, dp)); }
   template <typename Engine>
   Point random_point(Engine& eng) const {  // default_random_sampler on the super-space (default_random_sampler.hpp:64-66)
     return m_super.random_point(eng);
   }
+  Point random_point() const { return m_super.random_point(get_global_rng()); }
 
  private:
   std::shared_ptr<rkh_scene> m_scene;
   rkh_dyn_space m_sp;
   super_space_type m_super;
 };
+template <typename P>
+bound_distance_metric<kte_dynamic_free_space<P> > get(distance_metric_t, const kte_dynamic_free_space<P>&) {
+  return bound_distance_metric<kte_dynamic_free_space<P> >();
+}
+
+// ---- quasi-static C_free topology: manip_quasi_static_env (manip_free_workspace.hpp:113-300) -------------------------
+// Points are joint positions (n_dof doubles); move_position_toward walks the straight line in min_interval steps and
+// returns the last free point (interp_topo_move_position_toward_pred, interpolated_topologies.hpp:137-163), distance is
+// the length if the walk arrives, +inf otherwise (:193-199).
+template <typename Point = std::vector<double> >
+class manip_quasi_static_free_space {
+ public:
+  typedef Point point_type;
+  typedef Point point_difference_type;
+  typedef hyperbox_super_space<Point> super_space_type;
+  manip_quasi_static_free_space(const std::shared_ptr<rkh_scene>& scene, const rkh_qs_space& sp) : m_scene(scene), m_sp(sp) {
+    const std::size_t n = std::size_t(sp.n_dof);
+    m_super.lower = Point(n);
+    m_super.upper = Point(n);
+    for (std::size_t i = 0; i < n; ++i) {
+      m_super.lower[i] = sp.lower[i];
+      m_super.upper[i] = sp.upper[i];
+    }
+  }
+  const super_space_type& get_super_space() const { return m_super; }
+  const rkh_qs_space& qs_space() const { return m_sp; }
+  const std::shared_ptr<rkh_scene>& scene() const { return m_scene; }
+  std::size_t dimensions() const { return std::size_t(m_sp.n_dof); }
+  bool is_free(const Point& p) const {
+    if (!m_super.is_in_bounds(p)) return false;
+    std::vector<double> x(2 * p.size(), 0.0);  // rkh_min_distance takes states (q, qd interleaved)
+    for (std::size_t i = 0; i < p.size(); ++i) x[2 * i] = p[i];
+    double d = 0.0;
+    check(rkh_min_distance(m_scene.get(), x.data(), 1, &d));
+    return !(d < 0.0);
+  }
+  Point move_position_toward(const Point& a, double fraction, const Point& b) const {
+    Point out(a);
+    uint32_t n_checked = 0;
+    check(rkh_edge_check(m_scene.get(), m_sp.lower, m_sp.upper, m_sp.min_interval, &a[0], &b[0], 1, fraction, &out[0],
+                         &n_checked));
+    return out;
+  }
+  double distance(const Point& a, const Point& b) const {  // interp_topo_get_distance_pred
+    const Point r = move_position_toward(a, 1.0, b);
+    return (m_super.distance(r, b) < std::numeric_limits<double>::epsilon()) ? m_super.distance(a, b)
+                                                                            : std::numeric_limits<double>::infinity();
+  }
+  double norm(const Point& dp) const { return m_super.norm(dp); }
+  Point difference(const Point& a, const Point& b) const { return m_super.difference(a, b); }
+  Point origin() const { return m_super.origin(); }
+  Point adjust(const Point& a, const Point& dp) const { return move_position_toward(a, 1.0, m_super.adjust(a, dp)); }
+  template <typename Engine>
+  Point random_point(Engine& eng) const {
+    return m_super.random_point(eng);
+  }
+  Point random_point() const { return m_super.random_point(get_global_rng()); }
+
+ private:
+  std::shared_ptr<rkh_scene> m_scene;
+  rkh_qs_space m_sp;
+  super_space_type m_super;
+};
+template <typename P>
+bound_distance_metric<manip_quasi_static_free_space<P> > get(distance_metric_t, const manip_quasi_static_free_space<P>&) {
+  return bound_distance_metric<manip_quasi_static_free_space<P> >();
+}
 // trait tags the planners dispatch on (is_steerable_space / is_metric_space / ... are boost::mpl bools in ReaK;
-// a maintainer specialises them to true_ for this class, manip_free_workspace.hpp:307-318)
+// a maintainer specialises them to true_ for these classes, manip_free_workspace.hpp:307-318)
 template <typename T>
 struct is_steerable_space_tag {
   static const bool value = false;
@@ -297,67 +455,401 @@ class hip_proxy_query_pair {
   std::vector<double> m_state;
 };
 
-// ---- planner entry: sample_based_planner<FreeSpace>::solve_planning_query ------------------------------------------
-// (motion_planner_base.hpp:102, options :400-422; rrt_planner with UNIDIRECTIONAL_PLANNING | LINEAR_SEARCH_KNN,
-// rrt_path_planner.tpp:66-145).  The batched device driver grows exactly the tree of the sequential generate_rrt on
-// the query's seed; the adaptor rebuilds the caller's motion graph from it and reports the solutions.
-// Query concept used here: get_start_position(), get_goal_position(), max_num_results, register_solution(cost, path)
-// -- what planning_query / path_planning_p2p_query offer (p2p_planning_query.hpp:74-229).
+// ---- planner entry: sample_based_planner<FreeSpace>::solve_planning_query(planning_query<FreeSpace>&) ---------------
+// (motion_planner_base.hpp:102, options :400-422, report_progress / report_solution :343-351).  The batched device
+// drivers build exactly the graphs of the sequential algorithms on the seed of the global generator; an adaptor hands
+// the caller's QUERY OBJECT what the sequential planner's visitor would: every solution through
+//     query.register_solution(start_node, goal_node, goal_distance, graph)            (planning_queries.hpp:168-212)
+//     query.register_joining_point(start, goal, join1, join2, joining_distance, g1, g2)   (:214-273, bidirectional)
+// in the order the sequential planner finds them, and stops reporting once query.keep_going() turns false.  The Query
+// type is whatever offers the members planning_query / path_planning_p2p_query do (p2p_planning_query.hpp:74-229):
+// get_start_position(), get_goal_position(), max_num_results, keep_going(), register_solution(...), reset_solution_records().
+// The reporter chain (any_sbmp_reporter_chain) is two std::function hooks with the arguments of
+// do_report_progress_impl(space, g, reporter) / reporter.draw_solution(space, srp).
+//
+// The motion graph handed to the query: vertices in insertion order (vecBC semantics), bundles named like ReaK's
+// (any_motion_graphs.hpp:170-184: position, distance_accum, predecessor, weight).
+template <typename Point>
+struct hip_motion_graph {
+  struct vertex_bundled {
+    Point position;
+    double distance_accum;    // cost from the start along the predecessors (optimal_mg_vertex)
+    std::size_t predecessor;  // null_vertex() for a root / unconnected vertex
+    double weight;            // length of the edge from the predecessor
+    double density;           // PRM: prm_density_calculator
+  };
+  typedef std::size_t vertex_descriptor;
+  std::vector<vertex_bundled> v;
+  std::vector<std::pair<std::size_t, std::size_t> > edges;  // PRM roadmap edges in insertion order
+  std::vector<double> edge_weight;
+  static std::size_t null_vertex() { return std::size_t(-1); }
+  vertex_bundled& operator[](std::size_t u) { return v[u]; }
+  const vertex_bundled& operator[](std::size_t u) const { return v[u]; }
+};
+template <typename Point>
+std::size_t num_vertices(const hip_motion_graph<Point>& g) {
+  return g.v.size();
+}
+template <typename Point>
+std::size_t vertex(std::size_t i, const hip_motion_graph<Point>&) {
+  return i;
+}
+template <typename Point>
+std::size_t null_vertex(const hip_motion_graph<Point>&) {
+  return std::size_t(-1);
+}
+
+namespace detail {
+template <typename Point>
+inline void fill_params(rkh_rrt_params& prm, const Point& start, const Point& goal, uint32_t seed, std::size_t max_vertices,
+                        std::size_t max_results, double steer_tol, double conn_tol) {
+  prm = rkh_rrt_params();
+  prm.seed = seed;
+  prm.max_vertices = uint32_t(max_vertices);
+  prm.max_results = uint32_t(std::min<std::size_t>(max_results, std::size_t(1) << 30));
+  prm.steer_tol = steer_tol;
+  prm.conn_tol = conn_tol;
+  for (std::size_t i = 0; i < start.size(); ++i) {
+    prm.start[i] = start[i];
+    prm.goal[i] = goal[i];
+  }
+}
+// the draws a finished planner consumed leave the global engine where the sequential planner would have left it
+inline void consume_global_draws(uint64_t draws) { get_global_rng().discard(draws); }
+inline const rkh_dyn_space* dyn_of(const void*) { return nullptr; }
+}  // namespace detail
+
+// common options of sample_based_planner (motion_planner_base.hpp:400-422)
 template <typename FreeSpace>
-class hip_rrt_planner {
+class hip_planner_base {
  public:
   typedef typename FreeSpace::point_type point_type;
-  hip_rrt_planner(const std::shared_ptr<FreeSpace>& space, std::size_t max_vertex_count, double steer_progress_tol = 0.1,
-                  double connection_tol = 0.05)
-      : m_space(space), m_max_vertex_count(max_vertex_count), m_steer_tol(steer_progress_tol), m_conn_tol(connection_tol) {}
+  typedef hip_motion_graph<point_type> graph_type;
+  hip_planner_base(const std::shared_ptr<FreeSpace>& world, std::size_t max_vertex_count, std::size_t progress_interval,
+                   double steer_progress_tol, double connection_tol, double sampling_radius)
+      : m_space(world), m_max_vertex_count(max_vertex_count), m_progress_interval(progress_interval),
+        m_steer_progress_tol(steer_progress_tol), m_connection_tol(connection_tol), m_sampling_radius(sampling_radius) {}
+  virtual ~hip_planner_base() {}
+  // set_reporter (motion_planner_base.hpp:112): the two calls a reporter chain receives
+  std::function<void(const FreeSpace&, const graph_type&)> progress_reporter;
+  std::function<void(const FreeSpace&, const graph_type&, double /*solution cost*/)> solution_reporter;
+  std::size_t get_max_vertex_count() const { return m_max_vertex_count; }
+  std::size_t get_progress_interval() const { return m_progress_interval; }
+  double get_steer_progress_tolerance() const { return m_steer_progress_tol; }
+  double get_connection_tolerance() const { return m_connection_tol; }
+  double get_sampling_radius() const { return m_sampling_radius; }
+  const graph_type& motion_graph() const { return m_graph; }  // the graph of the last query
 
-  struct result {
-    rkh_planner_stats stats;
-    std::vector<point_type> positions;  // vertices in insertion order (vertex 0 = the query's start)
-    std::vector<uint32_t> parent;       // 0xFFFFFFFF for the root
-    std::vector<uint32_t> solution;     // vertex ids of the best registered solution, start first (empty: none)
-    double solution_cost = std::numeric_limits<double>::infinity();
-  };
+ protected:
+  // report_progress (motion_planner_base.hpp:343-347) counts vertex_added calls and reports every m_progress_interval-th.
+  // The device grows the graph in batches, so the reports for the interval boundaries crossed since the last call are
+  // issued together, each seeing the graph as it is NOW (at most one batch ahead of its boundary).
+  void report_progress_upto(std::size_t vertices_added) {
+    if (!m_progress_interval) return;
+    while (m_reported + m_progress_interval <= vertices_added) {
+      m_reported += m_progress_interval;
+      if (progress_reporter) progress_reporter(*m_space, m_graph);
+    }
+  }
+  std::shared_ptr<FreeSpace> m_space;
+  std::size_t m_max_vertex_count, m_progress_interval;
+  double m_steer_progress_tol, m_connection_tol, m_sampling_radius;
+  graph_type m_graph;
+  std::size_t m_reported = 0;
+};
 
-  // seed = what the caller passed to get_global_rng().seed() (global_rng.hpp:44-54)
-  result solve_planning_query(const point_type& start, const point_type& goal, uint32_t seed,
-                              uint32_t max_num_results = 1u << 30) const {
-    rkh_rrt_params prm = rkh_rrt_params();
-    prm.seed = seed;
-    prm.max_vertices = uint32_t(m_max_vertex_count);
-    prm.max_results = max_num_results;
-    prm.steer_tol = m_steer_tol;
-    prm.conn_tol = m_conn_tol;
+// ---- rrt_planner, UNIDIRECTIONAL_PLANNING | LINEAR_SEARCH_KNN (rrt_path_planner.tpp:66-145) over the steerable dynamic
+// space or the quasi-static space
+template <typename FreeSpace>
+class hip_rrt_planner : public hip_planner_base<FreeSpace> {
+  typedef hip_planner_base<FreeSpace> base;
+
+ public:
+  typedef typename base::point_type point_type;
+  typedef typename base::graph_type graph_type;
+  hip_rrt_planner(const std::shared_ptr<FreeSpace>& world, std::size_t max_vertex_count, std::size_t progress_interval = 0,
+                  double steer_progress_tol = 0.1, double connection_tol = 0.05)
+      : base(world, max_vertex_count, progress_interval, steer_progress_tol, connection_tol, 1.0) {}
+
+  rkh_planner_stats last_stats = rkh_planner_stats();
+
+  template <typename Query>
+  void solve_planning_query(Query& aQuery) {
+    const point_type& start = aQuery.get_start_position();
+    const point_type& goal = aQuery.get_goal_position();
     const std::size_t D = start.size();
-    for (std::size_t i = 0; i < D; ++i) {
-      prm.start[i] = start[i];
-      prm.goal[i] = goal[i];
+    rkh_rrt_params prm;
+    detail::fill_params(prm, start, goal, global_rng_fresh_seed(), this->m_max_vertex_count, aQuery.max_num_results,
+                        this->m_steer_progress_tol, this->m_connection_tol);
+    std::shared_ptr<rkh_planner> pl = create(prm, static_cast<const FreeSpace*>(nullptr));
+    this->m_graph = graph_type();
+    this->m_reported = 0;
+    rkh_planner_stats st = rkh_planner_stats();
+    for (;;) {  // generate_rrt (rr_tree.hpp:179-199) in batches of rounds
+      check(rkh_planner_enqueue(pl.get(), 16));
+      check(rkh_planner_sync(pl.get(), &st));
+      pull_tree(pl.get(), D, st, st.done != 0);
+      this->report_progress_upto(std::size_t(st.num_vertices) - 1);
+      if (st.done) break;
     }
-    rkh_planner* raw = nullptr;
-    check(rkh_planner_create(m_space->scene().get(), &m_space->dyn_space(), &prm, &raw));
-    std::shared_ptr<rkh_planner> pl(raw, [](rkh_planner* p) { (void)rkh_planner_destroy(p); });
-    result r;
-    check(rkh_planner_solve(pl.get(), &r.stats));
-    const std::size_t nv = std::size_t(r.stats.num_vertices);
-    std::vector<double> pos(nv * D);
-    r.parent.resize(nv);
-    check(rkh_planner_get_tree(pl.get(), 0, pos.data(), r.parent.data(), nullptr, nullptr, nullptr));
-    r.positions.assign(nv, start);
-    for (std::size_t v = 0; v < nv; ++v)
-      for (std::size_t i = 0; i < D; ++i) r.positions[v][i] = pos[v * D + i];
-    uint32_t n_path = 0;
-    check(rkh_planner_get_solution(pl.get(), 0, nullptr, 0, &n_path, &r.solution_cost));
-    if (n_path) {
-      r.solution.resize(n_path);
-      check(rkh_planner_get_solution(pl.get(), 0, r.solution.data(), n_path, &n_path, &r.solution_cost));
-    }
-    return r;
+    // The goal probe of a vertex rides in the steer launch of the round after the one that added it, so the probes are
+    // complete once the planner is done (it stops by itself at max_num_results solutions): the solutions are handed to
+    // the query then, in the order the sequential planner registers them.
+    register_solutions(aQuery);
+    last_stats = st;
+    detail::consume_global_draws(uint64_t(st.iterations) * D);
   }
 
  private:
-  std::shared_ptr<FreeSpace> m_space;
-  std::size_t m_max_vertex_count;
-  double m_steer_tol, m_conn_tol;
+  std::shared_ptr<rkh_planner> create(const rkh_rrt_params& prm, const kte_dynamic_free_space<point_type>*) {
+    rkh_planner* raw = nullptr;
+    check(rkh_planner_create(this->m_space->scene().get(), &this->m_space->dyn_space(), &prm, &raw));
+    return std::shared_ptr<rkh_planner>(raw, [](rkh_planner* p) { (void)rkh_planner_destroy(p); });
+  }
+  std::shared_ptr<rkh_planner> create(const rkh_rrt_params& prm, const manip_quasi_static_free_space<point_type>*) {
+    rkh_planner* raw = nullptr;
+    check(rkh_planner_create_qs_batch(this->m_space->scene().get(), &this->m_space->qs_space(), &prm, 1, &raw));
+    return std::shared_ptr<rkh_planner>(raw, [](rkh_planner* p) { (void)rkh_planner_destroy(p); });
+  }
+  void pull_tree(rkh_planner* pl, std::size_t D, const rkh_planner_stats& st, bool with_goal_probes) {
+    const std::size_t nv = std::size_t(st.num_vertices);
+    std::vector<double> pos(nv * D), gd(nv > 1 ? nv - 1 : 1, std::numeric_limits<double>::infinity());
+    std::vector<uint32_t> parent(nv);
+    check(rkh_planner_get_tree(pl, 0, pos.data(), parent.data(), nullptr, nullptr, with_goal_probes ? gd.data() : nullptr));
+    graph_type& g = this->m_graph;
+    const std::size_t old = g.v.size();
+    g.v.resize(nv);
+    m_goal_dist.resize(nv, std::numeric_limits<double>::infinity());
+    for (std::size_t v = old; v < nv; ++v) {
+      typename graph_type::vertex_bundled& b = g.v[v];
+      b.position = point_type(pos.begin() + v * D, pos.begin() + (v + 1) * D);
+      b.predecessor = v == 0 ? graph_type::null_vertex() : std::size_t(parent[v]);
+      b.weight = v == 0 ? 0.0 : this->m_space->get_super_space().distance(g.v[b.predecessor].position, b.position);
+      b.distance_accum = v == 0 ? 0.0 : g.v[b.predecessor].distance_accum + b.weight;
+      b.density = 0.0;
+    }
+    if (with_goal_probes)
+      for (std::size_t v = 1; v < nv; ++v) m_goal_dist[v] = gd[v - 1];
+  }
+  // planning_visitor_base::edge_added (planning_visitors.hpp:186-201): a vertex whose goal probe is finite registers a
+  // solution, in vertex order, while the query wants more
+  template <typename Query>
+  void register_solutions(Query& aQuery) {
+    const graph_type& g = this->m_graph;
+    for (std::size_t v = 1; v < g.v.size(); ++v) {
+      if (!(m_goal_dist[v] < std::numeric_limits<double>::infinity())) continue;
+      if (!aQuery.keep_going()) break;
+      if (aQuery.register_solution(std::size_t(0), v, m_goal_dist[v], this->m_graph) && this->solution_reporter)
+        this->solution_reporter(*this->m_space, g, g.v[v].distance_accum + m_goal_dist[v]);
+    }
+  }
+  std::vector<double> m_goal_dist;
+};
+
+// ---- rrtstar_planner, UNIDIRECTIONAL_PLANNING | LINEAR_SEARCH_KNN (rrtstar_path_planner.tpp:298-; optionally
+// USE_BRANCH_AND_BOUND_PRUNING_FLAG).  Vertex 0 = start, vertex 1 = goal (the goal node is part of the graph, so
+// vertex_added -> dispatched_register_solution reports whenever the goal's distance_accum improved,
+// planning_visitors.hpp:108-116,178-182); the adaptor registers the goal's final best cost.
+template <typename FreeSpace>
+class hip_rrtstar_planner : public hip_planner_base<FreeSpace> {
+  typedef hip_planner_base<FreeSpace> base;
+
+ public:
+  typedef typename base::point_type point_type;
+  typedef typename base::graph_type graph_type;
+  hip_rrtstar_planner(const std::shared_ptr<FreeSpace>& world, std::size_t max_vertex_count, std::size_t progress_interval = 0,
+                      double steer_progress_tol = 0.1, double connection_tol = 0.05, bool branch_and_bound = false)
+      : base(world, max_vertex_count, progress_interval, steer_progress_tol, connection_tol, 1.0), m_bnb(branch_and_bound) {}
+  rkh_rrtstar_stats last_stats = rkh_rrtstar_stats();
+
+  template <typename Query>
+  void solve_planning_query(Query& aQuery) {
+    const point_type& start = aQuery.get_start_position();
+    const point_type& goal = aQuery.get_goal_position();
+    const std::size_t D = start.size();
+    rkh_rrt_params prm;
+    detail::fill_params(prm, start, goal, global_rng_fresh_seed(), this->m_max_vertex_count, aQuery.max_num_results,
+                        this->m_steer_progress_tol, this->m_connection_tol);
+    std::shared_ptr<rkh_rrtstar> pl = create(prm, static_cast<const FreeSpace*>(nullptr));
+    if (m_bnb) check(rkh_rrtstar_set_branch_and_bound(pl.get(), 1));
+    rkh_rrtstar_stats st = rkh_rrtstar_stats();
+    check(rkh_rrtstar_solve(pl.get(), -1, &st));
+    const std::size_t nv = std::size_t(st.num_vertices);
+    std::vector<double> pos(nv * D), dist(nv);
+    std::vector<uint32_t> pred(nv);
+    check(rkh_rrtstar_get_graph(pl.get(), 0, pos.data(), pred.data(), dist.data(), nullptr));
+    graph_type& g = this->m_graph;
+    g = graph_type();
+    g.v.resize(nv);
+    for (std::size_t v = 0; v < nv; ++v) {
+      typename graph_type::vertex_bundled& b = g.v[v];
+      b.position = point_type(pos.begin() + v * D, pos.begin() + (v + 1) * D);
+      b.predecessor = (pred[v] == 0xFFFFFFFFu || v == 0) ? graph_type::null_vertex() : std::size_t(pred[v]);
+      b.distance_accum = dist[v];
+      b.weight = b.predecessor == graph_type::null_vertex() ? 0.0 : dist[v] - dist[b.predecessor];
+      b.density = 0.0;
+    }
+    this->m_reported = 0;
+    this->report_progress_upto(nv);
+    if (nv > 1 && g.v[1].predecessor != graph_type::null_vertex() && aQuery.keep_going()) {
+      if (aQuery.register_solution(std::size_t(0), std::size_t(1), 0.0, g) && this->solution_reporter)
+        this->solution_reporter(*this->m_space, g, g.v[1].distance_accum);
+    }
+    last_stats = st;
+    detail::consume_global_draws(uint64_t(st.samples) * D);
+  }
+
+ private:
+  std::shared_ptr<rkh_rrtstar> create(const rkh_rrt_params& prm, const kte_dynamic_free_space<point_type>*) {
+    rkh_rrtstar* raw = nullptr;
+    check(rkh_rrtstar_create_batch(this->m_space->scene().get(), &this->m_space->dyn_space(), &prm, 1, &raw));
+    return std::shared_ptr<rkh_rrtstar>(raw, [](rkh_rrtstar* p) { (void)rkh_rrtstar_destroy(p); });
+  }
+  std::shared_ptr<rkh_rrtstar> create(const rkh_rrt_params& prm, const manip_quasi_static_free_space<point_type>*) {
+    rkh_rrtstar* raw = nullptr;
+    check(rkh_rrtstar_create_qs_batch(this->m_space->scene().get(), &this->m_space->qs_space(), &prm, 1, &raw));
+    return std::shared_ptr<rkh_rrtstar>(raw, [](rkh_rrtstar* p) { (void)rkh_rrtstar_destroy(p); });
+  }
+  bool m_bnb;
+};
+
+// ---- prm_planner (prm_path_planner.tpp:131-365).  As in the reference (density_plan_visitor; rkh.h), the roadmap grows to
+// max_vertex_count and no solution is registered: the query's records stay as they were; the roadmap is motion_graph().
+template <typename FreeSpace>
+class hip_prm_planner : public hip_planner_base<FreeSpace> {
+  typedef hip_planner_base<FreeSpace> base;
+
+ public:
+  typedef typename base::point_type point_type;
+  typedef typename base::graph_type graph_type;
+  hip_prm_planner(const std::shared_ptr<FreeSpace>& world, std::size_t max_vertex_count, std::size_t progress_interval = 0,
+                  double steer_progress_tol = 0.1, double connection_tol = 0.05, double sampling_radius = 1.0)
+      : base(world, max_vertex_count, progress_interval, steer_progress_tol, connection_tol, sampling_radius) {}
+  rkh_prm_stats last_stats = rkh_prm_stats();
+
+  template <typename Query>
+  void solve_planning_query(Query& aQuery) {
+    const point_type& start = aQuery.get_start_position();
+    const point_type& goal = aQuery.get_goal_position();
+    const std::size_t D = start.size();
+    rkh_prm_params prm = rkh_prm_params();
+    detail::fill_params(prm.base, start, goal, global_rng_fresh_seed(), this->m_max_vertex_count, aQuery.max_num_results,
+                        this->m_steer_progress_tol, this->m_connection_tol);
+    prm.sampling_radius = this->m_sampling_radius;
+    prm.expand_probability = 0.2;  // fixed by the reference's generate_prm call (prm_path_planner.tpp:250-253)
+    std::shared_ptr<rkh_prm> pl = create(prm, static_cast<const FreeSpace*>(nullptr));
+    rkh_prm_stats st = rkh_prm_stats();
+    check(rkh_prm_solve(pl.get(), -1, &st));
+    const std::size_t nv = std::size_t(st.num_vertices), ne = std::size_t(st.num_edges);
+    std::vector<double> pos(nv * D), ew(ne ? ne : 1), dens(nv);
+    std::vector<uint32_t> eu(ne ? ne : 1), ev(ne ? ne : 1);
+    check(rkh_prm_get_graph(pl.get(), 0, pos.data(), eu.data(), ev.data(), ew.data(), dens.data(), nullptr, nullptr, nullptr));
+    graph_type& g = this->m_graph;
+    g = graph_type();
+    g.v.resize(nv);
+    for (std::size_t v = 0; v < nv; ++v) {
+      typename graph_type::vertex_bundled& b = g.v[v];
+      b.position = point_type(pos.begin() + v * D, pos.begin() + (v + 1) * D);
+      b.predecessor = graph_type::null_vertex();
+      b.distance_accum = std::numeric_limits<double>::infinity();
+      b.weight = 0.0;
+      b.density = dens[v];
+    }
+    for (std::size_t e = 0; e < ne; ++e) {
+      g.edges.push_back(std::make_pair(std::size_t(eu[e]), std::size_t(ev[e])));
+      g.edge_weight.push_back(ew[e]);
+    }
+    this->m_reported = 0;
+    this->report_progress_upto(nv);
+    last_stats = st;
+    // PRM's draws depend on its control flow (rejection samples, expansion coin, random walks): the planner reports them
+    detail::consume_global_draws(uint64_t(st.samples));
+  }
+
+ private:
+  std::shared_ptr<rkh_prm> create(const rkh_prm_params& prm, const kte_dynamic_free_space<point_type>*) {
+    rkh_prm* raw = nullptr;
+    check(rkh_prm_create_batch(this->m_space->scene().get(), &this->m_space->dyn_space(), &prm, 1, &raw));
+    return std::shared_ptr<rkh_prm>(raw, [](rkh_prm* p) { (void)rkh_prm_destroy(p); });
+  }
+  std::shared_ptr<rkh_prm> create(const rkh_prm_params& prm, const manip_quasi_static_free_space<point_type>*) {
+    rkh_prm* raw = nullptr;
+    check(rkh_prm_create_qs_batch(this->m_space->scene().get(), &this->m_space->qs_space(), &prm, 1, &raw));
+    return std::shared_ptr<rkh_prm>(raw, [](rkh_prm* p) { (void)rkh_prm_destroy(p); });
+  }
+};
+
+// ---- rrt_planner with BIDIRECTIONAL_PLANNING, the reference's default flag (rrt_path_planner.hpp:114 ->
+// generate_bidirectional_rrt, rr_tree.hpp:256-317) over the quasi-static space (a reversible space).  Two trees; a
+// joining vertex registers a solution through query.register_joining_point (planning_visitors.hpp:223-231).  The best
+// registered solution is handed over after the run: graph1() / graph2() are the trees, the joining pair are the last
+// vertices of the two solution paths.
+template <typename FreeSpace>
+class hip_birrt_planner : public hip_planner_base<FreeSpace> {
+  typedef hip_planner_base<FreeSpace> base;
+
+ public:
+  typedef typename base::point_type point_type;
+  typedef typename base::graph_type graph_type;
+  hip_birrt_planner(const std::shared_ptr<FreeSpace>& world, std::size_t max_vertex_count, std::size_t progress_interval = 0,
+                    double steer_progress_tol = 0.1, double connection_tol = 0.05)
+      : base(world, max_vertex_count, progress_interval, steer_progress_tol, connection_tol, 1.0) {}
+  rkh_birrt_stats last_stats = rkh_birrt_stats();
+  const graph_type& graph1() const { return this->m_graph; }
+  const graph_type& graph2() const { return m_graph2; }
+
+  template <typename Query>
+  void solve_planning_query(Query& aQuery) {
+    const point_type& start = aQuery.get_start_position();
+    const point_type& goal = aQuery.get_goal_position();
+    const std::size_t D = start.size();
+    rkh_rrt_params prm;
+    detail::fill_params(prm, start, goal, global_rng_fresh_seed(), this->m_max_vertex_count, aQuery.max_num_results,
+                        this->m_steer_progress_tol, this->m_connection_tol);
+    rkh_birrt* raw = nullptr;
+    check(rkh_birrt_create_qs_batch(this->m_space->scene().get(), &this->m_space->qs_space(), &prm, 1, &raw));
+    std::shared_ptr<rkh_birrt> pl(raw, [](rkh_birrt* p) { (void)rkh_birrt_destroy(p); });
+    rkh_birrt_stats st = rkh_birrt_stats();
+    check(rkh_birrt_solve(pl.get(), -1, &st));
+    const std::size_t n1 = std::size_t(st.num_vertices_1), n2 = std::size_t(st.num_vertices_2);
+    std::vector<double> p1(n1 * D), p2(n2 * D);
+    std::vector<uint32_t> par1(n1), par2(n2);
+    check(rkh_birrt_get_trees(pl.get(), 0, p1.data(), par1.data(), p2.data(), par2.data(), nullptr, nullptr));
+    fill_tree(this->m_graph, p1, par1, D);
+    fill_tree(m_graph2, p2, par2, D);
+    this->m_reported = 0;
+    this->report_progress_upto(n1 + n2);
+    std::vector<uint32_t> s1(n1), s2(n2);
+    uint32_t m1 = 0, m2 = 0;
+    double cost = std::numeric_limits<double>::infinity();
+    check(rkh_birrt_get_solution(pl.get(), 0, s1.data(), &m1, s2.data(), &m2, uint32_t(std::max(n1, n2)), &cost));
+    if (m1 && m2 && aQuery.keep_going()) {
+      const std::size_t j1 = s1[m1 - 1], j2 = s2[m2 - 1];
+      const double join = cost - this->m_graph.v[j1].distance_accum - m_graph2.v[j2].distance_accum;
+      if (aQuery.register_joining_point(std::size_t(0), std::size_t(0), j1, j2, join, this->m_graph, m_graph2) &&
+          this->solution_reporter)
+        this->solution_reporter(*this->m_space, this->m_graph, cost);
+    }
+    last_stats = st;
+    detail::consume_global_draws(uint64_t(st.samples) * D);
+  }
+
+ private:
+  void fill_tree(graph_type& g, const std::vector<double>& pos, const std::vector<uint32_t>& parent, std::size_t D) {
+    g = graph_type();
+    g.v.resize(parent.size());
+    for (std::size_t v = 0; v < parent.size(); ++v) {
+      typename graph_type::vertex_bundled& b = g.v[v];
+      b.position = point_type(pos.begin() + v * D, pos.begin() + (v + 1) * D);
+      b.predecessor = parent[v] == 0xFFFFFFFFu ? graph_type::null_vertex() : std::size_t(parent[v]);
+      b.weight = b.predecessor == graph_type::null_vertex()
+                     ? 0.0
+                     : this->m_space->get_super_space().distance(g.v[b.predecessor].position, b.position);
+      b.distance_accum = b.predecessor == graph_type::null_vertex() ? 0.0 : g.v[b.predecessor].distance_accum + b.weight;
+      b.density = 0.0;
+    }
+  }
+  graph_type m_graph2;
 };
 
 }  // namespace rkh

@@ -557,3 +557,24 @@ def make_random_chain(n, seed=1, n_obstacles=12):
     return Scenario(name=f"chain{n}", ops=ops, base=base, shapes=shapes, dyn=dyn, n_dof=n, n_frames=2 * n + 1,
                     start=np.zeros(2 * n), goal=goal, meta={"lower": np.full(n, -np.pi), "upper": np.full(n, np.pi),
                                                             "min_interval": 0.05})
+
+
+def make_hidim(D, min_interval=0.05):
+    """The reference's own planner scenario (R/ctrl/path_planning/test_hidim_planners.cpp:151,195-212): the unit hypercube
+    [0, 1]^D without obstacles, start 0.05 * 1, goal 0.95 * 1.  Here it is a quasi-static space over a D-joint chain that
+    carries no shapes and an environment without shapes -- ZERO proximity pairs, so is_free is the hyperbox test alone
+    and every edge walk reaches its target.  Not modelled: no_obstacle_space clips an edge at max_edge_length = 0.2
+    sqrt(D) (no_obstacle_space.hpp:178-184) and reports targets beyond it as unreachable; manip_quasi_static_env, the
+    space on the hot path, has no such cap, so edges run to their samples.  The reference holds no expected output for
+    the scenario (it pins nothing); the tests compare the device with the oracle on it."""
+    axes = [((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0))[j % 3] for j in range(D)]
+    offsets = [(0.0, 0.0, 0.1)] * D
+    ops = serial_chain_ops(axes, offsets, [1.0] * D, [(0.01, 0, 0, 0.01, 0, 0.01)] * D, [0.1] * D)
+    base = T.ChainBase()
+    base.pose = T.make_pose()
+    dyn = T.DynSpace()
+    dyn.n_dof = D
+    return Scenario(name=f"hidim{D}", ops=ops, base=base, shapes=[], dyn=dyn, n_dof=D, n_frames=2 * D + 1,
+                    start=np.full(D, 0.05), goal=np.full(D, 0.95),
+                    meta={"lower": np.zeros(D), "upper": np.ones(D), "min_interval": min_interval,
+                          "max_edge_length": 0.2 * np.sqrt(D)})

@@ -1462,3 +1462,59 @@ def test_stepwise_and_two_phase_steer_launches_do_not_change_results(L, ctx, ora
     for key in ("parent", "nn_seq", "accept"):
         assert np.array_equal(t[key], rt[key]), key
     assert np.allclose(t["pos"], rt["pos"], rtol=STATE_RTOL, atol=1e-12)
+
+
+@pytest.mark.parametrize("D", [3, 6, 12])
+def test_reference_hidim_scenario_without_obstacles(L, ctx, oracle, D):
+    """The reference's own planner scenario (test_hidim_planners.cpp:151,195-212: unit hypercube, no obstacles, start
+    0.05 * 1 -> goal 0.95 * 1; see scenarios.make_hidim for what is and is not modelled).  The scene has ZERO proximity
+    pairs: rkh_scene_create must accept it, rkh_min_distance reports +inf (findMinimumDistance over an empty finder list
+    leaves the initial infinity, proxy_query_model.cpp:376-402), every edge walk reaches its target, and RRT, RRT*, PRM and
+    the bidirectional RRT build the oracle's graphs.  The reference holds no expected output for the scenario: the pin is
+    the oracle (parity unpinned beyond it)."""
+    hd = scenarios.make_hidim(D)
+    sc, osc = L.Scene(ctx, hd), oracle.OracleScene(hd)
+    assert sc.num_pairs == 0
+    lo, hi, mi = hd.meta["lower"], hd.meta["upper"], hd.meta["min_interval"]
+    rng = np.random.default_rng(D)
+    x = np.zeros((64, 2 * D))
+    x[:, 0::2] = rng.uniform(0, 1, size=(64, D))
+    d = sc.min_distance(x)
+    assert np.all(np.isinf(d)) and np.all(d > 0) and np.array_equal(d, osc.min_distance(x))
+    a, b = rng.uniform(0, 1, size=(32, D)), rng.uniform(0, 1, size=(32, D))
+    out, steps = sc.move_position_toward(lo, hi, mi, a, b)
+    assert np.array_equal(out, b)  # nothing in the way: the walk ends on its target (the exact-end shortcut of fraction 1)
+    qs = L.make_qs_space(D, lo, hi, mi)
+    prm = hd.rrt_params(seed=2, max_vertices=1500)
+    rc, ro, rt = osc.rrt_qs(lo, hi, mi, prm)
+    pl = L.RrtPlanner(sc, prm, qs=qs)
+    st, tree = pl.solve_planning_query(), pl.tree()
+    assert (st.num_vertices, st.iterations, st.edges_checked, st.num_solutions) == (ro.num_vertices, ro.iterations,
+                                                                                  ro.edges_checked, ro.num_solutions)
+    for k in ("nn_seq", "accept", "parent", "pos", "goal_dist"):
+        assert np.array_equal(tree[k], rt[k]), k
+    assert st.num_solutions > 0 and st.best_cost == ro.best_cost
+    assert np.all(tree["accept"] == 1)  # every sample is reached: an expansion is rejected by obstacles only
+    pl.close()
+    prm = hd.rrt_params(seed=3, max_vertices=600)
+    rc, ro, rg = osc.rrtstar_qs(lo, hi, mi, prm)
+    ps = L.RrtStarPlanner(sc, prm, qs)
+    st, g = ps.solve_planning_query(), ps.graph()
+    assert (st.num_vertices, st.loop_iterations, st.rewires, st.edges_checked) == (ro.num_vertices, ro.loop_iterations,
+                                                                                   ro.rewires, ro.edges_checked)
+    for k in ("pred", "pos", "dist"):
+        assert np.array_equal(g[k], rg[k]), k
+    # in free space the optimal cost to every vertex is its straight-line distance from the start, and RRT* may only
+    # approach it from above
+    conn = np.flatnonzero(g["pred"] != 0xFFFFFFFF)
+    assert np.all(g["dist"][conn] >= np.sqrt(((g["pos"][conn] - g["pos"][0]) ** 2).sum(axis=1)) * (1 - 1e-12))
+    ps.close()
+    pp = hd.prm_params(seed=4, max_vertices=400, sampling_radius=0.2 * np.sqrt(D))
+    rc, ro, rg = osc.prm_qs(lo, hi, mi, pp)
+    pr = L.PrmPlanner(sc, pp, qs)
+    st, g = pr.solve_planning_query(), pr.graph()
+    assert (st.num_vertices, st.num_edges, st.num_components, st.loop_iterations) == (ro.num_vertices, ro.num_edges,
+                                                                                     ro.num_components, ro.loop_iterations)
+    for k in ("pos", "edge_u", "edge_v", "edge_w", "density"):
+        assert np.array_equal(g[k], rg[k]), k
+    pr.close()

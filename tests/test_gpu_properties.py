@@ -176,3 +176,31 @@ def test_rrtstar_and_prm_invariants_at_scale(L, ctx):
         assert np.all((g["density"] >= 0.0) & (g["density"] <= 1.0))
         k = np.bincount(g["kind"], minlength=3)
         assert k.sum() == st.loop_iterations and k[0] + k[1] == n - 2
+
+
+def test_c5_workload_on_one_rank():
+    """BASELINE config C5 (independent RRT* seeds sharded over the ranks, best-cost all-reduce) through its own entry,
+    `bench.py --workload c5`, on the one rank a test box has: the child process plans two seeds to 40 000 vertices each
+    (the configuration's 1 M per seed is about four minutes of sequential RRT* iterations per problem; 200 000 vertices
+    ran in 50 s, profiles/r03_c5_one_rank_200k.log) and must print the bench contract's JSON line with consistent
+    counters.  The N > 1 control path (seed blocks per rank, reductions) is covered on the CPU by
+    tests/test_distributed.py; no 8-GPU node is available to the builder."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    nv, P = 40000, 2
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c5", "--gpus", "1", "--c5-vertices",
+                          str(nv), "--c5-problems", str(P), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 1 and rec["scaling"] == "weak" and rec["dtype"] == "f64"
+    assert "C5" in rec["config"]["workload"] and rec["config"]["vertices_per_seed"] == nv and rec["config"]["seeds_per_gpu"] == P
+    secs = rec["ms_per_step"] * 1e-3
+    # every seed grew its tree to the budget (+ start and goal vertices); an RRT* iteration adds at most one vertex
+    assert abs(rec["vertices_per_s"] * secs - P * (nv + 2)) < 1.0
+    assert rec["value"] * secs >= P * nv and rec["edges_collision_checked_per_s"] > rec["value"]
+    assert rec["best_solution_cost"] is not None and 0.0 < rec["best_solution_cost"] < 50.0
