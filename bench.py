@@ -214,6 +214,25 @@ def nn_published_config(lib, ctx, events, n_rows=25000, D=6, B=1000, reps=20):
     return out
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota (a GPU box hands one GPU's
+    share of the host, 16 CPUs, to a job whose affinity mask still lists every core of the machine)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def host_description():
     model = "unknown"
     try:
@@ -223,67 +242,87 @@ def host_description():
                 break
     except OSError:
         pass
-    return {"cpu_model": model, "nproc": os.cpu_count(), "usable_cores": len(os.sched_getaffinity(0))}
+    return {"cpu_model": model, "nproc": os.cpu_count(), "affinity_cores": len(os.sched_getaffinity(0)),
+            "cgroup_cpu_quota": cpu_quota()}
 
 
-def cpu_baseline(scn, max_vertices, seconds_target=15.0):
-    """Oracle (kind 'port': the reference cannot be built here) on a bounded sample."""
+def cpu_baseline(lib, scene, scn, max_vertices, seconds_target=18.0):
+    """Oracle (kind 'port': the reference cannot be built here) on a bounded sample of the SAME workload,
+    measured at the benchmark's own tree sizes.  The sequential planner's cost per iteration grows with the tree (linear-
+    search NN), so a from-scratch run of a few seconds only sees a young tree.  Instead one tree is grown to max_vertices
+    on the GPU (same world, its own seed) and the oracle's loop is started on prefixes of it (orc_rrt_dyn_warm: a prefix
+    of an RRT is the tree at that moment): the rate at 1 k, 10 k, 30 k and max_vertices vertices is MEASURED, the rate of
+    a whole run to max_vertices is their integral sum(dn / rate(n)) -- `value`."""
     import oracle_lib
 
     osc = oracle_lib.OracleScene(scn, fast=True)
-    nv = 1500
-    rc, out, _ = osc.rrt_dyn(scn.rrt_params(seed=1, max_vertices=nv))
-    rate = out.num_vertices / out.seconds
-    nv2 = int(min(20000, max(nv, rate * seconds_target)))
-    rc, out, _ = osc.rrt_dyn(scn.rrt_params(seed=1, max_vertices=nv2))
-    assert rc == 0
-    # The CPU's cost per iteration grows with the tree (linear-search NN): the rate it would hold at the bench's final
-    # tree size, from the measured steer cost per iteration of the sample and the measured linear search at that size.
-    rng = np.random.default_rng(1)
-    pts = rng.uniform(-2, 2, size=(max_vertices, 12))
-    q = rng.uniform(-2, 2, size=(16, 12))
-    oracle_lib.nn1(q[:2], pts[:1000], fast=True)
-    t0 = time.perf_counter()
-    oracle_lib.nn1(q, pts, fast=True)
-    t_nn_full = (time.perf_counter() - t0) / len(q)
-    t0 = time.perf_counter()
-    oracle_lib.nn1(q, pts[: nv2 // 2], fast=True)
-    t_nn_half = (time.perf_counter() - t0) / len(q)  # the sample's average tree size
-    it_per_v = out.iterations / max(1, out.num_vertices - 1)
-    t_iter_sample = out.seconds / out.iterations
-    t_iter_full = max(t_iter_sample - t_nn_half, 0.0) + t_nn_full
-    return {"value": (out.num_vertices - 1) / out.seconds, "unit": "valid node expansions/s", "cores": 1, "kind": "port",
-            "edges_checked_per_s": out.edges_checked / out.seconds,
-            "sample": f"seed 1 of the same C2 world, first {nv2} vertices ({out.iterations} iterations, "
-                      f"{out.seconds:.1f} s), oracle -O3 -march=native, 1 thread (ReaK is single-threaded)",
-            "rate_at_final_tree_size": {"value": 1.0 / (it_per_v * t_iter_full), "unit": "valid node expansions/s",
-                                        "tree_size": max_vertices,
-                                        "how": "steer cost per iteration of the sample + the oracle's linear search timed "
-                                               f"at {max_vertices} vertices ({t_nn_full * 1e6:.0f} us per query); an estimate, "
-                                               "the sample itself stops earlier"},
+    pl = lib.RrtPlanner(scene, scn.rrt_params(seed=424242, max_vertices=max_vertices))
+    pl.solve_planning_query()
+    pos = pl.tree()["pos"]
+    pl.close()
+    sizes = [n for n in (1000, 10000, 30000) if n < max_vertices] + [max_vertices]
+    share = seconds_target / len(sizes)
+    pts, it_tot, sec_tot, edges_tot = [], 0, 0.0, 0
+    for n in sizes:
+        prm = scn.rrt_params(seed=7 + n, max_vertices=2 ** 31 - 1)
+        rc, o = osc.rrt_dyn_warm(prm, pos[1:n + 1], 64)  # calibration: cost of an iteration at this size
+        iters = int(max(64, min(20000, share / max(o.seconds / 64, 1e-6))))
+        rc, o = osc.rrt_dyn_warm(prm, pos[1:n + 1], iters)
+        assert rc == 0
+        added = int(o.num_vertices) - 1 - n
+        pts.append({"tree_size": n, "iterations": int(o.iterations), "vertices_added": added, "seconds": float(o.seconds),
+                    "expansions_per_s": added / o.seconds, "edges_checked_per_s": int(o.edges_checked) / o.seconds})
+        it_tot += int(o.iterations)
+        sec_tot += float(o.seconds)
+        edges_tot += int(o.edges_checked)
+    # time of a whole run: trapezoid of 1 / rate over the tree size (rate falls monotonically with n)
+    ns = [0] + [p_["tree_size"] for p_ in pts]
+    inv = [1.0 / pts[0]["expansions_per_s"]] + [1.0 / p_["expansions_per_s"] for p_ in pts]
+    t_run = sum(0.5 * (inv[i] + inv[i + 1]) * (ns[i + 1] - ns[i]) for i in range(len(ns) - 1))
+    whole = max_vertices / t_run
+    at_full = pts[-1]
+    return {"value": whole, "unit": "valid node expansions/s", "cores": 1, "kind": "port",
+            "edges_checked_per_s": whole * at_full["edges_checked_per_s"] / at_full["expansions_per_s"],
+            "at_final_tree_size": at_full, "by_tree_size": pts,
+            "sample": f"the same C2 world; the oracle's sequential RRT loop (-O3 -march=native, 1 thread: ReaK is single-"
+                      f"threaded) MEASURED on a tree of {max_vertices} vertices ({at_full['iterations']} iterations, "
+                      f"{at_full['seconds']:.1f} s) and on its prefixes of {', '.join(str(n) for n in sizes[:-1])} vertices "
+                      f"({it_tot} iterations, {sec_tot:.1f} s in all); value = {max_vertices} / sum(dn / rate(n)), the rate of a "
+                      f"whole run to {max_vertices} vertices",
             "host": host_description(),
-            "note": "ReaK planner, CPU restatement (reference binary unavailable: needs Boost + BGL-Extra)"}
+            "note": "ReaK planner, CPU restatement (reference binary unavailable: needs Boost + BGL-Extra); the tree the "
+                    "loop starts on was grown by the GPU planner on another seed of the same world"}
 
 
-def cpu_baseline_all_cores(nv, max_workers=16):
-    """The same bounded sample on every host core the process may use: one oracle process per core, independent seeds
-    (the reference's own evaluation mode is independent Monte-Carlo runs, planner_exec_engines.hpp:139-206)."""
+def cpu_baseline_all_cores(lib, scene, scn, max_vertices, seconds_target=15.0):
+    """The final-tree-size leg of cpu_baseline on every CPU the job may use (cgroup quota): one oracle process per CPU,
+    independent seeds (the reference's own evaluation mode is independent Monte-Carlo runs,
+    planner_exec_engines.hpp:139-206), each on the same 100 000-vertex tree."""
     import subprocess
+    import tempfile
 
-    cores = min(len(os.sched_getaffinity(0)), max_workers)
+    cores = cpu_quota()
+    pl = lib.RrtPlanner(scene, scn.rrt_params(seed=424243, max_vertices=max_vertices))
+    pl.solve_planning_query()
+    pos = pl.tree()["pos"]
+    pl.close()
     worker = os.path.join(ROOT, "tests", "cpu_worker.py")
-    t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, worker, str(1 + i), str(nv)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-             for i in range(cores)]
-    outs = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in procs]
-    wall = time.perf_counter() - t0
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        path = os.path.join(td, "tree.npy")
+        np.save(path, pos[1:max_vertices + 1])
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, worker, str(1 + i), path, str(seconds_target)], stdout=subprocess.PIPE,
+                                  stderr=subprocess.DEVNULL) for i in range(cores)]
+        outs = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in procs]
+        wall = time.perf_counter() - t0
     busy = max(o["seconds"] for o in outs)
-    nodes = sum(o["vertices"] - 1 for o in outs)
+    nodes = sum(o["vertices_added"] for o in outs)
     return {"value": nodes / busy, "unit": "valid node expansions/s", "cores": cores, "kind": "port",
             "edges_checked_per_s": sum(o["edges"] for o in outs) / busy,
-            "sample": f"{cores} processes x seeds 1..{cores}, first {nv} vertices each ({busy:.1f} s planner time, "
-                      f"{wall:.1f} s wall incl. process start), oracle -O3 -march=native",
-            "host": host_description()}
+            "sample": f"{cores} processes (the job's CPU quota; affinity mask {len(os.sched_getaffinity(0))} of "
+                      f"{os.cpu_count()} cores) x seeds 1..{cores}, each the sequential loop on a tree of {max_vertices} "
+                      f"vertices ({busy:.1f} s planner time, {wall:.1f} s wall incl. process start), oracle -O3 -march=native",
+            "tree_size": max_vertices, "host": host_description()}
 
 
 def feval_ops(scn, samples=32):
@@ -722,9 +761,8 @@ def main():
             out["c3_rrtstar"] = c3_rrtstar_rate(lib, ctx, events)
             out["c4_prm_meshes"] = c4_prm_rate(lib, ctx)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scn, args.max_vertices)
-            nv_used = int(out["cpu_baseline"]["sample"].split("first ")[1].split(" ")[0])
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(nv_used)
+            out["cpu_baseline"] = cpu_baseline(lib, scene, scn, args.max_vertices)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(lib, scene, scn, args.max_vertices)
             out["nn_published_config"] = nn_published_config(lib, ctx, events)
         print(json.dumps(out))
     if dist is not None:

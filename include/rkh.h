@@ -46,6 +46,19 @@ typedef struct rkh_birrt rkh_birrt;     /* batched bidirectional-RRT driver over
 
 const char* rkh_last_error(void);
 const char* rkh_version(void);
+/* ABI number of this header: bumped whenever a public POD changes size or meaning (2: rkh_rrtstar_stats gained
+ * pruned / skipped, rkh_qs_space gained speed_limits; 3: this handshake).  A binding checks once after loading:
+ *   rkh_abi_check(RKH_ABI_VERSION, sizeof(rkh_dyn_space), sizeof(rkh_qs_space), ...) == RKH_OK
+ * (RKH_ABI_CHECK() below spells the call out). */
+#define RKH_ABI_VERSION 3u
+uint32_t rkh_abi_version(void);
+rkh_status rkh_abi_check(uint32_t abi_version, size_t sizeof_dyn_space, size_t sizeof_qs_space, size_t sizeof_rrt_params,
+                         size_t sizeof_prm_params, size_t sizeof_planner_stats, size_t sizeof_rrtstar_stats,
+                         size_t sizeof_prm_stats, size_t sizeof_birrt_stats, size_t sizeof_shape, size_t sizeof_kte_op);
+#define RKH_ABI_CHECK()                                                                                                  \
+  rkh_abi_check(RKH_ABI_VERSION, sizeof(rkh_dyn_space), sizeof(rkh_qs_space), sizeof(rkh_rrt_params), sizeof(rkh_prm_params), \
+                sizeof(rkh_planner_stats), sizeof(rkh_rrtstar_stats), sizeof(rkh_prm_stats), sizeof(rkh_birrt_stats),   \
+                sizeof(rkh_shape), sizeof(rkh_kte_op))
 
 /* ---- context ------------------------------------------------------------------------------ */
 rkh_status rkh_ctx_create(int device, rkh_ctx** out);

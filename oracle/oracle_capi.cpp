@@ -377,6 +377,21 @@ int orc_rrt_dyn(void* h, const rkh_dyn_space* P, const rkh_rrt_params* prm, int6
   fill_out(g_last, sp.env.n_pair_tests, secs, out);
   return 0;
 }
+// timing only: the same loop started on a tree of warm_n given vertices (generate_rrt's warm_pos)
+int orc_rrt_dyn_warm(void* h, const rkh_dyn_space* P, const rkh_rrt_params* prm, const double* warm_pos, uint64_t warm_n,
+                     int64_t max_iterations, OrcRrtOut* out) {
+  Scene* s = static_cast<Scene*>(h);
+  DynSpace sp = make_dyn(s, P);
+  auto t0 = std::chrono::steady_clock::now();
+  try {
+    generate_rrt(sp, *prm, long(max_iterations), g_last, warm_pos, std::size_t(warm_n));
+  } catch (const singularity_error&) {
+    return -3;
+  }
+  double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  fill_out(g_last, sp.env.n_pair_tests, secs, out);
+  return 0;
+}
 void orc_set_qs_speed_limits(const double* speed, int n) {
   g_qs_speed.assign(speed, speed + (speed ? n : 0));
 }

@@ -364,8 +364,12 @@ struct RrtResult {
   SpaceCounters cnt;
 };
 
+// warm_pos / warm_n (timing only, bench.py's cpu_baseline): the loop starts on a tree that already holds these vertices
+// (rows 1 .. warm_n of a tree grown elsewhere on the same world, hung under the root), so that the cost of an iteration
+// AT that tree size can be measured without growing the tree on the CPU first.
 template <typename Space>
-void generate_rrt(Space& space, const rkh_rrt_params& prm, long max_iterations, RrtResult& res) {
+void generate_rrt(Space& space, const rkh_rrt_params& prm, long max_iterations, RrtResult& res,
+                  const double* warm_pos = nullptr, std::size_t warm_n = 0) {
   const int D = space.D;
   GlobalRng rng(prm.seed);
   res = RrtResult();
@@ -374,7 +378,12 @@ void generate_rrt(Space& space, const rkh_rrt_params& prm, long max_iterations, 
   // create_root(vp_start): rrt_path_planner.tpp:131-133 (no vertex_added call => not counted)
   res.pos.insert(res.pos.end(), start.begin(), start.end());
   res.parent.push_back(0xFFFFFFFFu);
-  unsigned long m_iteration_count = 0;  // sample_based_planner::m_iteration_count
+  if (warm_pos && warm_n) {
+    res.pos.insert(res.pos.end(), warm_pos, warm_pos + warm_n * std::size_t(D));
+    res.parent.insert(res.parent.end(), warm_n, 0u);
+    res.goal_dist.insert(res.goal_dist.end(), warm_n, std::numeric_limits<double>::infinity());
+  }
+  unsigned long m_iteration_count = (unsigned long)warm_n;  // sample_based_planner::m_iteration_count
   // keep_going: planning_visitors.hpp:203-205 -> motion_planner_base.hpp:374 && p2p_planning_query.hpp:121-123
   auto keep_going = [&]() {
     return (m_iteration_count < prm.max_vertices) && (prm.max_results > (unsigned long)res.num_solutions);

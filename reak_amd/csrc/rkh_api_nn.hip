@@ -18,8 +18,29 @@ using namespace rkh;
 
 extern "C" {
 
+#define RKH_STR2(x) #x
+#define RKH_STR(x) RKH_STR2(x)
 const char* rkh_last_error(void) { return rkh::g_err.c_str(); }
-const char* rkh_version(void) { return "reak_amd/librkh 0.1 (gfx950)"; }
+const char* rkh_version(void) { return "reak_amd/librkh 0.3 (gfx950), ABI " RKH_STR(RKH_ABI_VERSION); }
+uint32_t rkh_abi_version(void) { return RKH_ABI_VERSION; }
+/* The caller's view of the public PODs against the library's: a caller built against another header is refused here
+ * instead of having a stats array overrun or garbage read as speed limits. */
+rkh_status rkh_abi_check(uint32_t abi_version, size_t sizeof_dyn_space, size_t sizeof_qs_space, size_t sizeof_rrt_params,
+                         size_t sizeof_prm_params, size_t sizeof_planner_stats, size_t sizeof_rrtstar_stats,
+                         size_t sizeof_prm_stats, size_t sizeof_birrt_stats, size_t sizeof_shape, size_t sizeof_kte_op) {
+  const bool ok = abi_version == RKH_ABI_VERSION && sizeof_dyn_space == sizeof(rkh_dyn_space) &&
+                  sizeof_qs_space == sizeof(rkh_qs_space) && sizeof_rrt_params == sizeof(rkh_rrt_params) &&
+                  sizeof_prm_params == sizeof(rkh_prm_params) && sizeof_planner_stats == sizeof(rkh_planner_stats) &&
+                  sizeof_rrtstar_stats == sizeof(rkh_rrtstar_stats) && sizeof_prm_stats == sizeof(rkh_prm_stats) &&
+                  sizeof_birrt_stats == sizeof(rkh_birrt_stats) && sizeof_shape == sizeof(rkh_shape) &&
+                  sizeof_kte_op == sizeof(rkh_kte_op);
+  if (!ok) {
+    rkh::set_error("rkh_abi_check: the caller was built against another version of rkh.h / rkh_types.h (ABI " +
+                   std::to_string(abi_version) + " vs " + std::to_string(RKH_ABI_VERSION) + ", or a struct size differs)");
+    return RKH_ERR_BAD_ARG;
+  }
+  return RKH_OK;
+}
 
 rkh_status rkh_ctx_create(int device, rkh_ctx** out) {
   if (!out) return RKH_ERR_BAD_ARG;
@@ -293,6 +314,10 @@ rkh_status rkh_nn_fill_uniform(rkh_nn* nn, uint64_t n, uint64_t seed) {
   if (st != RKH_OK) return st;
   RKH_HIP(hipStreamSynchronize(nn->ctx->stream));
   nn->n = n;
+  // every row was rewritten: no tombstone survives (a stale host copy would report a wrong live size and make a later
+  // rkh_nn_remove of such an index a silent no-op)
+  nn->removed.assign(nn->removed.size(), 0);
+  nn->n_removed = 0;
   if (nn->max_abs_coord < 1.0) nn->max_abs_coord = 1.0;  // the unit hypercube
   return RKH_OK;
 }

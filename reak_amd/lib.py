@@ -64,8 +64,17 @@ class PlannerStats(C.Structure):
     ]
 
 
+ABI_VERSION = 3  # RKH_ABI_VERSION of include/rkh.h this binding mirrors
+
+
+def abi_sizes():
+    """sizeof of the mirrored PODs, in the argument order of rkh_abi_check."""
+    return [C.sizeof(T.DynSpace), C.sizeof(T.QsSpace), C.sizeof(T.RrtParams), C.sizeof(T.PrmParams), C.sizeof(PlannerStats),
+            C.sizeof(RrtStarStats), C.sizeof(PrmStats), C.sizeof(BiRrtStats), C.sizeof(T.Shape), C.sizeof(T.KteOp)]
+
+
 EXPORTS = [
-    "rkh_last_error", "rkh_version", "rkh_ctx_create", "rkh_ctx_destroy", "rkh_ctx_synchronize", "rkh_ctx_stream",
+    "rkh_last_error", "rkh_version", "rkh_abi_version", "rkh_abi_check", "rkh_ctx_create", "rkh_ctx_destroy", "rkh_ctx_synchronize", "rkh_ctx_stream",
     "rkh_nn_create", "rkh_nn_destroy", "rkh_nn_clear", "rkh_nn_size", "rkh_nn_remove", "rkh_nn_live_size", "rkh_nn_append", "rkh_nn_query1",
     "rkh_nn_queryk", "rkh_nn_query1_async", "rkh_nn_queryk_async", "rkh_nn_fill_uniform", "rkh_nn_kernel_name",
     "rkh_nn_set_coord_bound",
@@ -170,6 +179,12 @@ def load():
     lib.rkh_planner_steer_profile.argtypes = [vp, dp, C.POINTER(C.c_uint64)]
     lib.rkh_planner_steer_steps.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.rkh_diag_nn_mirror_query.argtypes = [vp, dp, C.c_uint64, C.c_int, dp, C.c_uint32, C.c_double, C.POINTER(C.c_uint32), dp]
+    lib.rkh_abi_version.restype = C.c_uint32
+    lib.rkh_abi_check.argtypes = [C.c_uint32] + [C.c_size_t] * 10
+    # the handshake of include/rkh.h: this binding's struct mirrors against the library's (RKH_ABI_CHECK)
+    st = lib.rkh_abi_check(ABI_VERSION, *abi_sizes())
+    if st != 0:
+        raise RkhError(st, lib.rkh_last_error().decode())
     _lib = lib
     return lib
 

@@ -112,6 +112,7 @@ int main(int argc, char** argv) {
   std::fclose(f);
   if (!ok) return 2;
   try {
+    rkh::check(RKH_ABI_CHECK());  // this translation unit's rkh.h against the library's
     const std::size_t D = 2 * std::size_t(sp.n_dof);
     auto ctx = rkh::make_context(0);
     auto scene = rkh::make_scene(ctx, ops.data(), n_ops, base, shapes.data(), n_shapes);

@@ -124,6 +124,8 @@ def load(fast=False):
     lib.orc_rk4_step.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), dp, dp, C.c_int, d, dp]
     lib.orc_steer.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), dp, dp, C.c_int, d, dp, u32p, dp]
     lib.orc_rrt_dyn.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtOut)]
+    lib.orc_rrt_dyn_warm.argtypes = [C.c_void_p, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), C.POINTER(C.c_double),
+                                     C.c_uint64, C.c_int64, C.POINTER(RrtOut)]
     lib.orc_rrt_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtOut)]
     lib.orc_qs_move.argtypes = [C.c_void_p, C.c_int, dp, dp, d, dp, dp, C.c_int, d, dp, u32p]
     lib.orc_rrtstar_qs.argtypes = [C.c_void_p, C.c_int, dp, dp, d, C.POINTER(T.RrtParams), C.c_int64, C.POINTER(RrtStarOut)]
@@ -217,6 +219,15 @@ class OracleScene:
         out = RrtOut()
         rc = self.lib.orc_rrt_dyn(self.h, C.byref(self.scn.dyn), C.byref(prm), int(max_iterations), C.byref(out))
         return rc, out, self._copy_rrt(out, self.D)
+
+    def rrt_dyn_warm(self, prm, warm_pos, iterations):
+        """Timing only (bench.py cpu_baseline): `iterations` loop iterations of the sequential RRT started on a tree that
+        already holds the vertices warm_pos [n][D] (besides the root): the CPU's cost per iteration AT that tree size."""
+        warm_pos = np.ascontiguousarray(warm_pos, dtype=np.float64)
+        out = RrtOut()
+        rc = self.lib.orc_rrt_dyn_warm(self.h, C.byref(self.scn.dyn), C.byref(prm), T.dptr(warm_pos), warm_pos.shape[0],
+                                       int(iterations), C.byref(out))
+        return rc, out
 
     def rrt_qs(self, lower, upper, min_interval, prm, max_iterations=-1):
         lower = np.ascontiguousarray(lower, dtype=np.float64)

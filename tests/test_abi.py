@@ -63,8 +63,25 @@ def test_pod_layouts_match_the_header():
 
 
 def test_version_and_error_strings(lib):
-    assert b"gfx950" in lib.rkh_version()
+    assert b"gfx950" in lib.rkh_version() and b"ABI 3" in lib.rkh_version()
     assert isinstance(lib.rkh_last_error(), bytes)
+
+
+def test_abi_handshake(lib):
+    """rkh_abi_check refuses a caller whose view of the public PODs differs from the library's (another header version):
+    the Python binding passes with its mirrors, a wrong ABI number or one wrong struct size is an error, not a later
+    overrun of a stats array."""
+    from reak_amd import lib as L
+
+    assert lib.rkh_abi_version() == L.ABI_VERSION == 3
+    sizes = L.abi_sizes()
+    assert lib.rkh_abi_check(L.ABI_VERSION, *sizes) == 0
+    assert lib.rkh_abi_check(L.ABI_VERSION - 1, *sizes) != 0
+    for k in range(len(sizes)):
+        bad = list(sizes)
+        bad[k] -= 8
+        assert lib.rkh_abi_check(L.ABI_VERSION, *bad) != 0, k
+    assert b"another version" in lib.rkh_last_error()
 
 
 def test_no_gpu_fails_loudly(lib):

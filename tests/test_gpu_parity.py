@@ -1518,3 +1518,44 @@ def test_reference_hidim_scenario_without_obstacles(L, ctx, oracle, D):
     for k in ("pos", "edge_u", "edge_v", "edge_w", "density"):
         assert np.array_equal(g[k], rg[k]), k
     pr.close()
+
+
+def test_planning_in_an_obstacle_course_read_from_an_rkx_archive(L, ctx, oracle, tmp_path):
+    """f4: the `window_crossing` course of R/examples/misc/build_X8_obstacle_courses.cpp:69-152 (floor plane + eight wall
+    boxes) goes through a ReaK XML archive (reak_amd/rkx.py), is read back, and becomes the environment of the 6-R arm
+    standing in front of the window wall; the whole scene then round-trips through write_scene / read_scene and
+    the COPY is what the device and the oracle plan in: distances, edge walks and the quasi-static RRT must agree.  (The
+    reference flies a vehicle in SE(3) through the course; the hot path's spaces are joint spaces, so a manipulator
+    stands in.  The reference holds no expected outputs for the course: parity unpinned beyond the oracle.)"""
+    from reak_amd import rkx
+    from reak_amd import types as T
+
+    path = tmp_path / "window_crossing.rkx"
+    path.write_text(rkx.write_obstacle_course("window_crossing"))
+    shapes, names, start_pos, end_pos = rkx.read_obstacle_course(path.read_text())
+    assert names[0] == "floor" and len(shapes) == 9
+    c3 = scenarios.make_c3(world_seed=1)
+    arm = [s for s in c3.shapes if s.anchor >= 0]
+    c3.shapes = arm + shapes
+    c3.base.pose = T.make_pose((2.55, 4.5, -2.5))  # 0.35 m in front of wall2 (x = 2.9 .. 3.1), inside the course's volume (z < 0)
+    scene_file = tmp_path / "arm_in_course.rkx"
+    scene_file.write_text(rkx.write_scene(c3))
+    scn = rkx.read_scene(scene_file.read_text(), c3)
+    sc, osc = L.Scene(ctx, scn), oracle.OracleScene(scn)
+    lo, hi, mi = scn.meta["lower"], scn.meta["upper"], scn.meta["min_interval"]
+    rng = np.random.default_rng(5)
+    x = np.zeros((512, 12))
+    x[:, 0::2] = rng.uniform(-np.pi, np.pi, size=(512, 6))
+    d, rd = sc.min_distance(x), osc.min_distance(x)
+    assert np.allclose(d, rd, rtol=0, atol=1e-12) and np.array_equal(d < 0, rd < 0)
+    assert 0.05 < np.mean(d < 0) < 0.95  # the walls matter: some configurations collide, some are free
+    prm = scn.rrt_params(seed=3, max_vertices=1200)
+    rc, ro, rt = osc.rrt_qs(lo, hi, mi, prm)
+    pl = L.RrtPlanner(sc, prm, qs=L.make_qs_space(6, lo, hi, mi))
+    st, tree = pl.solve_planning_query(), pl.tree()
+    assert (st.num_vertices, st.iterations, st.edges_checked, st.num_solutions) == (ro.num_vertices, ro.iterations,
+                                                                                  ro.edges_checked, ro.num_solutions)
+    for k in ("nn_seq", "accept", "parent", "pos"):
+        assert np.array_equal(tree[k], rt[k]), k
+    assert 0 < np.sum(tree["accept"] == 0)  # walls stop some expansions
+    pl.close()
