@@ -638,10 +638,10 @@ struct GraphBatch {
     RKH_HIP(hipMemcpyAsync(d_cmd, h_cmd, cmd_bytes, hipMemcpyHostToDevice, s));
     if (any_append) hipLaunchKernelGGL(gb_prep_kernel, dim3(P), dim3(64), 0, s, d_aux, DP);
     if (any_stage_a) {
-      rkh_status st = dynamic ? launch_propagate(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs,
+      rkh_status st = dynamic ? launch_propagate(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs_verdict,
                                                  dyn, EdgeIO(), kGbStageA, nullptr, 0, 64, d_ioa, nullptr, P)
                               : launch_edge_check(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs,
-                                                  scene->n_pairs, qs, EdgeIO(), kGbStageA, nullptr, 0, d_ioa, nullptr, P);
+                                                  scene->n_pairs_verdict, qs, EdgeIO(), kGbStageA, nullptr, 0, d_ioa, nullptr, P);
       if (st != RKH_OK) return st;
       hipLaunchKernelGGL(gb_select_kernel, dim3(P), dim3(64), 0, s, d_aux, D, DP);
     }
@@ -652,10 +652,10 @@ struct GraphBatch {
     hipLaunchKernelGGL(gb_list_kernel, dim3(P), dim3(64), 0, s, d_aux);
     if (any_edges) {
       // one wave per edge: a step holds at most 2 k candidates per problem, far from filling the two-lanes mappings
-      rkh_status st = dynamic ? launch_propagate(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs,
+      rkh_status st = dynamic ? launch_propagate(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs_verdict,
                                                  dyn, EdgeIO(), emax, nullptr, 0, 64, d_io, nullptr, P)
                               : launch_edge_check(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs,
-                                                  scene->n_pairs, qs, EdgeIO(), emax, nullptr, 0, d_io, nullptr, P);
+                                                  scene->n_pairs_verdict, qs, EdgeIO(), emax, nullptr, 0, d_io, nullptr, P);
       if (st != RKH_OK) return st;
     }
     RKH_HIP(hipMemcpyAsync(h_res, d_res, res_stride * P, hipMemcpyDeviceToHost, s));

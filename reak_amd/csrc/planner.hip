@@ -671,10 +671,10 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
                         bool compact = false) {
   if (p->quasi_static)
     return launch_edge_check(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                             p->scene->n_pairs, p->qs, EdgeIO(), grid_a, nullptr, grid_b, tab_a, tab_b, p->P);
+                             p->scene->n_pairs_verdict, p->qs, EdgeIO(), grid_a, nullptr, grid_b, tab_a, tab_b, p->P);
   if (p->lanes_per_edge != 0)
     return launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                            p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lanes_per_edge, tab_a, tab_b,
+                            p->scene->n_pairs_verdict, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lanes_per_edge, tab_a, tab_b,
                             p->P, p->d_lane_ws);
   // automatic: both mappings are launched; on the device each compares the round's edge count with the threshold and
   // the one that is not chosen exits at once.  Small rounds -> one wave per edge (latency), large -> 32 edges per wave.
@@ -688,7 +688,7 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
     gate_wave.n_segments = 2 * p->P;
   }
   rkh_status st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                                   p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, 64, tab_a, tab_b, p->P,
+                                   p->scene->n_pairs_verdict, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, 64, tab_a, tab_b, p->P,
                                    nullptr, gate_wave);
   if (st != RKH_OK) return st;
   // The two-lanes mapping in two phases when the round is a regular one: half of the edges of a round end within a few
@@ -701,7 +701,7 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
                      tab_a == p->d_io_steer && tab_b == p->d_io_probe;
   if (!split)
     return launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                            p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b,
+                            p->scene->n_pairs_verdict, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b,
                             p->P, p->d_lane_ws, gate_lane);
   // ... when the round is large enough; below that the extra launches and tails cost more than the idle lanes (64
   // problems x 100 000 with the two-phase launch: 2.94 against 3.04 M expansions/s): such rounds take one launch
@@ -715,7 +715,7 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
     whole.steps_exec = p->d_steps_exec;
     if (edges_ub >= whole.lo) {  // (a round that cannot reach the gate needs no launch at all)
       st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                            p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b,
+                            p->scene->n_pairs_verdict, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b,
                             p->P, p->d_lane_ws, whole);
       if (st != RKH_OK) return st;
     }
@@ -732,7 +732,7 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
   KernelGate g1 = gate_lane;
   g1.step1 = p->steer_split;
   st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                        p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b, p->P,
+                        p->scene->n_pairs_verdict, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, tab_a, tab_b, p->P,
                         p->d_lane_ws, g1);
   if (st != RKH_OK) return st;
   hipLaunchKernelGGL(phase_compact_kernel, dim3(p->P, 2), dim3(256), 0, p->stream, p->d_io_steer, p->d_io_probe,
@@ -745,7 +745,7 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
   g2.n_segments = 2 * p->P;
   g2.step0 = p->steer_split;
   return launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                          p->scene->n_pairs, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, p->d_io_steer2,
+                          p->scene->n_pairs_verdict, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, p->lane_variant, p->d_io_steer2,
                           p->d_io_probe2, p->P, p->d_lane_ws, g2);
 }
 

@@ -644,19 +644,42 @@ struct SmemLayout {
   static size_t bytes(int n_env) { return block_bytes + size_t(n_env) * sizeof(ShapeDev); }
 };
 
+struct WaveArgs {
+  const SceneDev* sc;
+  const PairDev* pairs;
+  int n_pairs;
+  DynDev dyn;
+  EdgeIO io_a, io_b;
+  const EdgeIO* tab_a;
+  const EdgeIO* tab_b;
+  uint32_t grid_a;
+  KernelGate gate;
+};
+typedef const __attribute__((address_space(4))) WaveArgs* WaveArgP;
+RKH_DI WaveArgP wave_args() {
+  WaveArgP a = (WaveArgP)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(a));
+  return a;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Kernel: steer edges.  Two edge groups per launch (planner: this round's steer candidates + the
 // previous round's goal probes); 64/GL edges per wave.
+// GL = 64 (one wave per edge, the latency mapping: rounds of fewer waves than the chip has SIMDs) may use the whole
+// register file of its SIMD; four edges per wave (GL = 16) is the throughput form and keeps two waves per SIMD.
 template <int N, int GL>
-__global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __restrict__ sc,
-                                                           const PairDev* __restrict__ pairs, int n_pairs, DynDev dyn,
-                                                           EdgeIO io_a, EdgeIO io_b, const EdgeIO* __restrict__ tab_a,
-                                                           const EdgeIO* __restrict__ tab_b, uint32_t grid_a,
-                                                           KernelGate gate) {
+__global__ __launch_bounds__(64, GL == 64 ? 1 : 2) void propagate_kernel(WaveArgs) {
+  // Every argument is read through the kernarg segment pointer at its point of use (by-value parameters are loaded in the
+  // entry block and stay live in scalar registers; once those run out they are spilled into vector-register lanes, and
+  // the EdgeIO / DynDev / KernelGate copies alone are ~170 dwords: the kernel then needed 256 registers + 185 spilled)
+  const SceneDev* __restrict__ sc = wave_args()->sc;
+  const PairDev* __restrict__ pairs = wave_args()->pairs;
+  const int n_pairs = wave_args()->n_pairs;
+  const uint32_t grid_a = wave_args()->grid_a;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (gate.count) {  // the planner's per-round choice between the kernel mappings
-    const uint32_t c = *gate.count;
-    if (c < gate.lo || c >= gate.hi) return;
+  if (wave_args()->gate.count) {  // the planner's per-round choice between the kernel mappings
+    const uint32_t c = *wave_args()->gate.count;
+    if (c < wave_args()->gate.lo || c >= wave_args()->gate.hi) return;
   }
   constexpr int G = 64 / GL;
   BlockLds<N, GL>& lds = *reinterpret_cast<BlockLds<N, GL>*>(smem_raw);
@@ -665,21 +688,26 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
   bool group_b = blockIdx.x >= grid_a;
   uint32_t problem = blockIdx.y;
   uint32_t blk = group_b ? blockIdx.x - grid_a : blockIdx.x;
-  if (gate.wave_base) {  // compact mapping (one edge per wave): block L of a 1-D grid takes working edge L
+  if (wave_args()->gate.wave_base) {  // compact mapping (one edge per wave): block L of a 1-D grid takes working edge L
     const uint32_t L = blockIdx.x;
-    if (L >= gate.wave_base[gate.n_segments]) return;
-    uint32_t lo = 0, hi = gate.n_segments;
+    if (L >= wave_args()->gate.wave_base[wave_args()->gate.n_segments]) return;
+    uint32_t lo = 0, hi = wave_args()->gate.n_segments;
     while (hi - lo > 1) {
       const uint32_t mid = (lo + hi) >> 1;
-      if (gate.wave_base[mid] <= L) lo = mid;
+      if (wave_args()->gate.wave_base[mid] <= L) lo = mid;
       else hi = mid;
     }
     problem = lo >> 1;
     group_b = (lo & 1u) != 0u;
-    blk = L - gate.wave_base[lo];
+    blk = L - wave_args()->gate.wave_base[lo];
   }
-  const EdgeIO io = tab_a ? (group_b ? tab_b[problem] : tab_a[problem]) : (group_b ? io_b : io_a);
-  const uint32_t B = io.d_B ? *io.d_B : io.B;
+  auto edge_io = [&]() -> const EdgeIO* {
+    WaveArgP A = wave_args();
+    if (A->tab_a) return (group_b ? A->tab_b : A->tab_a) + problem;
+    const char* ka = (const char*)(const void*)A;
+    return (const EdgeIO*)(ka + (group_b ? offsetof(WaveArgs, io_b) : offsetof(WaveArgs, io_a)));
+  };
+  const uint32_t B = edge_io()->d_B ? *edge_io()->d_B : edge_io()->B;
   const int lane = threadIdx.x;
   const int g = lane / GL, gl = lane % GL, gb = g * GL;
   const uint32_t e0 = blk * G;
@@ -691,15 +719,15 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
   stage_chain<N>(sc, lds.joints, lds.base, lane);
   stage_env(sc, env_lds, lane);
   GroupWs<N>& ws = lds.g[g];
-  const uint32_t si = io.src_idx ? io.src_idx[ec] : ((io.d_src_first ? *io.d_src_first : 0u) + ec);
-  const uint64_t trow = io.tgt_idx ? uint64_t(io.tgt_idx[ec]) : (io.d_tgt_off ? uint64_t(*io.d_tgt_off) : 0ull) + ec;
-  const double a_d = (gl < D) ? io.src[uint64_t(si) * io.src_stride + gl] : 0.0;
-  const double b_d = (gl < D) ? io.tgt[trow * io.tgt_stride + gl] : 0.0;
-  const double lo = (gl < D) ? dyn.lower[gl] : 0.0;
-  const double hi = (gl < D) ? dyn.upper[gl] : 0.0;
+  const uint32_t si = edge_io()->src_idx ? edge_io()->src_idx[ec] : ((edge_io()->d_src_first ? *edge_io()->d_src_first : 0u) + ec);
+  const uint64_t trow = edge_io()->tgt_idx ? uint64_t(edge_io()->tgt_idx[ec]) : (edge_io()->d_tgt_off ? uint64_t(*edge_io()->d_tgt_off) : 0ull) + ec;
+  const double a_d = (gl < D) ? edge_io()->src[uint64_t(si) * edge_io()->src_stride + gl] : 0.0;
+  const double b_d = (gl < D) ? edge_io()->tgt[trow * edge_io()->tgt_stride + gl] : 0.0;
+  const double lo = (gl < D) ? wave_args()->dyn.lower[gl] : 0.0;
+  const double hi = (gl < D) ? wave_args()->dyn.upper[gl] : 0.0;
   if (gl < D) ws.b[gl] = b_d;
-  double* __restrict__ record = edge_valid ? io.record : nullptr;
-  const int record_stride = io.record_stride;
+  double* __restrict__ record = edge_valid ? edge_io()->record : nullptr;
+  const int record_stride = edge_io()->record_stride;
   __syncthreads();
   const CPack<N> cp = load_cpack<N>(lds.joints, lane);
 
@@ -712,17 +740,17 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
 
   // steps of this edge: the launch's schedule, or (EdgeIO::frac) the edge's own travel fraction cut with the comparison
   // of the steer loop, current_time < fraction * (steps_per_edge * dt), current_time accumulated step by step
-  int n_steps = dyn.n_steps;
-  if (io.frac) {
-    const double T_goal = io.frac[ec] * dyn.full_time;
+  int n_steps = wave_args()->dyn.n_steps;
+  if (edge_io()->frac) {
+    const double T_goal = edge_io()->frac[ec] * wave_args()->dyn.full_time;
     double current_time = 0.0;
     n_steps = 0;
     while (current_time < T_goal && n_steps < kMaxSteps) {
-      current_time += dyn.dt;
+      current_time += wave_args()->dyn.dt;
       ++n_steps;
     }
   }
-  if (io.mode == EDGE_POINT) {  // is_free(target): bounds, then proximity; no propagation
+  if (edge_io()->mode == EDGE_POINT) {  // is_free(target): bounds, then proximity; no propagation
     n_steps = 0;
     x = b_d;
     bool oob = false;
@@ -737,22 +765,22 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
     __syncthreads();
     const double dmin = proximity_min<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true, !free_pt);
     if (dmin < 0.0) free_pt = false;
-    if (edge_valid && gl == 0) io.accept[e] = free_pt ? 1 : 0;
+    if (edge_valid && gl == 0) edge_io()->accept[e] = free_pt ? 1 : 0;
   }
 
   for (int k = 0; k < n_steps; ++k) {
     // distance(x_current, x_goal) > goal_proximity_threshold
     const double dist = group_norm<N>(ws, x - b_d, gl);
-    if (!(dist > dyn.goal_tol)) alive = false;
+    if (!(dist > wave_args()->dyn.goal_tol)) alive = false;
     if (!__any(alive)) break;
     if (alive) ++n_exec;
     // PD law, zero-order hold over the step
     if (gl < D) ws.x[gl] = x;
     __syncthreads();
     if (gl < N) {
-      double v = dyn.kp * (ws.b[2 * gl] - ws.x[2 * gl]) + dyn.kd * (ws.b[2 * gl + 1] - ws.x[2 * gl + 1]);
-      if (v > dyn.u_max) v = dyn.u_max;
-      else if (v < -dyn.u_max) v = -dyn.u_max;
+      double v = wave_args()->dyn.kp * (ws.b[2 * gl] - ws.x[2 * gl]) + wave_args()->dyn.kd * (ws.b[2 * gl + 1] - ws.x[2 * gl + 1]);
+      if (v > wave_args()->dyn.u_max) v = wave_args()->dyn.u_max;
+      else if (v < -wave_args()->dyn.u_max) v = -wave_args()->dyn.u_max;
       ws.u[gl] = v;
     }
     // runge_kutta4_integrate_impl (runge_kutta4_integrator_sys.hpp:53-97), time_step = dt.
@@ -760,12 +788,12 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
     // matter (the prime of :69 or the re-prime of :95, then :82, :86, :92); they are the stages of
     // a rolled loop here, which keeps a single copy of the dynamics in the instruction stream.
     // The re-prime after the last iteration is dead in the reference and is not evaluated.
-    const double h = dyn.dt;
+    const double h = wave_args()->dyn.dt;
     double xe = x;  // end_point
     {
       double w = xe, k1 = 0.0, k2 = 0.0, k3 = 0.0;
       bool sing_now = false;
-      const int n_evals = 4 * dyn.inner[k];
+      const int n_evals = 4 * wave_args()->dyn.inner[k];
 #pragma unroll 1
       for (int ev = 0; ev < n_evals; ++ev) {
         if (gl < D) ws.x[gl] = xe;
@@ -813,31 +841,31 @@ __global__ __launch_bounds__(64, 2) void propagate_kernel(const SceneDev* __rest
       if (record && gl < D) record[(uint64_t(e) * record_stride + n_free) * D + gl] = x;
     }
   }
-  if (singular && gl == 0 && edge_valid) atomicExch(io.err_flag, int(RKH_ERR_SINGULAR));
-  if (edge_valid && gl < D) io.x_out[uint64_t(e) * D + gl] = x;
-  if (edge_valid && gl == 0) io.steps_free[e] = n_free;
-  if (gate.steps_exec && edge_valid && gl == 0 && n_exec) atomicAdd(gate.steps_exec, (unsigned long long)n_exec);
-  if (io.mode != EDGE_PLAIN) {
+  if (singular && gl == 0 && edge_valid) atomicExch(edge_io()->err_flag, int(RKH_ERR_SINGULAR));
+  if (edge_valid && gl < D) edge_io()->x_out[uint64_t(e) * D + gl] = x;
+  if (edge_valid && gl == 0) edge_io()->steps_free[e] = n_free;
+  if (wave_args()->gate.steps_exec && edge_valid && gl == 0 && n_exec) atomicAdd(wave_args()->gate.steps_exec, (unsigned long long)n_exec);
+  if (edge_io()->mode != EDGE_PLAIN) {
     const double n_ar = group_norm<N>(ws, a_d - x, gl);
     const double n_ab = group_norm<N>(ws, a_d - b_d, gl);
     const double n_rb = group_norm<N>(ws, x - b_d, gl);
-    if (io.mode == EDGE_STEER_ACCEPT) {
+    if (edge_io()->mode == EDGE_STEER_ACCEPT) {
       // planning_visitor_base::steer_towards_position (planning_visitors.hpp:349-360)
       const double traveled = n_ar;
-      const double best_case = io.best_case ? io.best_case[ec] : n_ab;
-      const bool ok = (!isinf(traveled)) && (traveled < 2.0 * best_case) && (traveled > io.steer_tol * best_case);
-      if (edge_valid && gl == 0) io.accept[e] = ok ? 1 : 0;
-    } else if (io.mode == EDGE_CONNECT) {
+      const double best_case = edge_io()->best_case ? edge_io()->best_case[ec] : n_ab;
+      const bool ok = (!isinf(traveled)) && (traveled < 2.0 * best_case) && (traveled > edge_io()->steer_tol * best_case);
+      if (edge_valid && gl == 0) edge_io()->accept[e] = ok ? 1 : 0;
+    } else if (edge_io()->mode == EDGE_CONNECT) {
       // planning_visitor_base::can_be_connected (planning_visitors.hpp:385-395); steer_tol carries the connection tolerance
-      const bool ok = (!isinf(n_ar)) && (n_rb < io.steer_tol * n_ar);
-      if (edge_valid && gl == 0) io.accept[e] = ok ? 1 : 0;
-    } else if (io.mode == EDGE_WALK_ACCEPT) {
+      const bool ok = (!isinf(n_ar)) && (n_rb < edge_io()->steer_tol * n_ar);
+      if (edge_valid && gl == 0) edge_io()->accept[e] = ok ? 1 : 0;
+    } else if (edge_io()->mode == EDGE_WALK_ACCEPT) {
       // planning_visitor_base::random_walk (planning_visitors.hpp:418-421)
-      const bool ok = (!isinf(n_ar)) && (n_ar > io.steer_tol * io.best_case[ec]);
-      if (edge_valid && gl == 0) io.accept[e] = ok ? 1 : 0;
-    } else if (io.mode == EDGE_GOAL_PROBE) {
+      const bool ok = (!isinf(n_ar)) && (n_ar > edge_io()->steer_tol * edge_io()->best_case[ec]);
+      if (edge_valid && gl == 0) edge_io()->accept[e] = ok ? 1 : 0;
+    } else if (edge_io()->mode == EDGE_GOAL_PROBE) {
       // C_free distance used by the goal probe (MEAQR_topology.hpp:995-1003)
-      if (edge_valid && gl == 0) io.goal_dist[si - 1] = (n_ab * 0.05 > n_rb) ? n_ab : INFINITY;
+      if (edge_valid && gl == 0) edge_io()->goal_dist[si - 1] = (n_ab * 0.05 > n_rb) ? n_ab : INFINITY;
     }
   }
 }
@@ -1177,8 +1205,18 @@ static void launch_propagate_t(hipStream_t s, int n_env, const SceneDev* d_scene
     const uint64_t all = uint64_t(ga + gbk) * n_problems;
     grid = dim3(uint32_t(std::min<uint64_t>(all, gate.hi)), 1);
   }
-  hipLaunchKernelGGL((propagate_kernel<N, GL>), grid, dim3(64), (SmemLayout<N, GL>::bytes(n_env)),
-                     s, d_scene, d_pairs, n_pairs, dyn, io, io_b, tab_a, tab_b, ga, gate);
+  WaveArgs args;
+  args.sc = d_scene;
+  args.pairs = d_pairs;
+  args.n_pairs = n_pairs;
+  args.dyn = dyn;
+  args.io_a = io;
+  args.io_b = io_b;
+  args.tab_a = tab_a;
+  args.tab_b = tab_b;
+  args.grid_a = ga;
+  args.gate = gate;
+  hipLaunchKernelGGL((propagate_kernel<N, GL>), grid, dim3(64), (SmemLayout<N, GL>::bytes(n_env)), s, args);
 }
 
 // Steer `grid_edges` (+ `grid_b` of a second group) edges per problem.  Either the two EdgeIO are given by value

@@ -224,6 +224,7 @@ struct rkh_scene {
   double* d_mesh_verts = nullptr;  // vertex pool of the mesh shapes
   int* d_err = nullptr;
   int n_pairs = 0;
+  int n_pairs_verdict = -1;  // the first entries of d_pairs: pairs whose shapes can touch at all (verdict kernels scan these)
 };
 
 namespace rkh {

@@ -160,6 +160,7 @@ __global__ void gjk_pairs_kernel(const rkh_shape* __restrict__ a, const rkh_shap
 static rkh_status upload_scene(rkh_ctx* ctx, rkh_scene* sc, const std::vector<PairDev>& pairs, rkh_scene** out) {
   SceneDev& S = sc->host;
   sc->n_pairs = int(pairs.size());
+  if (sc->n_pairs_verdict < 0 || sc->n_pairs_verdict > sc->n_pairs) sc->n_pairs_verdict = sc->n_pairs;
   RKH_HIP(hipSetDevice(ctx->device));
   if (S.has_meshes && g_n_mesh_vertices > 0) {
     RKH_HIP(hipMalloc(&sc->d_mesh_verts, size_t(g_n_mesh_vertices) * 3 * sizeof(double)));
@@ -572,7 +573,18 @@ rkh_status rkh_scene_create_with_meshes(rkh_ctx* ctx, const rkh_kte_op* prog, in
       }
       pairs.push_back(p);
     }
-  std::stable_sort(pairs.begin(), pairs.end(), [](const PairDev& a, const PairDev& b) { return a.routine < b.routine; });
+  // Pairs a robot shape can never reach (environment shape beyond its static reach, SceneDev::robot_n_reach: the bounding
+  // spheres have a positive gap in EVERY configuration) go to the end of the list.  A verdict query ("is some pair closer
+  // than 0") skips every pair whose spheres do not overlap anyway, so the verdict kernels -- steer and edge walks -- only
+  // scan the first n_pairs_verdict entries (C2: 130 of 300); a distance query (rkh_min_distance) scans them all.
+  auto unreachable = [&](const PairDev& q) { return int(q.env) >= S.robot_n_reach[q.robot] ? 1 : 0; };
+  std::stable_sort(pairs.begin(), pairs.end(), [&](const PairDev& a, const PairDev& b) {
+    const int ua = unreachable(a), ub = unreachable(b);
+    return ua != ub ? ua < ub : a.routine < b.routine;
+  });
+  int n_verdict = 0;
+  for (const PairDev& q : pairs) n_verdict += unreachable(q) ? 0 : 1;
+  sc->n_pairs_verdict = n_verdict;
   return upload_scene(ctx, sc, pairs, out);
 }
 
@@ -728,7 +740,7 @@ rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const dou
   DevBuf dws;
   if (lanes == 1) RKH_HIP(hipMalloc(&dws.p, propagate_lanes_workspace_bytes(n, B, 0, 1)));
   if (lanes == 2) RKH_HIP(hipMalloc(&dws.p, propagate_pairs_workspace_bytes(n, B, 0, 1)));
-  st = launch_propagate(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, dyn, io, B, nullptr, 0,
+  st = launch_propagate(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs_verdict, dyn, io, B, nullptr, 0,
                         lanes, nullptr, nullptr, 1, dws.as<double>());
   if (st != RKH_OK) return st;
   RKH_HIP(hipMemcpyAsync(x_out, dxo.p, size_t(B) * D * 8, hipMemcpyDeviceToHost, s));
@@ -803,7 +815,7 @@ rkh_status rkh_edge_check(rkh_scene* scene, const double* lower, const double* u
   io.x_out = dxo.as<double>();
   io.steps_free = dnc.as<uint32_t>();
   io.err_flag = scene->d_err;
-  rkh_status st = launch_edge_check(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, qs, io, B);
+  rkh_status st = launch_edge_check(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs_verdict, qs, io, B);
   if (st != RKH_OK) return st;
   RKH_HIP(hipMemcpyAsync(out, dxo.p, size_t(B) * n * 8, hipMemcpyDeviceToHost, s));
   RKH_HIP(hipMemcpyAsync(n_checked, dnc.p, size_t(B) * 4, hipMemcpyDeviceToHost, s));
