@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void round_begin_kernel(const ProblemDev* __re
                                                            uint32_t* __restrict__ step_cnt) {
   __shared__ unsigned int s_waves;
   // live-edge counters of the step-wise steer launches of this round (launch_propagate_pair_steps)
-  if (step_cnt && threadIdx.x <= uint32_t(kMaxSteps)) step_cnt[threadIdx.x] = 0u;
+  if (step_cnt && threadIdx.x <= uint32_t(kMaxSteps) + 2u) step_cnt[threadIdx.x] = 0u;  // + the pool cursor (last word)
   // per-problem inputs of the batch formula, cached once (the bisection below evaluates it ten times per problem) and the
   // three count arrays, scanned in LDS; problems beyond the cache capacity fall back to global memory
   constexpr uint32_t kCache = 1024;
@@ -567,8 +567,14 @@ struct rkh_planner {
   bool nn_mirror = false;  // the NN search of a round runs over the trees' half-precision mirrors (nn_mirror.hip)
   double x_norm_bound = 0.0;  // >= |x| of every vertex (hyperbox corners, start states)
   int steer_stepwise = 1;
+  // RKH_STEER_POOL=1: the first steer launch of a round in its POOL form (lane pairs refill from the round's pool).  Same
+  // results (test_stepwise_and_two_phase_...), measured SLOWER than one LIST launch per step (512 x 100 000: 6.45 against
+  // 7.57 M expansions/s): the lanes stay full while the pool lasts, but an edge started when it runs dry can still need
+  // 20 steps of >= 115 us each, and that tail is no shorter than the one every step-wise round has anyway.
+  int steer_pool = 0;
+  uint32_t pool_waves = 0;  // its grid: the resident steer waves of the device (RKH_STEER_POOL_WAVES: tests)
   uint2* d_step_list[2] = {nullptr, nullptr};  // (segment, edge) of the edges alive after step k (k odd / even)
-  uint32_t* d_step_cnt = nullptr;              // [kMaxSteps + 1] live edges entering step k (cleared by round_begin_kernel)
+  uint32_t* d_step_cnt = nullptr;              // [kMaxSteps + 2] entries of the list launch k reads, + the pool cursor (cleared by round_begin_kernel)
   unsigned long long* d_steps_exec = nullptr;  // edge-steps integrated by the steer kernels (diagnostics: rkh_planner_steer_steps)
   uint32_t step_blocks_cap = 0;                // grid bound of a step launch (its blocks stride over the chunks beyond it)
   // rounds below this many edges keep the single whole-edge launch of the two-lanes mapping (RKH_STEER_SPLIT_MIN_EDGES;
@@ -725,9 +731,11 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
   if (stepwise) {
     const uint32_t epw = pair_kernel_edges_per_wave();
     const uint32_t blocks = uint32_t(std::min<uint64_t>((edges_ub + epw - 1) / epw, p->step_blocks_cap));
+    // (the pool cursor is the last word of the step counters: round_begin_kernel clears it with them)
     return launch_propagate_pair_steps(p->stream, p->n_dof, p->scene->d_scene, p->dyn, tab_a, tab_b, p->P,
                                        p->d_wave_base + (2 * p->P + 1), p->d_step_list[0], p->d_step_list[1],
-                                       p->d_step_cnt, p->d_lane_ws, blocks, gate_lane, p->d_steps_exec);
+                                       p->d_step_cnt, p->d_lane_ws, blocks, gate_lane, p->d_steps_exec,
+                                       p->steer_pool ? p->pool_waves : 0u, p->d_step_cnt + kMaxSteps + 2);
   }
   KernelGate g1 = gate_lane;
   g1.step1 = p->steer_split;
@@ -962,6 +970,7 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   if (const char* e = getenv("RKH_STEER_SPLIT")) p->steer_split = uint32_t(std::max(0, atoi(e)));
   if (const char* e = getenv("RKH_WAVE_FILL")) p->wave_fill = atof(e);
   if (const char* e = getenv("RKH_STEER_STEPWISE")) p->steer_stepwise = atoi(e);
+  if (const char* e = getenv("RKH_STEER_POOL")) p->steer_pool = atoi(e);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, scene->ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -973,6 +982,8 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   p->split_min_edges = (p->steer_stepwise ? p->wave_slots / 2 : p->wave_slots) * pair_kernel_edges_per_wave();
   if (const char* e = getenv("RKH_STEER_SPLIT_MIN_EDGES")) p->split_min_edges = uint32_t(std::max(0, atoi(e)));
   p->step_blocks_cap = 2 * p->wave_slots;
+  p->pool_waves = p->wave_slots;
+  if (const char* e = getenv("RKH_STEER_POOL_WAVES")) p->pool_waves = uint32_t(std::max(1, atoi(e)));
   // Many problems per planner: a round's candidates per problem stay within ONE query block of the mirror sweep (a
   // second block re-reads the whole tree for a handful of queries; 512 problems x 100 000: 7.45 -> 7.62 M expansions/s).
   // The batch rule only reaches the cap late in a run (1.25 sqrt(n) = 384 at n = 94 k) or through the wave fit's scale.
@@ -1194,8 +1205,8 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
     if (p->steer_stepwise && p->lane_variant == 2) {
       const size_t cap = size_t(P) * (2 * size_t(p->b_max) + kProbeGranule);
       for (auto& l : p->d_step_list) RKH_HIP(hipMalloc(&l, cap * sizeof(uint2)));
-      RKH_HIP(hipMalloc(&p->d_step_cnt, (kMaxSteps + 1) * sizeof(uint32_t)));
-      RKH_HIP(hipMemset(p->d_step_cnt, 0, (kMaxSteps + 1) * sizeof(uint32_t)));
+      RKH_HIP(hipMalloc(&p->d_step_cnt, (kMaxSteps + 3) * sizeof(uint32_t)));
+      RKH_HIP(hipMemset(p->d_step_cnt, 0, (kMaxSteps + 3) * sizeof(uint32_t)));
       // the step kernel's blocks take their RK4 workspace out of the two-lanes workspace
       if (propagate_pair_step_workspace_bytes(p->n_dof, p->step_blocks_cap) >
           propagate_pairs_workspace_bytes(p->n_dof, p->b_max, p->b_max, P))

@@ -24,6 +24,7 @@
 //   * the RK4 stage vectors are split between the edge's lanes (lane h updates the joints 2r + h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -906,18 +907,27 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_kernel(PairArgs) {
   }
 }
 
-// ---- one RK4 step per launch --------------------------------------------------------------------------------------
+// ---- live edges in full waves: the pool kernel and the one-step-per-launch kernel ------------------------------------
 // The same edge arithmetic as propagate_pair_kernel, cut at every step of the steer loop (MEAQR_topology.hpp:503-565:
 // integrate one step, test is_free, stop at the first state that is not free).  The edges of a planner round are
 // short-lived (tests/diag_edge_lifetimes.py: a candidate survives 9.7 of its 20 steps on average, 21 % end in the
-// first), and a wave that carries an edge through all of its steps keeps the lanes of the edges that ended idle: about
-// half of the lane-steps of propagate_pair_kernel do nothing.  Here a launch advances every LIVE edge of the round by
-// one step, 32 per wave whatever (problem, candidates | probes) segment they belong to, and appends the survivors to
-// the list the next launch reads (one atomic per wave; the order of a list is irrelevant -- edges are independent and
-// their results are indexed by the edge): every wave of every launch is full except the last one.  Between two steps
-// an edge lives in its x_out row (the state after its last free step), so the launch of step k reads 2 D doubles per
-// edge and writes D.  Step 0 has no list: entry i of the round is found by bisection in the exclusive prefix of the
-// segments' edge counts (round_begin_kernel's edge_base).
+// first), and a wave that carries 32 edges through all of their steps keeps the lanes of the edges that ended idle:
+// about half of the lane-steps of propagate_pair_kernel do nothing.  Two launch forms of ONE kernel keep the lanes busy:
+//   * POOL form (PairStepArgs::pool_cursor set; the first launch of a round): a resident set of waves; whenever an edge
+//     of a wave ends -- accept test / goal probe done -- its lane pair takes the next edge of the round from a global
+//     cursor (one atomic per wave and step; entry i of the round is found by bisection in the exclusive prefix of the
+//     segments' edge counts, round_begin_kernel's edge_base), so a wave holds edges at DIFFERENT steps side by side
+//     (the step index only selects dyn.inner[k], which must be uniform for this form).  No wave ever waits for
+//     another: nothing can hang.  Once the cursor is exhausted a wave that is less than half full hands its live edges
+//     -- (segment, edge, step); the state is in the edge's x_out row -- to the orphan list and leaves.
+//   * LIST form (the launches after it): every launch advances every entry of its input list by one step, 32 per wave
+//     whatever (problem, candidates | probes) segment they belong to, and appends the survivors to the next list;
+//     with `step` = kStepFromEntry each entry carries its own step (the orphans), otherwise all are at step `step`
+//     (the pure step-wise form, RKH_STEER_POOL=0: one launch per step, step 0 reading the implicit list).
+// Between two steps an edge lives in its x_out row (the state after its last free step).  The order of a list is
+// irrelevant: edges are independent and their results are indexed by the edge.
+constexpr uint32_t kStepFromEntry = 0xFFFFFFFFu;
+constexpr uint32_t kEntryStepShift = 20;  // list entry .x = segment | step << 20 (segment = 2 problem + group < 2^20)
 struct PairStepArgs {
   const SceneDev* sc;
   DynDev dyn;
@@ -927,12 +937,14 @@ struct PairStepArgs {
   KernelGate gate;            // count / lo / hi: the planner's per-round choice between the mappings
   const uint32_t* edge_base;  // [n_segments + 1] exclusive prefix of the edges per segment (segment 2p + g)
   uint32_t n_segments;
-  uint32_t step;              // k: this launch integrates step k of every live edge
-  const uint2* list_in;       // k > 0: (segment, edge) of the edges that are still alive
-  const uint32_t* cnt_in;     //        their number
-  uint2* list_out;            // survivors of this step
+  uint32_t step;              // LIST form: the step this launch integrates, or kStepFromEntry
+  const uint2* list_in;       // LIST form, step > 0: (segment | step << 20, edge) of the edges that are still alive
+  const uint32_t* cnt_in;     //            their number
+  uint2* list_out;            // survivors of this launch (LIST form) / orphans (POOL form)
   uint32_t* cnt_out;
   unsigned long long* steps_exec;  // optional: + the number of edge-steps this launch integrated
+  uint32_t* pool_cursor;      // POOL form: next unclaimed entry of the round (zero when the launch starts)
+  uint32_t min_live;          // POOL form: below this many live edges (cursor exhausted) a wave hands them over
 };
 typedef const __attribute__((address_space(4))) PairStepArgs* PairStepArgP;
 RKH_DI PairStepArgP pair_step_args() {
@@ -956,13 +968,15 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_step_kernel(PairStepArgs
   const int h = lane & 1;
   const int el = lane >> 1;
   uint32_t n_total;
+  bool pool;
   {
     PairStepArgP A = pair_step_args();
     if (A->gate.count) {
       const uint32_t c = *A->gate.count;
       if (c < A->gate.lo || c >= A->gate.hi) return;
     }
-    n_total = A->step == 0u ? A->edge_base[A->n_segments] : *A->cnt_in;
+    pool = A->pool_cursor != nullptr;
+    n_total = (pool || A->step == 0u) ? A->edge_base[A->n_segments] : *A->cnt_in;
   }
   if (blockIdx.x * uint32_t(kPairEdges) >= n_total) return;
   const ScenePtr sc = (ScenePtr)pair_step_args()->sc;
@@ -975,27 +989,86 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_step_kernel(PairStepArgs
   ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(pair_step_args()->ws_all + uint64_t(blockIdx.x) * uint64_t(W_::SLOTS * 64), 0,
                                               W_::SLOTS * 512, 0x00020000);
   ws.voff = lane * 8;
-  const int k = int(pair_step_args()->step);
+  const int n_steps = pair_step_args()->dyn.n_steps;
+  // entry i of the round's implicit list -> (segment, edge): bisection in the prefix of the segments' edge counts
+  auto implicit_entry = [&](uint32_t i, uint32_t* seg_out, uint32_t* ec_out) {
+    const uint32_t* eb = pair_step_args()->edge_base;
+    uint32_t lo = 0, hi = pair_step_args()->n_segments;  // eb[lo] <= i < eb[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (eb[mid] <= i) lo = mid;
+      else hi = mid;
+    }
+    *seg_out = lo;
+    *ec_out = i - eb[lo];
+  };
+  // the lane pair's edge (both lanes of a pair hold the same values)
+  bool has = false;       // POOL form: this lane pair carries an edge
+  uint32_t seg = 0, ec = 0;
+  int k = 0;
+  bool pool_empty = false;  // uniform
+  uint32_t chunk = blockIdx.x;
 #pragma unroll 1
-  for (uint32_t chunk = blockIdx.x; chunk * uint32_t(kPairEdges) < n_total; chunk += gridDim.x) {
-    const uint32_t i0 = chunk * uint32_t(kPairEdges);
-    const bool edge_valid = i0 + uint32_t(el) < n_total;
-    const uint32_t ic = edge_valid ? i0 + uint32_t(el) : i0;  // idle slots shadow the chunk's first edge, results discarded
-    uint32_t seg, ec;
-    if (k == 0) {
-      const uint32_t* eb = pair_step_args()->edge_base;
-      uint32_t lo = 0, hi = pair_step_args()->n_segments;  // eb[lo] <= ic < eb[hi]
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (eb[mid] <= ic) lo = mid;
-        else hi = mid;
+  for (;;) {
+    bool edge_valid;
+    if (pool) {
+      // ---- refill: lane pairs without an edge take the next entries of the round
+      const unsigned long long need = __ballot(!has && h == 0);
+      if (!pool_empty && need) {
+        PairStepArgP A = pair_step_args();
+        const uint32_t cnt = uint32_t(__popcll(need));
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(A->pool_cursor, cnt);
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+        const uint32_t mine = base + uint32_t(__popcll(need & ((1ull << (lane & 62)) - 1ull)));  // same on both lanes of a pair
+        if (!has && mine < n_total) {
+          implicit_entry(mine, &seg, &ec);
+          k = 0;
+          has = true;
+        }
+        if (base + cnt >= n_total) pool_empty = true;
       }
-      seg = lo;
-      ec = ic - eb[lo];
+      const unsigned long long livem = __ballot(has && h == 0);
+      if (!livem) break;
+      PairStepArgP A = pair_step_args();
+      if (pool_empty && A->list_out && uint32_t(__popcll(livem)) < A->min_live) {
+        // less than half full and nothing left to take: the live edges go on in full waves of the launches that follow
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(A->cnt_out, uint32_t(__popcll(livem)));
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+        if (has && h == 0)
+          A->list_out[base + uint32_t(__popcll(livem & ((1ull << lane) - 1ull)))] =
+              make_uint2(seg | (uint32_t(k) << kEntryStepShift), ec);
+        break;
+      }
+      edge_valid = has;
+      {  // idle lane pairs shadow the wave's first live edge, results discarded (uniform reads: every lane executes them)
+        const int src = __builtin_ctzll(livem);
+        const uint32_t s_seg = uint32_t(__builtin_amdgcn_readlane(int(seg), src));
+        const uint32_t s_ec = uint32_t(__builtin_amdgcn_readlane(int(ec), src));
+        const int s_k = __builtin_amdgcn_readlane(k, src);
+        if (!has) {
+          seg = s_seg;
+          ec = s_ec;
+          k = s_k;
+        }
+      }
     } else {
-      const uint2 ent = pair_step_args()->list_in[ic];
-      seg = ent.x;
-      ec = ent.y;
+      const uint32_t i0 = chunk * uint32_t(kPairEdges);
+      if (i0 >= n_total) break;
+      chunk += gridDim.x;
+      edge_valid = i0 + uint32_t(el) < n_total;
+      const uint32_t ic = edge_valid ? i0 + uint32_t(el) : i0;  // idle slots shadow the chunk's first edge
+      const uint32_t step = pair_step_args()->step;
+      if (step == 0u) {
+        implicit_entry(ic, &seg, &ec);
+        k = 0;
+      } else {
+        const uint2 ent = pair_step_args()->list_in[ic];
+        seg = ent.x & ((1u << kEntryStepShift) - 1u);
+        ec = ent.y;
+        k = step == kStepFromEntry ? int(ent.x >> kEntryStepShift) : int(step);
+      }
     }
     const bool writer = edge_valid && h == 0;  // the lane that exports the edge's results
     auto edge_io = [&]() -> const EdgeIO* {
@@ -1049,9 +1122,11 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_step_kernel(PairStepArgs
           RKH_LD(L_::U + j) = v;
         }
       }
-      // runge_kutta4_integrate_impl (runge_kutta4_integrator_sys.hpp:53-97), see propagate_pair_kernel
+      // runge_kutta4_integrate_impl (runge_kutta4_integrator_sys.hpp:53-97), see propagate_pair_kernel.  The POOL form
+      // and the orphans' launches mix steps in a wave: their inner loop counts are equal (checked by the host).
       bool sing_now = false;
-      const int n_evals = 4 * int(pair_step_args()->dyn.inner[k]);
+      const int k_uniform = __builtin_amdgcn_readfirstlane(k);
+      const int n_evals = 4 * int(pair_step_args()->dyn.inner[k_uniform]);
 #pragma unroll 1
       for (int ev = 0; ev < n_evals; ++ev) {
         double qdd[N];
@@ -1115,7 +1190,6 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_step_kernel(PairStepArgs
       }
     }
     // ---- the step's outcome: alive = step k was free (the edge stands at the new state), else it stays where it was
-    const int n_steps = pair_step_args()->dyn.n_steps;
     const bool go_on = alive && (k + 1 < n_steps);
     const bool finished = edge_valid && !go_on;
     const uint32_t n_free = uint32_t(k) + (alive ? 1u : 0u);
@@ -1133,14 +1207,16 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_step_kernel(PairStepArgs
         }
       }
     }
-    {  // survivors -> the next launch's list
+    if (!pool) {  // survivors -> the next launch's list
       const unsigned long long m = __ballot(go_on && h == 0);
       if (m) {
         PairStepArgP A = pair_step_args();
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(A->cnt_out, uint32_t(__popcll(m)));
         base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
-        if (go_on && h == 0) A->list_out[base + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = make_uint2(seg, ec);
+        if (go_on && h == 0)
+          A->list_out[base + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] =
+              make_uint2(seg | (uint32_t(k + 1) << kEntryStepShift), ec);
       }
     }
     if (__any(finished)) {  // accept test / goal probe of the edges that end here
@@ -1176,6 +1252,10 @@ __global__ __launch_bounds__(64, 2) void propagate_pair_step_kernel(PairStepArgs
         }
       }
     }
+    if (pool) {  // the lane pair's next state: on to the next step, or free for a new edge
+      if (edge_valid && go_on) ++k;
+      else has = false;
+    }
   }
 }
 
@@ -1183,18 +1263,36 @@ template <int N>
 static void launch_pair_step_t(hipStream_t s, const PairStepArgs& args, uint32_t blocks) {
   hipLaunchKernelGGL((propagate_pair_step_kernel<N>), dim3(blocks), dim3(64), 0, s, args);
 }
+static rkh_status launch_pair_step_n(hipStream_t s, int n_dof, const PairStepArgs& args, uint32_t blocks) {
+  switch (n_dof) {
+    case 1: launch_pair_step_t<1>(s, args, blocks); break;
+    case 2: launch_pair_step_t<2>(s, args, blocks); break;
+    case 3: launch_pair_step_t<3>(s, args, blocks); break;
+    case 4: launch_pair_step_t<4>(s, args, blocks); break;
+    case 6: launch_pair_step_t<6>(s, args, blocks); break;
+    case 7: launch_pair_step_t<7>(s, args, blocks); break;
+    default:
+      set_error("propagate: chains with this number of joints are not instantiated (1,2,3,4,6,7)");
+      return RKH_ERR_UNSUPPORTED;
+  }
+  return RKH_OK;
+}
 
 size_t propagate_pair_step_workspace_bytes(int n_dof, uint32_t blocks) {
   return size_t(blocks) * size_t(6 * ((n_dof + 1) / 2)) * 64 * sizeof(double);
 }
 
-// One launch per step k = 0 .. n_steps-1 over two ping-pong lists; d_cnt[k] = live edges entering step k (d_cnt[1 ..]
-// must be zero when step 0 starts: round_begin_kernel clears them).  `blocks` bounds the grid; a launch with more
-// live chunks than blocks strides over them.
+// The steer launches of a round over two ping-pong lists; d_cnt[k] = entries of the list launch k reads (d_cnt[1 ..
+// n_steps + 1] and *d_pool_cursor must be zero when the first launch starts: round_begin_kernel clears them).  `blocks` bounds the
+// grids; a LIST launch with more chunks than blocks strides over them.  pool_blocks > 0: the POOL form first (that many
+// resident waves), then n_steps - 1 LIST launches for the edges it handed over (each carries its own step; a launch
+// whose list is empty returns at once); pool_blocks == 0 (or a step schedule whose inner counts differ): one LIST
+// launch per step.
 rkh_status launch_propagate_pair_steps(hipStream_t s, int n_dof, const SceneDev* d_scene, const DynDev& dyn,
                                        const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems,
                                        const uint32_t* d_edge_base, uint2* d_list0, uint2* d_list1, uint32_t* d_cnt,
-                                       double* d_ws, uint32_t blocks, KernelGate gate, unsigned long long* d_steps_exec) {
+                                       double* d_ws, uint32_t blocks, KernelGate gate, unsigned long long* d_steps_exec,
+                                       uint32_t pool_blocks, uint32_t* d_pool_cursor) {
   if (blocks == 0 || n_problems == 0) return RKH_OK;
   PairStepArgs args;
   args.sc = d_scene;
@@ -1206,23 +1304,30 @@ rkh_status launch_propagate_pair_steps(hipStream_t s, int n_dof, const SceneDev*
   args.edge_base = d_edge_base;
   args.n_segments = 2 * n_problems;
   args.steps_exec = d_steps_exec;
-  for (int k = 0; k < dyn.n_steps; ++k) {
-    args.step = uint32_t(k);
+  args.pool_cursor = nullptr;
+  args.min_live = 0;
+  bool uniform_inner = true;
+  for (int k = 1; k < dyn.n_steps; ++k) uniform_inner = uniform_inner && dyn.inner[k] == dyn.inner[0];
+  const bool use_pool = pool_blocks > 0 && d_pool_cursor && uniform_inner && (2u * n_problems) < (1u << kEntryStepShift);
+  // (an edge the pool form hands over before its FIRST step still has n_steps steps to go: one launch more than steps)
+  const int n_launches = use_pool ? dyn.n_steps + 1 : dyn.n_steps;
+  for (int k = 0; k < n_launches; ++k) {
     args.list_in = (k & 1) ? d_list1 : d_list0;
     args.list_out = (k & 1) ? d_list0 : d_list1;
     args.cnt_in = d_cnt + k;
     args.cnt_out = d_cnt + k + 1;
-    switch (n_dof) {
-      case 1: launch_pair_step_t<1>(s, args, blocks); break;
-      case 2: launch_pair_step_t<2>(s, args, blocks); break;
-      case 3: launch_pair_step_t<3>(s, args, blocks); break;
-      case 4: launch_pair_step_t<4>(s, args, blocks); break;
-      case 6: launch_pair_step_t<6>(s, args, blocks); break;
-      case 7: launch_pair_step_t<7>(s, args, blocks); break;
-      default:
-        set_error("propagate: chains with this number of joints are not instantiated (1,2,3,4,6,7)");
-        return RKH_ERR_UNSUPPORTED;
+    rkh_status st;
+    if (use_pool && k == 0) {
+      args.step = 0;
+      args.pool_cursor = d_pool_cursor;
+      args.min_live = uint32_t(kPairEdges) / 2;
+      st = launch_pair_step_n(s, n_dof, args, std::min(blocks, pool_blocks));
+      args.pool_cursor = nullptr;
+    } else {
+      args.step = use_pool ? kStepFromEntry : uint32_t(k);
+      st = launch_pair_step_n(s, n_dof, args, blocks);
     }
+    if (st != RKH_OK) return st;
   }
   RKH_HIP(hipGetLastError());
   return RKH_OK;

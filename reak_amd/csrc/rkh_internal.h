@@ -358,7 +358,8 @@ size_t propagate_pair_step_workspace_bytes(int n_dof, uint32_t blocks);
 rkh_status launch_propagate_pair_steps(hipStream_t s, int n_dof, const SceneDev* d_scene, const DynDev& dyn,
                                        const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems,
                                        const uint32_t* d_edge_base, uint2* d_list0, uint2* d_list1, uint32_t* d_cnt,
-                                       double* d_ws, uint32_t blocks, KernelGate gate, unsigned long long* d_steps_exec);
+                                       double* d_ws, uint32_t blocks, KernelGate gate, unsigned long long* d_steps_exec,
+                                       uint32_t pool_blocks = 0, uint32_t* d_pool_cursor = nullptr);
 uint32_t pair_kernel_waves_per_cu(int n_dof);
 uint32_t pair_kernel_edges_per_wave();
 rkh_status launch_pair_cycles(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, const double* d_u,

@@ -1423,9 +1423,10 @@ def test_planner_pool_splits_a_batch_without_changing_results(L, ctx, oracle, c2
 
 
 def test_stepwise_and_two_phase_steer_launches_do_not_change_results(L, ctx, oracle, c2, monkeypatch):
-    """The steer launch of a large round in its three forms -- one launch for the whole edge, two phases with a compaction
-    of the survivors between them, one launch per RK4 step over the live edges of all problems (the default) -- runs the
-    same arithmetic per edge.  The round sizes at which the planner switches between them are far above what a test can
+    """The steer launch of a large round in its forms -- one launch for the whole edge, two phases with a compaction of
+    the survivors between them, one launch per RK4 step over the live edges of all problems, and the default: a resident
+    set of waves whose lane pairs take a new edge from the round's pool whenever theirs ends, followed by list launches
+    for the edges the waves hand over at the end -- runs the same arithmetic per edge.  The round sizes at which the planner switches between them are far above what a test can
     afford (32 k / 65 k edges), so RKH_STEER_SPLIT_MIN_EDGES = 0 sends every round of the two-lanes mapping (>= 1024 edges)
     through the form under test.  Trees, NN sequences, accept bits, goal probes and counters must be identical across
     the forms, equal to the oracle's, and the executed-step counter must agree with the free-step counts."""
@@ -1434,8 +1435,12 @@ def test_stepwise_and_two_phase_steer_launches_do_not_change_results(L, ctx, ora
     runs = {}
     for name, env in (("whole", {"RKH_STEER_SPLIT": "0", "RKH_STEER_STEPWISE": "0"}),
                       ("two_phase", {"RKH_STEER_STEPWISE": "0", "RKH_STEER_SPLIT": "5", "RKH_STEER_SPLIT_MIN_EDGES": "0"}),
-                      ("stepwise", {"RKH_STEER_STEPWISE": "1", "RKH_STEER_SPLIT_MIN_EDGES": "0"})):
-        for k in ("RKH_STEER_SPLIT", "RKH_STEER_STEPWISE", "RKH_STEER_SPLIT_MIN_EDGES"):
+                      ("stepwise", {"RKH_STEER_STEPWISE": "1", "RKH_STEER_POOL": "0", "RKH_STEER_SPLIT_MIN_EDGES": "0"}),
+                      ("pool", {"RKH_STEER_STEPWISE": "1", "RKH_STEER_POOL": "1", "RKH_STEER_SPLIT_MIN_EDGES": "0"}),
+                      # few resident waves: every wave refills its lanes many times and hands orphans over at the end
+                      ("pool_few_waves", {"RKH_STEER_STEPWISE": "1", "RKH_STEER_POOL": "1", "RKH_STEER_SPLIT_MIN_EDGES": "0",
+                                          "RKH_STEER_POOL_WAVES": "24"})):
+        for k in ("RKH_STEER_SPLIT", "RKH_STEER_STEPWISE", "RKH_STEER_SPLIT_MIN_EDGES", "RKH_STEER_POOL", "RKH_STEER_POOL_WAVES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1446,14 +1451,15 @@ def test_stepwise_and_two_phase_steer_launches_do_not_change_results(L, ctx, ora
                       "trees": [pl.tree(i) for i in picks], "steps": pl.steer_steps(),
                       "spec": sum(int(s.edges_speculated) for s in pl.all_stats)}
         pl.close()
-    for name in ("two_phase", "stepwise"):
+    for name in ("two_phase", "stepwise", "pool", "pool_few_waves"):
         assert runs[name]["stats"] == runs["whole"]["stats"], name
         for a, b in zip(runs[name]["trees"], runs["whole"]["trees"]):
             for key in ("parent", "nn_seq", "accept", "pos", "goal_dist"):
                 assert np.array_equal(a[key], b[key]), (name, key)
     # executed work: every form integrates the same steps (a step counts when it starts from a live edge), fewer than
     # the 20 per propagated edge the launches are sized for
-    assert runs["stepwise"]["steps"] == runs["whole"]["steps"] == runs["two_phase"]["steps"]
+    assert runs["stepwise"]["steps"] == runs["whole"]["steps"] == runs["two_phase"]["steps"] == runs["pool"]["steps"]
+    assert runs["pool_few_waves"]["steps"] == runs["whole"]["steps"]
     assert 0 < runs["stepwise"]["steps"] < 20 * 2 * runs["stepwise"]["spec"]
     osc = oracle.OracleScene(c2, fast=True)
     rc, ro, rt = osc.rrt_dyn(prms[17])
