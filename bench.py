@@ -365,7 +365,7 @@ def steer_occupancy():
 
 def nn_planner_traffic(problems, max_vertices):
     """HBM bytes per launch of the planner-regime NN sweep from the committed PMC passes, if they match this run."""
-    path = os.path.join(ROOT, "profiles", "r02_nn_planner_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r03_nn_planner_pmc.json")
     if not os.path.exists(path):
         return None
     rec = json.load(open(path))
@@ -489,7 +489,22 @@ def run_c5(args, rank, world, local_rank, dist, reduce_device, lib, scenarios, d
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
-        pl.solve_planning_query()
+        if dist is None:
+            pl.solve_planning_query()
+        else:
+            # RRT* resumes where it stopped: plan in slices of loop iterations and reduce tree sizes / edges (sum) and the
+            # best cost (min) over the ranks after each; done ranks keep answering until all are
+            done, budget = False, 0
+            while True:
+                if not done:
+                    budget += args.c5_report_iterations
+                    pl.solve_planning_query(max_loop_iterations=budget)
+                    done = all(int(s.num_vertices) >= args.c5_vertices + 2 for s in pl.all_stats)
+                all_done, *_ = dist_utils.progress_reduce(
+                    dist, done, sum(int(s.num_vertices) for s in pl.all_stats), sum(int(s.edges_checked) for s in pl.all_stats),
+                    min(float(s.best_cost) for s in pl.all_stats), reduce_device)
+                if all_done:
+                    break
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         r = {"seconds": dt, "nodes": sum(int(s.num_vertices) for s in pl.all_stats),
@@ -547,11 +562,15 @@ def main():
                          "steer tail with the other's NN sweep, which paid before the steer waves were packed and the "
                          "batches fitted to whole passes of the machine; now one group is faster (DESIGN.md section 5)")
     ap.add_argument("--rounds-per-sync", type=int, default=16)
+    ap.add_argument("--report-interval", type=int, default=4,
+                    help="N > 1: all-reduce {vertices, edges} (sum) and the best cost (min) every this many syncs")
     ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
                     help="c2 (default, BASELINE.json's metric): RRT with RK4 dynamics; c5: BASELINE config C5 -- independent "
                          "RRT* seeds sharded over the ranks (one planner batch per GPU), best-cost all-reduce (min)")
     ap.add_argument("--c5-vertices", type=int, default=1000000, help="vertices per RRT* seed of --workload c5")
     ap.add_argument("--c5-problems", type=int, default=1, help="RRT* seeds per GPU of --workload c5")
+    ap.add_argument("--c5-report-iterations", type=int, default=20000,
+                    help="--workload c5, N > 1: RRT* loop iterations between two report-interval reductions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
     args = ap.parse_args()
@@ -604,6 +623,7 @@ def main():
     P = args.problems
 
     nn_kernel = ["nn1_sweep_kernel"]
+    interval_reports = [0]
 
     def run_step(step_index, timed):
         seeds = dist_utils.seeds_for_rank(step_index, rank, world, P)
@@ -615,11 +635,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        n_sync = 0
         while True:
-            pl.enqueue(args.rounds_per_sync)
-            pl.sync()
-            if pl.done:
-                break
+            if not pl.done:
+                pl.enqueue(args.rounds_per_sync)
+                pl.sync()
+            n_sync += 1
+            if dist is None:
+                if pl.done:
+                    break
+            elif n_sync % args.report_interval == 0:
+                # the report-interval reductions of SURVEY.md 8(e), inside the timed region: tree sizes / edges (sum) and
+                # best solution cost (min) over all ranks; a rank that is done keeps answering until every rank is
+                all_done, *_ = dist_utils.progress_reduce(
+                    dist, pl.done, sum(int(st.num_vertices) - 1 for st in pl.all_stats),
+                    sum(int(st.edges_checked) for st in pl.all_stats), min(float(st.best_cost) for st in pl.all_stats),
+                    reduce_device)
+                interval_reports[0] += 1
+                if all_done:
+                    break
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         nodes = sum(int(st.num_vertices) - 1 for st in pl.all_stats)
@@ -685,6 +719,7 @@ def main():
                        "parallelism": f"{world} x {P} independent planners",
                        "planner_groups_per_gpu": args.groups},
             "rounds": tot["rounds"],
+            "interval_reductions": interval_reports[0],
             "speculation_efficiency": (tot["edges"] / tot["spec"]) if tot["spec"] else None,
             "best_solution_cost": None if best == float("inf") else best,
             # NN sweep of the timed region (rank 0) by SURVEY.md 8(d): algorithmic bytes = n * D * 8 per swept tree, against
@@ -698,8 +733,10 @@ def main():
                          "queries_per_launch": tot["spec"] / max(1, tot["nn_launches"]),
                          "note": "algorithmic bytes (sum over the swept trees of n * D * 8, SURVEY 8(d)) / HIP-event kernel "
                                  "time on the planner stream; traffic = HBM bytes per launch, FETCH_SIZE x 2 + WRITE_SIZE of "
-                                 "separate --pmc passes (profiles/r02_nn_planner_pmc.json; null if not collected for "
-                                 "this configuration)"},
+                                 "separate --pmc passes of the same code (tools/prof_pmc_nn.sh -> profiles/"
+                                 "r03_nn_planner_pmc.json; null if not collected for this configuration); a launch = the "
+                                 "five kernels of one round's NN search (B operands, pass 1, thresholds, pass 2, exact "
+                                 "resolution), HIP events around all five"},
             "nn_sweep_mfma_timed": mfma_view(nn_kernel[0], nn_tflops, scn.n_dof * 2,
                                              (tot["nn_pairs"] / tot["nn_launches"]) if tot["nn_launches"] else None),
         }

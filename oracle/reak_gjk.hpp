@@ -39,6 +39,10 @@ struct GjkShape {
     } else if (kind == RKH_SHAPE_BOX) {
       p = V3(dl[0] >= 0.0 ? 0.5 * dims[0] : -0.5 * dims[0], dl[1] >= 0.0 ? 0.5 * dims[1] : -0.5 * dims[1],
              dl[2] >= 0.0 ? 0.5 * dims[2] : -0.5 * dims[2]);
+    } else if (kind == RKH_SHAPE_CYLINDER) {  // flat-ended cylinder (dims: length, radius; axis = local z): rim point
+      const double rho = std::sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+      p = V3(rho > 0.0 ? (dims[1] * dl[0]) / rho : 0.0, rho > 0.0 ? (dims[1] * dl[1]) / rho : 0.0,
+             dl[2] >= 0.0 ? 0.5 * dims[0] : -0.5 * dims[0]);
     } else if (kind == RKH_SHAPE_MESH) {
       double best = -std::numeric_limits<double>::infinity();
       for (int i = 0; i < nv; ++i) {

@@ -4,8 +4,9 @@
 // The reference's proximity module has closed-form pairs only (no mesh shape, no GJK: TODO_list.txt:230); BASELINE
 // config C4 asks for convex-mesh obstacles through "batched GJK / support-mapping distance queries".  This is the
 // build's definition of that query, the same in the oracle (oracle/reak_gjk.hpp) and on the device:
-//   * a shape = a convex CORE swept by a radius: sphere = point + r, capped cylinder = axis segment + r, box and mesh =
-//     themselves (r = 0).  The radii are handled analytically (distance = core distance - rA - rB), so pairs of
+//   * a shape = a convex CORE swept by a radius: sphere = point + r, capped cylinder = axis segment + r, box, mesh and
+//     the flat-ended cylinder = themselves (r = 0; the cylinder's support map is curved, so its pairs end on the
+//     relative tolerance or the iteration cap instead of a repeated vertex).  The radii are handled analytically (distance = core distance - rA - rB), so pairs of
 //     spheres / capped cylinders / boxes reproduce the reference's closed forms to rounding while the cores are apart;
 //   * core distance = Gilbert-Johnson-Keerthi on the Minkowski difference with polytope supports (finite termination),
 //     closest point of the simplex by Voronoi-region tests (Ericson, Real-Time Collision Detection 5.1);
@@ -46,6 +47,10 @@ RKH_DI d3 gjk_support(const GjkShape& s, d3 dir) {
   } else if (s.kind == RKH_SHAPE_BOX) {
     p = mk3(dl.x >= 0.0 ? 0.5 * s.d0 : -0.5 * s.d0, dl.y >= 0.0 ? 0.5 * s.d1 : -0.5 * s.d1,
             dl.z >= 0.0 ? 0.5 * s.d2 : -0.5 * s.d2);
+  } else if (s.kind == RKH_SHAPE_CYLINDER) {  // flat-ended cylinder (d0 = length, d1 = radius; axis = local z): rim point
+    const double rho = sqrt(dl.x * dl.x + dl.y * dl.y);
+    p = mk3(rho > 0.0 ? (s.d1 * dl.x) / rho : 0.0, rho > 0.0 ? (s.d1 * dl.y) / rho : 0.0,
+            dl.z >= 0.0 ? 0.5 * s.d0 : -0.5 * s.d0);
   } else {  // mesh: first maximum wins
     double best = -INFINITY;
     p = mk3(0.0, 0.0, 0.0);

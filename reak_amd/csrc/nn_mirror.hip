@@ -51,6 +51,8 @@
 
 namespace rkh {
 
+void nn_set_last_kernel_name(const char* name);  // nn_sweep.hip (rkh_nn_kernel_name)
+
 namespace {
 
 typedef float mir_f16v __attribute__((ext_vector_type(16)));
@@ -442,6 +444,7 @@ rkh_status launch_nn1_mirror(hipStream_t s, int D, const NnArgs* d_table, uint32
   if (gx < 1) gx = 1;
   const dim3 grid(uint32_t((gx * gy * n_problems + 7) / 8 * 8));
   const dim3 qgrid((B_upper + 255) / 256, n_problems);
+  nn_set_last_kernel_name("nn1_mirror_kernel");
   if (ev0) (void)hipEventRecord(ev0, s);
   hipLaunchKernelGGL(nn1_mirror_prep_kernel, qgrid, dim3(256), 0, s, d_table, D);
   hipLaunchKernelGGL((nn1_mirror_kernel<1>), grid, dim3(kMirThreads), 0, s, d_table, d_yblock_base, n_problems, uint32_t(gx));

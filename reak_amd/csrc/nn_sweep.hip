@@ -1625,6 +1625,7 @@ uint32_t nn1_mfma_queries() { return uint32_t(kMfmaQueries); }
 
 static const char* g_last_kernel = "";
 const char* nn_last_kernel_name() { return g_last_kernel; }
+void nn_set_last_kernel_name(const char* name) { g_last_kernel = name; }
 
 template <int DP>
 static rkh_status launch_nn1_dp(hipStream_t s, int D, const NnArgs& single, const NnArgs* d_table, uint32_t n_problems,

@@ -578,3 +578,33 @@ def make_hidim(D, min_interval=0.05):
                     start=np.full(D, 0.05), goal=np.full(D, 0.95),
                     meta={"lower": np.zeros(D), "upper": np.ones(D), "min_interval": min_interval,
                           "max_edge_length": 0.2 * np.sqrt(D)})
+
+
+def nlp_proximity_shapes():
+    """The shapes and poses of R/geometry/proximity/test_nlp_proximity.cpp:40-58: six cylinders and six boxes at four poses
+    (a1 .. a4).  The reference feeds them to an NLP solver and prints what it finds -- it holds no expected distances --
+    and has no closed form for these pair kinds (cylinder-cylinder, cylinder-box, box-box: proxy_query_model.cpp:215-374
+    creates no finder); here they are a vector set for the support-map (GJK) distance query.  Returns {name: Shape}."""
+    s3 = np.sqrt(3.0) / 3.0
+    poses = {"a1": ((0.0, 0.0, 0.0), (0.8, 0.0, 0.6, 0.0)), "a2": ((0.0, 3.0, 5.0), (0.8, -0.6, 0.0, 0.0)),
+             "a3": ((10.0, -3.0, -2.0), (1.0, 0.0, 0.0, 0.0)), "a4": ((-3.0, -3.0, 6.0), (s3, 0.0, -s3, s3))}
+    spec = {"cy1": ("a1", T.SHAPE_CYLINDER, (5.0, 0.5, 0.0)), "cy2": ("a1", T.SHAPE_CYLINDER, (10.0, 0.25, 0.0)),
+            "cy3": ("a1", T.SHAPE_CYLINDER, (1.0, 2.0, 0.0)), "cy4": ("a2", T.SHAPE_CYLINDER, (5.0, 0.5, 0.0)),
+            "cy5": ("a3", T.SHAPE_CYLINDER, (5.0, 0.5, 0.0)), "cy6": ("a4", T.SHAPE_CYLINDER, (5.0, 0.5, 0.0)),
+            "bx1": ("a1", T.SHAPE_BOX, (1.0, 2.0, 1.0)), "bx2": ("a1", T.SHAPE_BOX, (4.0, 1.0, 10.0)),
+            "bx3": ("a1", T.SHAPE_BOX, (4.0, 4.0, 1.0)), "bx4": ("a2", T.SHAPE_BOX, (4.0, 2.0, 2.0)),
+            "bx5": ("a3", T.SHAPE_BOX, (4.0, 2.0, 2.0)), "bx6": ("a4", T.SHAPE_BOX, (4.0, 2.0, 2.0))}
+    out = {}
+    for name, (pose, kind, dims) in spec.items():
+        s = T.Shape(kind=kind, anchor=-1)
+        s.pose = T.make_pose(*poses[pose])
+        s.dims[:] = dims
+        out[name] = s
+    return out
+
+
+# the pairs test_nlp_proximity.cpp:211-233 queues: cylinder-cylinder, box-box, then box-cylinder and cylinder-box
+NLP_PROXIMITY_PAIRS = [("cy1", "cy4"), ("cy1", "cy5"), ("cy1", "cy6"), ("cy2", "cy4"), ("cy3", "cy4"),
+                       ("bx1", "bx4"), ("bx1", "bx5"), ("bx1", "bx6"), ("bx2", "bx4"), ("bx3", "bx4"),
+                       ("bx1", "cy4"), ("bx1", "cy5"), ("bx1", "cy6"), ("bx2", "cy4"), ("bx3", "cy4"),
+                       ("cy1", "bx4"), ("cy1", "bx5"), ("cy1", "bx6"), ("cy2", "bx4"), ("cy3", "bx4")]

@@ -68,3 +68,41 @@ def test_two_rank_gloo_reduction(oracle):
     assert r0 == r1  # every rank sees the same reduced line
     elapsed, nodes, edges, spec, best = r0
     assert elapsed == 2.0 and nodes == n0 + n1 == 4 * 60 and edges == e0 + e1
+
+
+def _progress_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank r "plans" for 3 + 2 r intervals, adding 100 (r + 1) vertices per interval; its best cost improves at interval 2
+    my_intervals = 3 + 2 * rank
+    calls, log, nodes, best = 0, [], 0, float("inf")
+    while True:
+        done = calls >= my_intervals
+        if not done:
+            nodes += 100 * (rank + 1)
+            if calls == 2:
+                best = 10.0 - rank
+        all_done, n_all, e_all, b_all = dist_utils.progress_reduce(dist, done, nodes, 2 * nodes, best, torch.device("cpu"))
+        calls += 1
+        log.append((all_done, n_all, e_all, b_all))
+        if all_done:
+            break
+    results[rank] = (calls, log)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_report_interval_reductions_with_ranks_that_finish_at_different_times():
+    """progress_reduce (bench.py's per-interval collectives): ranks run different numbers of rounds, so a
+    rank that is done keeps taking part until every rank is -- all ranks make the same number of calls (no hang), see the
+    same sums / minimum at every interval, and stop together."""
+    world = 2
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_progress_worker, args=(world, _free_port(), results), nprocs=world, join=True)
+    (c0, l0), (c1, l1) = results[0], results[1]
+    assert c0 == c1 == 6 and l0 == l1          # rank 1 needs 5 intervals of work + the one that finds everybody done
+    assert [x[0] for x in l0] == [False] * 5 + [True]
+    assert l0[-1][1] == 3 * 100 + 5 * 200 and l0[-1][2] == 2 * l0[-1][1] and l0[-1][3] == 9.0
+    assert l0[1][3] == float("inf") and l0[2][3] == 9.0  # the minimum appears at the interval both improved

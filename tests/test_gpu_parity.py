@@ -1072,6 +1072,19 @@ def test_gjk_on_the_device_matches_the_oracle_and_the_closed_forms(L, ctx, oracl
     assert np.max(np.abs(g - og)) <= 1e-12
 
 
+def test_nlp_proximity_poses_through_gjk(L, ctx, oracle):
+    """Shapes and poses of test_nlp_proximity.cpp:40-58 (six cylinders, six boxes, four poses) and the twenty pairs it
+    queues: the device GJK against the oracle's (1e-12).  The reference asserts no value for these pairs -- parity
+    unpinned; test_oracle_kat.py checks the oracle against a surface sampling."""
+    sh = scenarios.nlp_proximity_shapes()
+    pairs = scenarios.NLP_PROXIMITY_PAIRS
+    A, B = [sh[a] for a, _ in pairs], [sh[b] for _, b in pairs]
+    g, og = L.gjk_distance(ctx, A, B), oracle.gjk_distance(A, B)
+    assert np.max(np.abs(g - og)) <= 1e-12 and np.all(g > 1.0)
+    g2 = L.gjk_distance(ctx, B, A)
+    assert np.max(np.abs(g2 - oracle.gjk_distance(B, A))) <= 1e-12 and np.max(np.abs(g - g2)) <= 1e-10
+
+
 def test_c4_with_200_convex_mesh_obstacles(L, ctx, oracle):
     """BASELINE config C4 as written: the 12-DOF dual arm among 200 convex MESH obstacles (12-32 vertices each),
     proximity through batched GJK.  Distance queries, edge walks, RRT, bidirectional RRT and the PRM roadmap against
@@ -1564,4 +1577,33 @@ def test_planning_in_an_obstacle_course_read_from_an_rkx_archive(L, ctx, oracle,
     for k in ("nn_seq", "accept", "parent", "pos"):
         assert np.array_equal(tree[k], rt[k]), k
     assert 0 < np.sum(tree["accept"] == 0)  # walls stop some expansions
+    pl.close()
+
+
+def test_prm_random_walks_over_the_planar_dynamic_space(L, ctx, oracle):
+    """PRM -- rejection sampling on is_free(state), random_walk as an RK4 propagation over a fraction of the edge time
+    (EDGE_WALK_ACCEPT, planning_visitors.hpp:403-432), can_be_connected by full propagations -- over the state space of the
+    PLANAR 3R arm (revolute_joint_2D / rigid_link_2D / inertia_2D; one lane per edge, propagate_planar.hip): the entry
+    point existed since round 2 without a test.  Same loop decisions, roadmap and densities as the sequential planner.
+    (The bidirectional planners need a reversible space -- rrtstar_path_planner.tpp:70 -- and are not offered over any
+    dynamic space, planar or not.)"""
+    scn = scenarios.make_c1_planar(world_seed=1, dynamics=True)
+    sc, osc = L.Scene(ctx, scn), oracle.OracleScene(scn)
+    prm = scn.prm_params(seed=4, max_vertices=400, sampling_radius=1.0)
+    prm.base.conn_tol = 3.0
+    rc, rout, rg = osc.prm_dyn(prm)
+    assert rc == 0
+    pl = L.PrmPlanner(sc, prm, scn.dyn)
+    st = pl.solve_planning_query()
+    g = pl.graph()
+    assert (st.num_vertices, st.num_edges, st.samples, st.rejected, st.loop_iterations, st.num_components,
+            st.edges_checked) == (rout.num_vertices, rout.num_edges, rout.samples, rout.rejected, rout.loop_iterations,
+                                  rout.num_components, rout.edges_checked)
+    k = np.bincount(g["kind"], minlength=3)
+    assert k[1] > 10 and st.num_edges > 100  # random walks expanded the roadmap, connections were made
+    assert np.array_equal(g["kind"], rg["kind"]) and np.array_equal(g["expanded"], rg["expanded"])
+    assert np.array_equal(g["edge_u"], rg["edge_u"]) and np.array_equal(g["edge_v"], rg["edge_v"])
+    assert np.array_equal(g["cc_root"], rg["cc_root"])
+    assert np.allclose(g["pos"], rg["pos"], rtol=STATE_RTOL, atol=1e-12)
+    assert np.allclose(g["density"], rg["density"], rtol=1e-8, atol=1e-12)
     pl.close()

@@ -724,3 +724,43 @@ def test_planar_dynamics_2d_classes_equal_the_3d_classes_on_the_same_mechanism(o
     rc, pd, M, f = o2.state_derivative(np.zeros((1, 6)), np.zeros((1, 3)))
     assert np.isclose(f[0, 2], -masses[2] * 9.81 * lengths[2], rtol=1e-14)
     assert np.isclose(M[0, 2, 2], jin[2] + moments[2] + masses[2] * lengths[2] ** 2, rtol=1e-14)
+
+
+def test_nlp_proximity_poses_through_the_support_map_query(oracle):
+    """The cylinders and boxes of test_nlp_proximity.cpp:40-58 at its four poses, the twenty pairs it queues (:211-238).
+    The reference prints what its NLP solver finds and asserts nothing, so there is no expected value to pin (parity
+    unpinned); the support-map distance is checked against a dense sampling of both surfaces instead: never above the
+    closest sampled pair, and within the sampling pitch of it.  Flat-ended cylinders enter GJK through their own
+    support map (rim point), which these poses exercise at generic orientations."""
+    from scipy.spatial import cKDTree
+
+    sh = scenarios.nlp_proximity_shapes()
+    pairs = scenarios.NLP_PROXIMITY_PAIRS
+    d = oracle.gjk_distance([sh[a] for a, _ in pairs], [sh[b] for _, b in pairs])
+    dsw = oracle.gjk_distance([sh[b] for _, b in pairs], [sh[a] for a, _ in pairs])
+    assert np.max(np.abs(d - dsw)) <= 1e-10 and np.all(d > 1.0)
+
+    def rot(q):
+        w, x, y, z = np.array(q) / np.linalg.norm(q)
+        return np.array([[1-2*(y*y+z*z), 2*(x*y-w*z), 2*(x*z+w*y)], [2*(x*y+w*z), 1-2*(x*x+z*z), 2*(y*z-w*x)], [2*(x*z-w*y), 2*(y*z+w*x), 1-2*(x*x+y*y)]])
+
+    def surface(s, n=40000):
+        rng = np.random.default_rng(5)
+        if s.kind == T.SHAPE_BOX:
+            u = rng.uniform(-0.5, 0.5, size=(n, 3))
+            u[np.arange(n), rng.integers(0, 3, size=n)] = rng.choice([-0.5, 0.5], size=n)
+            p = u * np.array(s.dims[:3])
+        else:
+            ln, rad = s.dims[0], s.dims[1]
+            th, z, r = rng.uniform(0, 2 * np.pi, size=n), rng.uniform(-ln / 2, ln / 2, size=n), np.full(n, rad)
+            cap = rng.random(n) < 0.3
+            r[cap] = rad * np.sqrt(rng.random(cap.sum()))
+            z[cap] = rng.choice([-ln / 2, ln / 2], size=cap.sum())
+            p = np.stack([r * np.cos(th), r * np.sin(th), z], axis=1)
+        return p @ rot(list(s.pose.quat)).T + np.array(s.pose.pos)
+
+    clouds = {k: surface(v) for k, v in sh.items()}
+    trees = {k: cKDTree(v) for k, v in clouds.items()}
+    for (a, b), dd in zip(pairs, d):
+        m = trees[b].query(clouds[a])[0].min()
+        assert dd <= m + 1e-9 and m - dd < 0.06, (a, b, dd, m)
