@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -87,6 +88,25 @@ static __global__ void gb_select_kernel(GbAux* __restrict__ aux, int D, int DP) 
     if (d < D) v = (a.select_mode == GB_SELECT_POINT) ? a.pts[j][d] : a.a_xout[size_t(j) * D + d];
     if (d < RKH_MAX_DOF) a.query[d] = v;
     a.select_dst[d] = v;
+  }
+}
+
+// Result blocks -> pinned host memory, written by the device itself, then a step number behind a system-scope fence:
+// the host spins on that word instead of sleeping in hipStreamSynchronize (whose wake-up costs more than a whole
+// device step of a single planner is worth).  One block per problem; the block that arrives last publishes the step.
+static __global__ void gb_download_kernel(const uint4* __restrict__ d_res, uint4* __restrict__ h_res, uint32_t words16,
+                                          uint32_t* __restrict__ arrivals, volatile uint32_t* __restrict__ h_flag, uint32_t step) {
+  const uint4* src = d_res + size_t(blockIdx.x) * words16;
+  uint4* dst = h_res + size_t(blockIdx.x) * words16;
+  for (uint32_t i = threadIdx.x; i < words16; i += blockDim.x) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (atomicAdd(arrivals, 1u) == gridDim.x - 1) {
+      *arrivals = 0u;
+      __threadfence_system();
+      *h_flag = step;
+    }
   }
 }
 
@@ -250,6 +270,10 @@ struct GraphBatch {
   // result block per problem: {kcnt, overflow, n_edges, sel} kidx[kmax] kdist[kmax] nchk[emax] accept[emax] x_out[emax][D]
   //                           a_nchk[16] a_accept[16] a_xout[16][D]
   unsigned char *h_res = nullptr, *d_res = nullptr;
+  unsigned char* h_res_dev = nullptr;            // h_res as the device sees it
+  uint32_t *h_flag = nullptr, *h_flag_dev = nullptr, *d_arrivals = nullptr;
+  uint32_t flag_seq = 0;
+  bool spin_download = true;
   size_t res_stride = 0, off_kidx = 0, off_kdist = 0, off_nchk = 0, off_accept = 0, off_xout = 0, off_anchk = 0,
          off_aaccept = 0, off_axout = 0;
   bool any_knn = false, any_edges = false, any_append = false, any_stage_a = false;
@@ -323,6 +347,17 @@ struct GraphBatch {
     RKH_HIP(hipMalloc(reinterpret_cast<void**>(&d_res), res_stride * P));
     RKH_HIP(hipMemset(d_res, 0, res_stride * P));
     std::memset(h_res, 0, res_stride * P);
+    {  // results written to the host by the device + a flag word the host spins on (gb_download_kernel)
+      const char* env = getenv("RKH_GB_SPIN");
+      spin_download = !env || atoi(env) != 0;
+      RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_flag), 64, hipHostMallocDefault));
+      *h_flag = 0u;
+      RKH_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_flag_dev), h_flag, 0));
+      RKH_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_res_dev), h_res, 0));
+      RKH_HIP(hipMalloc(reinterpret_cast<void**>(&d_arrivals), sizeof(uint32_t)));
+      RKH_HIP(hipMemset(d_arrivals, 0, sizeof(uint32_t)));
+      flag_seq = 0;
+    }
     prob.resize(P);
     for (uint32_t i = 0; i < P; ++i) {
       GbProblem& q = prob[i];
@@ -349,6 +384,10 @@ struct GraphBatch {
     (void)hipHostFree(h_cmd);
     (void)hipFree(d_cmd);
     (void)hipHostFree(h_res);
+    if (h_flag) (void)hipHostFree(h_flag);
+    (void)hipFree(d_arrivals);
+    h_flag = nullptr;
+    d_arrivals = nullptr;
     (void)hipFree(d_res);
     if (stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
@@ -658,8 +697,26 @@ struct GraphBatch {
                                                   scene->n_pairs_verdict, qs, EdgeIO(), emax, nullptr, 0, d_io, nullptr, P);
       if (st != RKH_OK) return st;
     }
-    RKH_HIP(hipMemcpyAsync(h_res, d_res, res_stride * P, hipMemcpyDeviceToHost, s));
-    RKH_HIP(hipStreamSynchronize(s));
+    if (spin_download) {
+      const uint32_t tag = ++flag_seq;
+      hipLaunchKernelGGL(gb_download_kernel, dim3(P), dim3(256), 0, s, reinterpret_cast<const uint4*>(d_res),
+                         reinterpret_cast<uint4*>(h_res_dev), uint32_t(res_stride / 16), d_arrivals, h_flag_dev, tag);
+      RKH_HIP(hipGetLastError());
+      for (uint32_t spins = 0; *reinterpret_cast<volatile uint32_t*>(h_flag) != tag; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFFu) == 0xFFFFu) {  // a failed launch or a device fault must not hang the host
+          const hipError_t q = hipStreamQuery(s);
+          if (q != hipSuccess && q != hipErrorNotReady) RKH_HIP(q);
+          if (q == hipSuccess && *reinterpret_cast<volatile uint32_t*>(h_flag) != tag) {
+            set_error("graph batch: the step's results never arrived");
+            return RKH_ERR_DEVICE;
+          }
+        }
+      }
+    } else {
+      RKH_HIP(hipMemcpyAsync(h_res, d_res, res_stride * P, hipMemcpyDeviceToHost, s));
+      RKH_HIP(hipStreamSynchronize(s));
+    }
     ++steps;
     for (uint32_t i = 0; i < P; ++i)
       if (h_knn[i].B && overflow(i)) {

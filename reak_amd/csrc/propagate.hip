@@ -29,6 +29,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
+#include <unordered_set>
 
 #include "device_math.h"
 #include "proximity_device.h"
@@ -524,12 +526,12 @@ __device__ double proximity_min_planar(const SceneDev* __restrict__ sc, const CP
 // With cull_positive, pairs whose bounding spheres are apart are skipped (they cannot make the verdict
 // "colliding"; proxy_query_model.cpp:386-389 culls the same way against the running minimum) and the scan
 // stops once every edge of the wave has met a negative distance.
+// Global poses of the robot shapes at the configuration in ws.x (ws.Rpos / ws.Rquat), every lane group for its own
+// point; ends on a block barrier.
 template <int N, int GL, typename WS>
-__device__ double proximity_min(const SceneDev* __restrict__ sc, const CPack<N>& cp,
-                                const double* __restrict__ base, const ShapeDev* __restrict__ env_lds,
-                                const PairDev* __restrict__ pairs, int n_pairs, WS& ws,
-                                double* __restrict__ sink, int gl, int gb, bool cull_positive, bool group_done) {
-  if (sc->planar) return proximity_min_planar<N, GL>(sc, cp, base, env_lds, pairs, n_pairs, ws, gl, gb);
+__device__ __forceinline__ void proximity_frames(const SceneDev* __restrict__ sc, const ShapeDev* __restrict__ robot,
+                                                 const CPack<N>& cp, const double* __restrict__ base, WS& ws,
+                                                 double* __restrict__ sink, int gl) {
   const bool lead = (gl == 0);
   // half-angle sin/cos, one joint per lane (strided: a 16-lane group may carry more than 16 / 2 joints)
   for (int jj = gl; jj < N; jj += GL) {
@@ -565,7 +567,7 @@ __device__ double proximity_min(const SceneDev* __restrict__ sc, const CPack<N>&
   __syncthreads();
   // robot shapes -> global pose (pose_3D::getGlobalPose, pose_3D.hpp:102-110)
   for (int r = gl; r < sc->n_robot; r += GL) {
-    const ShapeDev& sh = sc->robot[r];
+    const ShapeDev& sh = robot[r];
     const int j = sh.link;
     const d3 pp = ld3(ws.Epos[j]);
     const d4 pq = ld4(ws.Equat[j]);
@@ -573,6 +575,15 @@ __device__ double proximity_min(const SceneDev* __restrict__ sc, const CPack<N>&
     st4(ws.Rquat[r], qmul(pq, ld4(sh.quat)));
   }
   __syncthreads();
+}
+
+template <int N, int GL, typename WS>
+__device__ double proximity_min(const SceneDev* __restrict__ sc, const CPack<N>& cp,
+                                const double* __restrict__ base, const ShapeDev* __restrict__ env_lds,
+                                const PairDev* __restrict__ pairs, int n_pairs, WS& ws,
+                                double* __restrict__ sink, int gl, int gb, bool cull_positive, bool group_done) {
+  if (sc->planar) return proximity_min_planar<N, GL>(sc, cp, base, env_lds, pairs, n_pairs, ws, gl, gb);
+  proximity_frames<N, GL>(sc, sc->robot, cp, base, ws, sink, gl);
   double dmin = INFINITY;
   bool hit = group_done;  // finished edges of the wave do not hold the scan open
   for (int p0 = 0; p0 < n_pairs; p0 += GL) {
@@ -925,31 +936,98 @@ struct BlockLdsQsW {
   GroupWsQs<N> g[(64 / GL) * W];
   double pts[(64 / GL) * W][N];   // the groups' interpolation points (space coordinates)
   uint32_t masks[W];      // per wave: bit t = group t's point lies on the edge, bit 4 + t = it passed the predicate
+  // block-level verdicts (proximity_verdicts_block): per group bit 0 = its point is to be tested, bit 1 = a shape pair
+  // of it is closer than 0; the (pair, group) combinations that survive the bounding-sphere cull
+  static constexpr int kQueueCap = 128 * W;
+  uint32_t flags[(64 / GL) * W];
+  uint32_t q_cnt;
+  uint32_t queue[kQueueCap];
+  ShapeDev robot[2 * N];  // the scene's robot shapes (SceneDev::robot)
 };
 template <int N, int GL, int W>
 struct SmemLayoutQsW {
   static constexpr size_t block_bytes = (sizeof(BlockLdsQsW<N, GL, W>) + 15) / 16 * 16;
-  static size_t bytes(int n_env) { return block_bytes + size_t(n_env) * sizeof(ShapeDev); }
+  // env shapes, then (if it fits: edge_check_kernel's pairs_staged) the proxy pair list
+  static size_t bytes(int n_env, int n_pairs_staged) {
+    return block_bytes + size_t(n_env) * sizeof(ShapeDev) + size_t(n_pairs_staged) * sizeof(PairDev);
+  }
 };
-template <int N, int GL, int W>
-__global__ __launch_bounds__(64 * W) void edge_check_kernel(const SceneDev* __restrict__ sc,
-                                                            const PairDev* __restrict__ pairs, int n_pairs, QsDev qs,
-                                                            EdgeIO io_a, EdgeIO io_b, const EdgeIO* __restrict__ tab_a,
-                                                            const EdgeIO* __restrict__ tab_b, uint32_t grid_a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+// The predicate's proximity half for all G points of a pass at once (3D scenes; robot shape poses already in
+// lds.g[t], lds.flags[t] = 1 for the points to test, lds.q_cnt = 0).  is_free only asks whether SOME proxy pair is
+// closer than 0 (manip_free_workspace.hpp:154-156), so the pairs need no order: every thread culls (pair, point)
+// combinations by the bounding spheres -- exactly findMinimumDistance's test against a running minimum of 0
+// (proxy_query_model.cpp:384-389), behind a cheaper test on squares that only ever skips what that one skips -- and
+// pushes the survivors into an LDS queue; then the block's threads take one surviving combination each and run its
+// closed form (bit 1 of the point's flag word = some pair of it is closer than 0).  A lane group walking the pair list
+// by itself (proximity_min) pays one closed form per 16 pairs as soon as any lane of the WAVE has a survivor: 9-19 in a
+// row per point; here a pass costs n_pairs G / threads culls and, nearly always, ONE round of closed forms.  Should the
+// survivors not fit the queue, the pair list is redone in slices that fit whatever survives.
+template <int N, int GL, int W, bool GJK>
+__device__ __forceinline__ void proximity_verdicts_block(const SceneDev* __restrict__ sc, const ShapeDev* __restrict__ env_lds,
+                                                         const PairDev* __restrict__ pairs, int n_pairs,
+                                                         BlockLdsQsW<N, GL, W>& lds, int tid) {
+  constexpr int G = (64 / GL) * W, QCAP = BlockLdsQsW<N, GL, W>::kQueueCap;
+  int p_lo = 0, p_step = n_pairs;
+  while (p_lo < n_pairs) {
+    const int p_hi = (p_lo + p_step < n_pairs) ? p_lo + p_step : n_pairs;
+    for (int idx = p_lo * G + tid; idx < p_hi * G; idx += 64 * W) {
+      const int t = idx % G, p = idx / G;
+      if (lds.flags[t] != 1u) continue;
+      const PairDev pr = pairs[p];
+      const ShapeDev& rs = lds.robot[pr.robot];
+      const ShapeDev& es = env_lds[pr.env];
+      const d3 ca = ld3(lds.g[t].Rpos[pr.robot]), cb = ld3(es.pos);
+      const d3 dc = pr.s1_is_robot ? cb - ca : ca - cb;
+      const double r1 = pr.s1_is_robot ? rs.brad : es.brad, r2 = pr.s1_is_robot ? es.brad : rs.brad;
+      const double sq = ((0.0 + dc.x * dc.x) + dc.y * dc.y) + dc.z * dc.z, rr = r1 + r2;
+      if (sq > (rr * rr) * (1.0 + 1e-9)) continue;   // clearly apart: the exact test below skips it too
+      if (sqrt(sq) - r1 - r2 > 0.0) continue;        // |c2 - c1| - r1 - r2 > 0 (transformToGlobal(0) is the shape's position)
+      const uint32_t slot = atomicAdd(&lds.q_cnt, 1u);
+      if (slot < uint32_t(QCAP)) lds.queue[slot] = uint32_t(t) | (uint32_t(p) << 8);
+    }
+    __syncthreads();
+    const uint32_t cnt = lds.q_cnt;
+    __syncthreads();
+    if (tid == 0) lds.q_cnt = 0u;
+    if (cnt > uint32_t(QCAP)) {  // (block-uniform) does not fit: slices of QCAP / G pairs always do
+      p_step = QCAP / G;
+      __syncthreads();
+      continue;
+    }
+    for (uint32_t i = tid; i < cnt; i += 64 * W) {
+      const uint32_t ent = lds.queue[i];
+      const int t = int(ent & 255u);
+      if (lds.flags[t] != 1u) continue;              // this point already has a colliding pair
+      const PairDev pr = pairs[ent >> 8];
+      const ShapeDev& rs = lds.robot[pr.robot];
+      const ShapeDev& es = env_lds[pr.env];
+      ShapeG A, Bv;
+      A.kind = rs.kind;
+      A.pos = ld3(lds.g[t].Rpos[pr.robot]);
+      A.q = ld4(lds.g[t].Rquat[pr.robot]);
+      A.d0 = rs.dims[0]; A.d1 = rs.dims[1]; A.d2 = rs.dims[2];
+      Bv.kind = es.kind;
+      Bv.pos = ld3(es.pos);
+      Bv.q = ld4(es.quat);
+      Bv.d0 = es.dims[0]; Bv.d1 = es.dims[1]; Bv.d2 = es.dims[2];
+      const double d = pr.s1_is_robot ? pair_distance<GJK>(pr.routine, A, Bv, sc->mesh_verts)
+                                      : pair_distance<GJK>(pr.routine, Bv, A, sc->mesh_verts);
+      if (d < 0.0) atomicOr(&lds.flags[t], 2u);
+    }
+    __syncthreads();
+    p_lo = p_hi;
+  }
+}
+
+// One edge walk of edge_check_kernel (the block's groups test G consecutive points per pass).
+template <int N, int GL, int W, bool GJK>
+__device__ __forceinline__ void edge_walk(const SceneDev* __restrict__ sc, const PairDev* __restrict__ pairs, int n_pairs,
+                                          const QsDev& qs, const EdgeIO& io, BlockLdsQsW<N, GL, W>& lds,
+                                          const ShapeDev* __restrict__ env_lds, uint32_t e) {
   constexpr int GPW = 64 / GL, G = GPW * W;  // groups per wave, groups (= points per pass) of the block
-  BlockLdsQsW<N, GL, W>& lds = *reinterpret_cast<BlockLdsQsW<N, GL, W>*>(smem_raw);
-  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayoutQsW<N, GL, W>::block_bytes);
-  const bool group_b = blockIdx.x >= grid_a;
-  const EdgeIO io = tab_a ? (group_b ? tab_b[blockIdx.y] : tab_a[blockIdx.y]) : (group_b ? io_b : io_a);
-  const uint32_t B = io.d_B ? *io.d_B : io.B;
-  const uint32_t e = group_b ? blockIdx.x - grid_a : blockIdx.x;
-  if (e >= B) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = tid / GL, gl = lane % GL, gb = (lane / GL) * GL;  // group of the block, lane of the group, its base lane in the wave
-  stage_chain<N>(sc, lds.joints, lds.base, lane);  // (every wave writes the same values)
-  stage_env(sc, env_lds, lane);
   GroupWsQs<N>& ws = lds.g[g];
   const uint32_t si = io.src_idx ? io.src_idx[e] : ((io.d_src_first ? *io.d_src_first : 0u) + e);
   const uint64_t trow = io.tgt_idx ? uint64_t(io.tgt_idx[e]) : ((io.d_tgt_off ? uint64_t(*io.d_tgt_off) : 0ull) + e);
@@ -982,10 +1060,19 @@ __global__ __launch_bounds__(64 * W) void edge_check_kernel(const SceneDev* __re
     }
     const unsigned long long mo = __ballot(oob);
     const bool group_oob = (GL == 64 ? mo : ((mo >> gb) & ((1ull << (GL & 63)) - 1ull))) != 0ull;
-    __syncthreads();
-    const double dmin = proximity_min<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true,
-                                             g != 0 || group_oob);
-    const bool is_free = !group_oob && !(dmin < 0.0);
+    bool is_free;
+    if (!sc->planar) {
+      if (gl == 0) lds.flags[g] = (g == 0 && !group_oob) ? 1u : 0u;
+      if (tid == 0) lds.q_cnt = 0u;
+      __syncthreads();
+      proximity_frames<N, GL>(sc, lds.robot, cp, lds.base, ws, lds.sink[lane], gl);
+      proximity_verdicts_block<N, GL, W, GJK>(sc, env_lds, pairs, n_pairs, lds, tid);
+      is_free = (lds.flags[0] == 1u);
+    } else {
+      __syncthreads();
+      const double dmin = proximity_min_planar<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, gl, gb);
+      is_free = !group_oob && !(dmin < 0.0);
+    }
     if (g == 0 && gl < N) io.x_out[uint64_t(e) * N + gl] = b_d;
     if (tid == 0) {
       io.steps_free[e] = 1;
@@ -1029,10 +1116,19 @@ __global__ __launch_bounds__(64 * W) void edge_check_kernel(const SceneDev* __re
       }
       const unsigned long long mo = __ballot(oob);
       const bool group_oob = (GL == 64 ? mo : ((mo >> gb) & ((1ull << (GL & 63)) - 1ull))) != 0ull;
-      __syncthreads();
-      const double dmin = proximity_min<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true,
-                                               !valid || group_oob);
-      const bool is_free = valid && !group_oob && !(dmin < 0.0);
+      bool is_free;
+      if (!sc->planar) {
+        if (gl == 0) lds.flags[g] = (valid && !group_oob) ? 1u : 0u;
+        if (tid == 0) lds.q_cnt = 0u;
+        __syncthreads();
+        proximity_frames<N, GL>(sc, lds.robot, cp, lds.base, ws, lds.sink[lane], gl);
+        proximity_verdicts_block<N, GL, W, GJK>(sc, env_lds, pairs, n_pairs, lds, tid);
+        is_free = (lds.flags[g] == 1u);
+      } else {  // planar scenes: the verdict depends on the finder order (proximity_min_planar)
+        __syncthreads();
+        const double dmin = proximity_min_planar<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, gl, gb);
+        is_free = valid && !group_oob && !(dmin < 0.0);
+      }
       {  // the wave's verdicts -> LDS, then every thread scans the block's groups in edge order
         const unsigned long long mv = __ballot(valid && gl == 0), mf = __ballot(is_free && gl == 0);
         uint32_t m = 0;
@@ -1096,6 +1192,405 @@ __global__ __launch_bounds__(64 * W) void edge_check_kernel(const SceneDev* __re
       if (tid == 0) io.accept[e] = ok ? 1 : 0;
     }
   }
+}
+
+
+template <int N, int GL, int W>
+__device__ __forceinline__ const PairDev* edge_check_stage(const SceneDev* __restrict__ sc, const PairDev* __restrict__ pairs,
+                                                           int n_pairs, int pairs_staged, BlockLdsQsW<N, GL, W>& lds,
+                                                           ShapeDev* env_lds) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  stage_chain<N>(sc, lds.joints, lds.base, lane);  // (every wave writes the same values)
+  stage_env(sc, env_lds, lane);
+  // robot shapes and, when the launch made room for it, the pair list: the cull loop reads both per combination
+  const int n_words = sc->n_robot * int(sizeof(ShapeDev) / sizeof(double));
+  for (int i = tid; i < n_words; i += 64 * W)
+    reinterpret_cast<double*>(lds.robot)[i] = reinterpret_cast<const double*>(sc->robot)[i];
+  if (!pairs_staged) return pairs;
+  PairDev* pl = reinterpret_cast<PairDev*>(env_lds + sc->n_env);
+  for (int i = tid; i < n_pairs; i += 64 * W) pl[i] = pairs[i];
+  return pl;
+}
+
+template <int N, int GL, int W, bool GJK>
+__global__ __launch_bounds__(64 * W) void edge_check_kernel(const SceneDev* __restrict__ sc,
+                                                            const PairDev* __restrict__ pairs, int n_pairs, QsDev qs,
+                                                            EdgeIO io_a, EdgeIO io_b, const EdgeIO* __restrict__ tab_a,
+                                                            const EdgeIO* __restrict__ tab_b, uint32_t grid_a,
+                                                            int pairs_staged) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  BlockLdsQsW<N, GL, W>& lds = *reinterpret_cast<BlockLdsQsW<N, GL, W>*>(smem_raw);
+  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + SmemLayoutQsW<N, GL, W>::block_bytes);
+  const bool group_b = blockIdx.x >= grid_a;
+  const EdgeIO io = tab_a ? (group_b ? tab_b[blockIdx.y] : tab_a[blockIdx.y]) : (group_b ? io_b : io_a);
+  const uint32_t B = io.d_B ? *io.d_B : io.B;
+  const uint32_t e = group_b ? blockIdx.x - grid_a : blockIdx.x;
+  if (e >= B) return;
+  pairs = edge_check_stage<N, GL, W>(sc, pairs, n_pairs, pairs_staged, lds, env_lds);
+  edge_walk<N, GL, W, GJK>(sc, pairs, n_pairs, qs, io, lds, env_lds, e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same edge walk for 3D scenes with ONE LANE PER POINT in the chain kinematics (edge_points_kernel).  In
+// edge_check_kernel a point belongs to a 16-lane group whose lanes all run the serial base -> tip chain of that one
+// point: ~1.2 k fp64 instructions per wave for 4 points.  Here a block of 4 waves takes G = 64 (32 for chains of more
+// than 7 joints) consecutive points per pass and every phase is spread over what it is parallel in:
+//   half-angle sin / cos   one (point, joint) per thread
+//   joint end frames       one POINT per lane of the first wave: the serial chain, once per 64 points
+//   robot shape poses      one (point, shape) per thread
+//   bounding-sphere cull   one (point, pair) per thread -> survivors into the LDS queue (as proximity_verdicts_block)
+//   closed forms           one surviving (point, pair) per thread
+// and the first colliding point comes out of two ballots.  Per-point data sit in LDS component-major ([..][G]: lanes of
+// a wave = consecutive points = consecutive addresses).  Same arithmetic per point as edge_check_kernel (the same
+// device functions in the same order), so n_checked, results and verdicts are the same bits; planar scenes, whose
+// verdict depends on the finder order, stay on edge_check_kernel.
+template <int N>
+struct EdgePointsCfg {
+  static constexpr int G = N <= 7 ? 64 : 32;   // points per pass
+  static constexpr int T = 256;                // threads per block
+  static constexpr int QCAP = 1024;            // surviving (point, pair) combinations per round of closed forms
+};
+template <int N>
+struct __attribute__((aligned(16))) EdgePointsLds {
+  static constexpr int G = EdgePointsCfg<N>::G;
+  JointLds joints[N];
+  double base[10];
+  ShapeDev robot[2 * N];
+  double a[N], b[N], res[N];      // the edge's end points; staging of an N-vector for the ordered sums
+  double pts[N][G];               // the pass's interpolation points (space coordinates)
+  double cs[N][2][G];             // cos, sin of the half joint angles
+  double E[N][7][G];              // joint end frames: position, quaternion
+  double R[2 * N][7][G];          // robot shapes, global pose
+  uint32_t flags[G];              // bit 0: to be tested (on the edge, inside the bounds), bit 1: a pair closer than 0, bit 2: on the edge
+  uint32_t q_cnt;
+  uint32_t scan[2];               // first point that fails the predicate, points on the edge
+  uint32_t queue[EdgePointsCfg<N>::QCAP];
+};
+template <int N>
+struct EdgePointsSmem {
+  static constexpr size_t block_bytes = (sizeof(EdgePointsLds<N>) + 15) / 16 * 16;
+  static size_t bytes(int n_env, int n_pairs_staged) {
+    return block_bytes + size_t(n_env) * sizeof(ShapeDev) + size_t(n_pairs_staged) * sizeof(PairDev);
+  }
+};
+
+struct EdgePointsArgs {
+  const SceneDev* sc;
+  const PairDev* pairs;
+  int n_pairs;
+  QsDev qs;
+  EdgeIO io_a, io_b;
+  const EdgeIO* tab_a;
+  const EdgeIO* tab_b;
+  uint32_t grid_a;
+  int pairs_staged;
+};
+typedef const __attribute__((address_space(4))) EdgePointsArgs* EdgePointsArgP;
+template <int N, bool GJK>
+__global__ __launch_bounds__(256) void edge_points_kernel(EdgePointsArgs) {
+  // arguments are read through the kernarg segment pointer (a by-value record indexed at run time -- qs.speed[j], the
+  // choice between io_a and io_b -- would be copied to scratch)
+  EdgePointsArgP ka = (EdgePointsArgP)__builtin_amdgcn_kernarg_segment_ptr();
+  const SceneDev* __restrict__ sc = ka->sc;
+  const PairDev* __restrict__ pairs = ka->pairs;
+  const int n_pairs = ka->n_pairs, pairs_staged = ka->pairs_staged;
+  const uint32_t grid_a = ka->grid_a;
+  const EdgeIO* __restrict__ tab_a = ka->tab_a;
+  const EdgeIO* __restrict__ tab_b = ka->tab_b;
+  const auto& qs = ka->qs;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int G = EdgePointsCfg<N>::G, T = EdgePointsCfg<N>::T, QCAP = EdgePointsCfg<N>::QCAP;
+  EdgePointsLds<N>& lds = *reinterpret_cast<EdgePointsLds<N>*>(smem_raw);
+  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + EdgePointsSmem<N>::block_bytes);
+  const bool group_b = blockIdx.x >= grid_a;
+  const EdgeIO* iop = tab_a ? (group_b ? &tab_b[blockIdx.y] : &tab_a[blockIdx.y]) : nullptr;
+  const __attribute__((address_space(4))) EdgeIO* iok = group_b ? &ka->io_b : &ka->io_a;
+#define RKH_IO(f) (iop ? iop->f : iok->f)
+  const uint32_t B = RKH_IO(d_B) ? *RKH_IO(d_B) : RKH_IO(B);
+  const uint32_t e = group_b ? blockIdx.x - grid_a : blockIdx.x;
+  if (e >= B) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  stage_chain<N>(sc, lds.joints, lds.base, lane);  // (every wave writes the same values)
+  stage_env(sc, env_lds, lane);
+  {
+    const int n_words = sc->n_robot * int(sizeof(ShapeDev) / sizeof(double));
+    for (int i = tid; i < n_words; i += T) reinterpret_cast<double*>(lds.robot)[i] = reinterpret_cast<const double*>(sc->robot)[i];
+    if (pairs_staged) {
+      PairDev* pl = reinterpret_cast<PairDev*>(env_lds + sc->n_env);
+      for (int i = tid; i < n_pairs; i += T) pl[i] = pairs[i];
+      pairs = pl;
+    }
+  }
+  const int mode = RKH_IO(mode);
+  if (tid < N) {
+    const uint32_t* src_idx = RKH_IO(src_idx);
+    const uint32_t* d_src_first = RKH_IO(d_src_first);
+    const uint32_t* tgt_idx = RKH_IO(tgt_idx);
+    const uint32_t* d_tgt_off = RKH_IO(d_tgt_off);
+    const uint32_t si = src_idx ? src_idx[e] : ((d_src_first ? *d_src_first : 0u) + e);
+    const uint64_t trow = tgt_idx ? uint64_t(tgt_idx[e]) : ((d_tgt_off ? uint64_t(*d_tgt_off) : 0ull) + e);
+    lds.a[tid] = RKH_IO(src)[uint64_t(si) * RKH_IO(src_stride) + tid];
+    lds.b[tid] = RKH_IO(tgt)[trow * RKH_IO(tgt_stride) + tid];
+  }
+  __syncthreads();
+  const CPack<N> cp = load_cpack<N>(lds.joints, lane);
+  const int n_robot = sc->n_robot;
+
+  // exact left-to-right euclidean norm of the N-vector whose component d thread d holds (vect_distance_metrics.hpp:126-137)
+  auto norm_n = [&](double diff) {
+    if (tid < N) lds.res[tid] = diff * diff;
+    __syncthreads();
+    double sacc = 0.0;
+#pragma unroll
+    for (int d = 0; d < N; ++d) sacc = sacc + lds.res[d];
+    __syncthreads();
+    return sqrt(sacc);
+  };
+  // is_free's proximity half for the points flagged 1 in lds.flags (their coordinates in lds.pts): sets bit 1 of the
+  // flag of every point with a proxy pair closer than 0.  Block-uniform control flow throughout.
+  auto test_points = [&](int n_pts) {
+    for (int idx = tid; idx < G * N; idx += T) {   // half-angle sin / cos (revolute_joint_3D::doMotion)
+      const int t = idx % G, j = idx / G;
+      if (t >= n_pts) continue;
+      double sn, cs;
+      sincos(0.5 * (lds.pts[j][t] * qs.speed[j]), &sn, &cs);
+      lds.cs[j][0][t] = cs;
+      lds.cs[j][1][t] = sn;
+    }
+    __syncthreads();
+    if (tid < G) {  // revolute_joint_3D / rigid_link_3D kinematics, position + orientation only: this lane's point
+      const int t = tid;
+      d3 pos = ld3(lds.base);
+      d4 Q = ld4(lds.base + 3);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const int jb = j * 32;
+        if (sc->branch_start[j]) {  // a new branch: base frame * mount pose (rigid_link_3D::doMotion from frame 0)
+          const d4 bq = ld4(lds.base + 3);
+          pos = ld3(lds.base) + mul(rotmat(bq), ld3(sc->mount_pos[j]));
+          Q = qmul(bq, ld4(sc->mount_quat[j]));
+        }
+        const d3 axis_n = cget3(cp, jb + JC_AXISN);
+        const double c2 = lds.cs[j][0][t], s2 = lds.cs[j][1][t];
+        const d4 tq = d4{c2, axis_n.x * s2, axis_n.y * s2, axis_n.z * s2};
+        const d4 EQ = qmul(Q, tq);
+        lds.E[j][0][t] = pos.x; lds.E[j][1][t] = pos.y; lds.E[j][2][t] = pos.z;
+        lds.E[j][3][t] = EQ.w; lds.E[j][4][t] = EQ.x; lds.E[j][5][t] = EQ.y; lds.E[j][6][t] = EQ.z;
+        const m33 Rm = rotmat(EQ);
+        pos = pos + mul(Rm, cget3(cp, jb + JC_OFFP));
+        Q = qmul(EQ, d4{cget(cp, jb + JC_OFFQ), cget(cp, jb + JC_OFFQ + 1), cget(cp, jb + JC_OFFQ + 2),
+                        cget(cp, jb + JC_OFFQ + 3)});
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * n_robot; idx += T) {  // robot shapes -> global pose (pose_3D::getGlobalPose, pose_3D.hpp:102-110)
+      const int t = idx % G, r = idx / G;
+      const ShapeDev& sh = lds.robot[r];
+      const int j = sh.link;
+      const d3 pp = d3{lds.E[j][0][t], lds.E[j][1][t], lds.E[j][2][t]};
+      const d4 pq = d4{lds.E[j][3][t], lds.E[j][4][t], lds.E[j][5][t], lds.E[j][6][t]};
+      const d3 gp = pp + qrot(pq, ld3(sh.pos));
+      const d4 gq = qmul(pq, ld4(sh.quat));
+      lds.R[r][0][t] = gp.x; lds.R[r][1][t] = gp.y; lds.R[r][2][t] = gp.z;
+      lds.R[r][3][t] = gq.w; lds.R[r][4][t] = gq.x; lds.R[r][5][t] = gq.y; lds.R[r][6][t] = gq.z;
+    }
+    __syncthreads();
+    // bounding-sphere cull of every (pair, point), survivors -> queue -> closed forms (see proximity_verdicts_block)
+    int p_lo = 0, p_step = n_pairs;
+    while (p_lo < n_pairs) {
+      const int p_hi = (p_lo + p_step < n_pairs) ? p_lo + p_step : n_pairs;
+      {  // a wave's lanes are consecutive points of ONE pair (two pairs when G = 32): the pair's constants are uniform
+        constexpr int PPB = T / G;   // pairs per block iteration
+        const int t = tid % G;
+        const bool live = lds.flags[t] == 5u;
+        auto cull = [&](int p) {
+          const PairDev pr = pairs[p];
+          const ShapeDev& rs = lds.robot[pr.robot];
+          const ShapeDev& es = env_lds[pr.env];
+          const d3 ca = d3{lds.R[pr.robot][0][t], lds.R[pr.robot][1][t], lds.R[pr.robot][2][t]}, cb = ld3(es.pos);
+          const d3 dc = pr.s1_is_robot ? cb - ca : ca - cb;
+          const double r1 = pr.s1_is_robot ? rs.brad : es.brad, r2 = pr.s1_is_robot ? es.brad : rs.brad;
+          const double sq = ((0.0 + dc.x * dc.x) + dc.y * dc.y) + dc.z * dc.z, rr = r1 + r2;
+          if (sq > (rr * rr) * (1.0 + 1e-9)) return false;   // clearly apart: the exact test below skips it too
+          return !(sqrt(sq) - r1 - r2 > 0.0);                // |c2 - c1| - r1 - r2 > 0 (proxy_query_model.cpp:384-389, minimum 0)
+        };
+        int p = p_lo + tid / G;
+        for (; p + 3 * PPB < p_hi; p += 4 * PPB) {  // four independent pairs in flight
+          const bool k0 = cull(p), k1 = cull(p + PPB), k2 = cull(p + 2 * PPB), k3 = cull(p + 3 * PPB);
+          if (live) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const bool k = u == 0 ? k0 : (u == 1 ? k1 : (u == 2 ? k2 : k3));
+              if (k) {
+                const uint32_t slot = atomicAdd(&lds.q_cnt, 1u);
+                if (slot < uint32_t(QCAP)) lds.queue[slot] = uint32_t(t) | (uint32_t(p + u * PPB) << 8);
+              }
+            }
+          }
+        }
+        for (; p < p_hi; p += PPB) {
+          if (live && cull(p)) {
+            const uint32_t slot = atomicAdd(&lds.q_cnt, 1u);
+            if (slot < uint32_t(QCAP)) lds.queue[slot] = uint32_t(t) | (uint32_t(p) << 8);
+          }
+        }
+      }
+      __syncthreads();
+      const uint32_t cnt = lds.q_cnt;
+      __syncthreads();
+      if (tid == 0) lds.q_cnt = 0u;
+      if (cnt > uint32_t(QCAP)) {  // (block-uniform) does not fit: slices of QCAP / G pairs always do
+        p_step = QCAP / G;
+        __syncthreads();
+        continue;
+      }
+      for (uint32_t i = tid; i < cnt; i += T) {
+        const uint32_t ent = lds.queue[i];
+        const int t = int(ent & 255u);
+        if (lds.flags[t] != 5u) continue;              // this point already has a colliding pair
+        const PairDev pr = pairs[ent >> 8];
+        const ShapeDev& rs = lds.robot[pr.robot];
+        const ShapeDev& es = env_lds[pr.env];
+        ShapeG A, Bv;
+        A.kind = rs.kind;
+        A.pos = d3{lds.R[pr.robot][0][t], lds.R[pr.robot][1][t], lds.R[pr.robot][2][t]};
+        A.q = d4{lds.R[pr.robot][3][t], lds.R[pr.robot][4][t], lds.R[pr.robot][5][t], lds.R[pr.robot][6][t]};
+        A.d0 = rs.dims[0]; A.d1 = rs.dims[1]; A.d2 = rs.dims[2];
+        Bv.kind = es.kind;
+        Bv.pos = ld3(es.pos);
+        Bv.q = ld4(es.quat);
+        Bv.d0 = es.dims[0]; Bv.d1 = es.dims[1]; Bv.d2 = es.dims[2];
+        const double d = pr.s1_is_robot ? pair_distance<GJK>(pr.routine, A, Bv, sc->mesh_verts)
+                                        : pair_distance<GJK>(pr.routine, Bv, A, sc->mesh_verts);
+        if (d < 0.0) atomicOr(&lds.flags[t], 2u);
+      }
+      __syncthreads();
+      p_lo = p_hi;
+    }
+  };
+  // hyperbox bounds of point t (manip_free_workspace.hpp:79-99; lower > upper: a wrapped coordinate)
+  auto out_of_bounds = [&](int t) {
+    bool oob = false;
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+      const double pt = lds.pts[d][t], lo = qs.lower[d], hi = qs.upper[d];
+      if (lo < hi) oob = oob || (pt < lo) || (pt > hi);
+      else oob = oob || (pt > lo) || (pt < hi);
+    }
+    return oob;
+  };
+
+  const double a_d = tid < N ? lds.a[tid] : 0.0, b_d = tid < N ? lds.b[tid] : 0.0;
+  if (mode == EDGE_POINT) {
+    // is_free(target): hyperbox bounds, then proximity (manip_free_workspace.hpp:79-99,154-156)
+    if (tid < N) lds.pts[tid][0] = b_d;
+    if (tid == 0) lds.q_cnt = 0u;
+    __syncthreads();
+    if (tid < G) lds.flags[tid] = (tid == 0 && !out_of_bounds(0)) ? 5u : 0u;
+    __syncthreads();
+    test_points(1);
+    if (tid < N) RKH_IO(x_out)[uint64_t(e) * N + tid] = b_d;
+    if (tid == 0) {
+      RKH_IO(steps_free)[e] = 1;
+      RKH_IO(accept)[e] = (lds.flags[0] == 5u) ? 1 : 0;
+    }
+    return;
+  }
+  const double dist_tot = norm_n(a_d - b_d);
+  const double fraction = RKH_IO(frac) ? RKH_IO(frac)[e] : qs.fraction;
+  double result = a_d;       // component tid of the returned point
+  uint32_t n_checked = 0;
+  bool completed_walk = false;  // the predicate loop ran to dist_inter without a collision (EDGE_STEER_BOTH)
+  if (dist_tot == INFINITY) {
+    result = a_d;
+  } else if (dist_tot < qs.min_interval) {
+    result = a_d + (b_d - a_d) * fraction;  // vector_topology::move_position_toward, no predicate call
+  } else {
+    const double dist_inter = dist_tot * fraction;
+    double cur = 0.0;          // dist_cur of the last tested point (0 + min_interval == min_interval exactly)
+    double last_result = a_d;  // last point that passed the predicate
+    bool collided = false;
+    for (;;) {
+      // dist_cur of this thread's point and of the pass's last one: cur + min_interval, repeatedly (":157 dist_cur += min_interval")
+      double my = cur, last = cur;
+      const int t_mine = tid < G ? tid : 0;
+#pragma unroll 8
+      for (int t = 0; t < G; ++t) {
+        if (t <= t_mine) my = my + qs.min_interval;
+        last = last + qs.min_interval;
+      }
+      if (!((cur + qs.min_interval) < dist_inter)) break;  // not even the first point is on the edge (block-uniform)
+      if (tid < G) {
+        const bool valid = my < dist_inter;
+        const double f = my / dist_tot;
+#pragma unroll
+        for (int d = 0; d < N; ++d) lds.pts[d][tid] = lds.a[d] + (lds.b[d] - lds.a[d]) * f;
+        lds.flags[tid] = valid ? (out_of_bounds(tid) ? 4u : 5u) : 0u;
+      }
+      if (tid == 0) lds.q_cnt = 0u;
+      __syncthreads();
+      test_points(G);
+      if (tid < 64) {  // the first point on the edge that fails the predicate, and how many points are on the edge
+        const uint32_t fl = tid < G ? lds.flags[tid] : 0u;
+        const unsigned long long mv = __ballot((fl & 4u) != 0u), mf = __ballot(fl == 5u);
+        const unsigned long long bad = mv & ~mf;
+        if (tid == 0) {
+          lds.scan[0] = bad ? uint32_t(__builtin_ctzll(bad)) : uint32_t(G);
+          lds.scan[1] = uint32_t(__builtin_popcountll(mv));
+        }
+      }
+      __syncthreads();
+      const int first_bad = int(lds.scan[0]), n_valid = int(lds.scan[1]);
+      if (first_bad < G) {
+        n_checked += uint32_t(first_bad + 1);
+        if (first_bad > 0 && tid < N) last_result = lds.pts[tid][first_bad - 1];
+        collided = true;
+        break;
+      }
+      n_checked += uint32_t(n_valid);
+      if (tid < N) last_result = lds.pts[tid][n_valid - 1];
+      if (n_valid < G) break;  // reached dist_inter without a collision
+      cur = last;
+      __syncthreads();         // the points and verdicts are rewritten by the next pass
+    }
+    completed_walk = !collided;
+    if (collided) result = last_result;
+    else if (fraction == 1.0) result = b_d;  // exact end fractions (:159-162)
+    else if (fraction == 0.0) result = a_d;
+    else result = a_d + (b_d - a_d) * fraction;
+  }
+  if (tid < N) RKH_IO(x_out)[uint64_t(e) * N + tid] = result;
+  if (tid == 0) RKH_IO(steps_free)[e] = n_checked;
+  if (mode != EDGE_PLAIN) {
+    const double n_ar = norm_n(a_d - result);
+    const double n_ab = dist_tot;
+    const double n_rb = norm_n(result - b_d);
+    const double steer_tol = RKH_IO(steer_tol);
+    if (mode == EDGE_STEER_ACCEPT || mode == EDGE_STEER_BOTH) {
+      // planning_visitor_base::steer_towards_position (planning_visitors.hpp:349-360)
+      const double best_case = RKH_IO(best_case) ? RKH_IO(best_case)[e] : n_ab;
+      const bool ok = (!isinf(n_ar)) && (n_ar < 2.0 * best_case) && (n_ar > steer_tol * best_case);
+      // EDGE_STEER_BOTH: bit 1 = the walk completed (see edge_check_kernel)
+      if (tid == 0) RKH_IO(accept)[e] = (ok ? 1 : 0) | ((mode == EDGE_STEER_BOTH && completed_walk) ? 2 : 0);
+    } else if (mode == EDGE_GOAL_PROBE) {
+      // interp_topo_get_distance_pred (interpolated_topologies.hpp:193-199)
+      if (tid == 0) {
+        const uint32_t* src_idx = RKH_IO(src_idx);
+        const uint32_t* d_src_first = RKH_IO(d_src_first);
+        const uint32_t si = src_idx ? src_idx[e] : ((d_src_first ? *d_src_first : 0u) + e);
+        RKH_IO(goal_dist)[si - 1] = (n_rb < DBL_EPSILON) ? n_ab : INFINITY;
+      }
+    } else if (mode == EDGE_CONNECT) {
+      // planning_visitor_base::can_be_connected (planning_visitors.hpp:385-395); steer_tol carries the connection tolerance
+      const bool ok = (!isinf(n_ar)) && (n_rb < steer_tol * n_ar);
+      if (tid == 0) RKH_IO(accept)[e] = ok ? 1 : 0;
+    } else if (mode == EDGE_WALK_ACCEPT) {
+      // planning_visitor_base::random_walk (planning_visitors.hpp:418-421)
+      const bool ok = (!isinf(n_ar)) && (n_ar > steer_tol * RKH_IO(best_case)[e]);
+      if (tid == 0) RKH_IO(accept)[e] = ok ? 1 : 0;
+    }
+  }
+#undef RKH_IO
 }
 
 // Diagnostic kernel (not on the product path): `iters` back-to-back f-evals + proximity tests of one edge per
@@ -1259,6 +1754,57 @@ rkh_status launch_state_derivative(hipStream_t s, int n_dof, const SceneDev* d_s
   return RKH_OK;
 }
 
+static std::unordered_set<const void*>& mesh_scenes() {
+  static std::unordered_set<const void*> s;
+  return s;
+}
+void register_mesh_scene(const SceneDev* d_scene) { mesh_scenes().insert(d_scene); }
+void forget_mesh_scene(const SceneDev* d_scene) { mesh_scenes().erase(d_scene); }
+bool is_mesh_scene(const SceneDev* d_scene) { return mesh_scenes().count(d_scene) != 0; }
+
+// The shape of an edge_check_kernel launch, by the number of edges and by what fits 64 KB of LDS -- 0: GL 16 x 1 wave,
+// 1: GL 16 x 4 waves, 2: GL 16 x 2 waves, 3: GL 16 x 8 waves -- and whether the pair list rides in LDS too.
+template <int N>
+static void edge_check_shape(int n_env, int n_pairs, uint64_t n_edges, int* shape, int* staged) {
+  auto fit = [&](size_t with_pairs, size_t without) { return with_pairs <= 65536 ? 2 : (without <= 65536 ? 1 : 0); };
+  const int f1 = fit(SmemLayoutQsW<N, 16, 1>::bytes(n_env, n_pairs), SmemLayoutQsW<N, 16, 1>::bytes(n_env, 0));
+  const int f2 = fit(SmemLayoutQsW<N, 16, 2>::bytes(n_env, n_pairs), SmemLayoutQsW<N, 16, 2>::bytes(n_env, 0));
+  const int f4 = fit(SmemLayoutQsW<N, 16, 4>::bytes(n_env, n_pairs), SmemLayoutQsW<N, 16, 4>::bytes(n_env, 0));
+  const int f8 = fit(SmemLayoutQsW<N, 16, 8>::bytes(n_env, n_pairs), SmemLayoutQsW<N, 16, 8>::bytes(n_env, 0));
+  *shape = 0;
+  *staged = f1 == 2;
+  if (n_edges < 4096) {
+    if (f4) *shape = 1, *staged = f4 == 2;
+    else if (f2) *shape = 2, *staged = f2 == 2;
+  }
+  if (n_edges < 512 && f8) *shape = 3, *staged = f8 == 2;
+}
+
+template <int N, bool GJK>
+static rkh_status launch_edge_points_t(hipStream_t s, dim3 grid, size_t smem, const SceneDev* d_scene, const PairDev* pp,
+                                       int n_pairs, const QsDev& qs, const EdgeIO& io, const EdgeIO& second,
+                                       const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t grid_a, int staged) {
+  auto kern = edge_points_kernel<N, GJK>;
+  EdgePointsArgs ka;
+  ka.sc = d_scene;
+  ka.pairs = pp;
+  ka.n_pairs = n_pairs;
+  ka.qs = qs;
+  ka.io_a = io;
+  ka.io_b = second;
+  ka.tab_a = tab_a;
+  ka.tab_b = tab_b;
+  ka.grid_a = grid_a;
+  ka.pairs_staged = staged;
+  static bool big_lds = false;  // (per instantiation) more than the default 64 KB of dynamic LDS: ask once
+  if (smem > 65536 && !big_lds) {
+    RKH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    big_lds = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, ka);
+  return RKH_OK;
+}
+
 rkh_status launch_edge_check(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                              int n_pairs, const QsDev& qs, const EdgeIO& io, uint32_t grid_edges, const EdgeIO* io_b,
                              uint32_t grid_b, const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems) {
@@ -1266,25 +1812,45 @@ rkh_status launch_edge_check(hipStream_t s, int n_dof, int n_env, const SceneDev
   if (grid_edges + eb == 0 || n_problems == 0) return RKH_OK;
   const EdgeIO second = io_b ? *io_b : EdgeIO();
   const PairDev* pp = static_cast<const PairDev*>(d_pairs);
+  const bool gjk = is_mesh_scene(d_scene);  // scenes without vertex-set shapes run the instantiations without GJK (no scratch)
+  static const bool by_points = [] { const char* e = getenv("RKH_EDGE_POINTS"); return !e || atoi(e) != 0; }();
+  if (by_points && !is_planar_scene(d_scene)) {  // 3D scenes: one lane per point in the chain kinematics
+    size_t with_pairs = 0, without = 0;
+    RKH_DISPATCH_N_QS(n_dof, (with_pairs = EdgePointsSmem<N>::bytes(n_env, n_pairs), without = EdgePointsSmem<N>::bytes(n_env, 0)));
+    const size_t lds_max = 160 * 1024;
+    if (without <= lds_max) {
+      const int staged = with_pairs <= lds_max;
+      const size_t smem = staged ? with_pairs : without;
+      rkh_status st = RKH_OK;
+      if (gjk) {
+        RKH_DISPATCH_N_QS(n_dof, (st = launch_edge_points_t<N, true>(s, dim3(grid_edges + eb, n_problems), smem, d_scene, pp, n_pairs,
+                                                                     qs, io, second, tab_a, tab_b, grid_edges, staged)));
+      } else {
+        RKH_DISPATCH_N_QS(n_dof, (st = launch_edge_points_t<N, false>(s, dim3(grid_edges + eb, n_problems), smem, d_scene, pp, n_pairs,
+                                                                      qs, io, second, tab_a, tab_b, grid_edges, staged)));
+      }
+      if (st != RKH_OK) return st;
+      RKH_HIP(hipGetLastError());
+      return RKH_OK;
+    }
+  }
   // the shape of the launch (see edge_check_kernel): by the number of edges, and by what fits 64 KB of LDS
   const uint64_t n_edges = uint64_t(grid_edges + eb) * n_problems;
-  int shape = 0;  // 0: GL 16 x 1 wave, 1: GL 16 x 4 waves, 2: GL 16 x 2 waves, 3: GL 16 x 8 waves
-  if (n_edges < 4096) {
-    RKH_DISPATCH_N_QS(n_dof, shape = (SmemLayoutQsW<N, 16, 4>::bytes(n_env) <= 65536) ? 1
-                                     : ((SmemLayoutQsW<N, 16, 2>::bytes(n_env) <= 65536) ? 2 : 0));
-  }
-  if (n_edges < 512) {
-    RKH_DISPATCH_N_QS(n_dof, shape = (SmemLayoutQsW<N, 16, 8>::bytes(n_env) <= 65536) ? 3 : shape);
-  }
-#define RKH_EDGE_LAUNCH(GL_, W_)                                                                                          \
-  RKH_DISPATCH_N_QS(n_dof, hipLaunchKernelGGL((edge_check_kernel<N, GL_, W_>), dim3(grid_edges + eb, n_problems),         \
-                                           dim3(64 * W_), (SmemLayoutQsW<N, GL_, W_>::bytes(n_env)), s, d_scene, pp, n_pairs, \
-                                           qs, io, second, tab_a, tab_b, grid_edges))
-  switch (shape) {
-    case 1: RKH_EDGE_LAUNCH(16, 4); break;
-    case 2: RKH_EDGE_LAUNCH(16, 2); break;
-    case 3: RKH_EDGE_LAUNCH(16, 8); break;
-    default: RKH_EDGE_LAUNCH(16, 1); break;
+  int shape = 0, staged = 0;
+  RKH_DISPATCH_N_QS(n_dof, (edge_check_shape<N>(n_env, n_pairs, n_edges, &shape, &staged)));
+#define RKH_EDGE_LAUNCH(GL_, W_, GJK_)                                                                                          \
+  RKH_DISPATCH_N_QS(n_dof, hipLaunchKernelGGL((edge_check_kernel<N, GL_, W_, GJK_>), dim3(grid_edges + eb, n_problems),   \
+                                           dim3(64 * W_), (SmemLayoutQsW<N, GL_, W_>::bytes(n_env, staged ? n_pairs : 0)), s, \
+                                           d_scene, pp, n_pairs, qs, io, second, tab_a, tab_b, grid_edges, staged))
+  switch (shape + (gjk ? 4 : 0)) {
+    case 1: RKH_EDGE_LAUNCH(16, 4, false); break;
+    case 2: RKH_EDGE_LAUNCH(16, 2, false); break;
+    case 3: RKH_EDGE_LAUNCH(16, 8, false); break;
+    case 0: RKH_EDGE_LAUNCH(16, 1, false); break;
+    case 5: RKH_EDGE_LAUNCH(16, 4, true); break;
+    case 6: RKH_EDGE_LAUNCH(16, 2, true); break;
+    case 7: RKH_EDGE_LAUNCH(16, 8, true); break;
+    default: RKH_EDGE_LAUNCH(16, 1, true); break;
   }
 #undef RKH_EDGE_LAUNCH
   RKH_HIP(hipGetLastError());

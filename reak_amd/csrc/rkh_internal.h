@@ -344,6 +344,10 @@ size_t propagate_pairs_workspace_bytes(int n_dof, uint32_t edges_a, uint32_t edg
 void register_planar_scene(const SceneDev* d_scene);
 void forget_planar_scene(const SceneDev* d_scene);
 bool is_planar_scene(const SceneDev* d_scene);
+// scenes with vertex-set shapes (PR_GJK pairs); the others may run kernels compiled without the support-map query
+void register_mesh_scene(const SceneDev* d_scene);
+void forget_mesh_scene(const SceneDev* d_scene);
+bool is_mesh_scene(const SceneDev* d_scene);
 rkh_status launch_propagate_planar(hipStream_t s, int n_dof, const SceneDev* d_scene, const void* d_pairs, int n_pairs,
                                    const DynDev& dyn, const EdgeIO& io, uint32_t grid_edges, const EdgeIO* io_b,
                                    uint32_t grid_b, const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems,

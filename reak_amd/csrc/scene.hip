@@ -174,6 +174,7 @@ static rkh_status upload_scene(rkh_ctx* ctx, rkh_scene* sc, const std::vector<Pa
   RKH_HIP(hipMalloc(&sc->d_err, sizeof(int)));
   RKH_HIP(hipMemset(sc->d_err, 0, sizeof(int)));
   if (S.planar) register_planar_scene(sc->d_scene);
+  if (S.has_meshes) register_mesh_scene(sc->d_scene);
   *out = sc;
   return RKH_OK;
 }
@@ -613,6 +614,7 @@ rkh_status rkh_diag_gjk_distance(rkh_ctx* ctx, const rkh_shape* a, const rkh_sha
 rkh_status rkh_scene_destroy(rkh_scene* scene) {
   if (!scene) return RKH_OK;
   forget_planar_scene(scene->d_scene);  // (a later allocation may get the same address)
+  forget_mesh_scene(scene->d_scene);
   hipFree(scene->d_scene);
   hipFree(scene->d_pairs);
   if (scene->d_mesh_verts) hipFree(scene->d_mesh_verts);

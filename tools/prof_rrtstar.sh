@@ -6,7 +6,7 @@ TAG=${1:-r03_rs}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d /tmp/prof_$TAG -o rs -- python $ROOT/tests/diag_rrtstar_large.py 20000 1 > $OUT/run.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d /tmp/prof_$TAG -o rs -- python $ROOT/tests/diag_rrtstar_large.py 20000 ${2:-1} > $OUT/run.log 2>&1
 echo rc=$?; grep "RRT" $OUT/run.log
 F=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" < /dev/null | head -1); cp "$F" $OUT/kernel_stats.csv; cut -c1-150 "$F" | head -14
 T=$(find /tmp/prof_$TAG -name "*kernel_trace.csv" < /dev/null | head -1)
