@@ -1244,15 +1244,14 @@ __global__ __launch_bounds__(64 * W) void edge_check_kernel(const SceneDev* __re
 // a wave = consecutive points = consecutive addresses).  Same arithmetic per point as edge_check_kernel (the same
 // device functions in the same order), so n_checked, results and verdicts are the same bits; planar scenes, whose
 // verdict depends on the finder order, stay on edge_check_kernel.
-template <int N>
 struct EdgePointsCfg {
-  static constexpr int G = N <= 7 ? 64 : 32;   // points per pass
   static constexpr int T = 256;                // threads per block
   static constexpr int QCAP = 1024;            // surviving (point, pair) combinations per round of closed forms
 };
-template <int N>
+// G = points per pass: 64 for the launches of few edges (the step waits for its longest walk), 32 for the launches of
+// thousands of edges (half the LDS, three blocks per CU) and for chains of more than 7 joints
+template <int N, int G>
 struct __attribute__((aligned(16))) EdgePointsLds {
-  static constexpr int G = EdgePointsCfg<N>::G;
   JointLds joints[N];
   double base[10];
   ShapeDev robot[2 * N];
@@ -1264,11 +1263,11 @@ struct __attribute__((aligned(16))) EdgePointsLds {
   uint32_t flags[G];              // bit 0: to be tested (on the edge, inside the bounds), bit 1: a pair closer than 0, bit 2: on the edge
   uint32_t q_cnt;
   uint32_t scan[2];               // first point that fails the predicate, points on the edge
-  uint32_t queue[EdgePointsCfg<N>::QCAP];
+  uint32_t queue[EdgePointsCfg::QCAP];
 };
-template <int N>
+template <int N, int G>
 struct EdgePointsSmem {
-  static constexpr size_t block_bytes = (sizeof(EdgePointsLds<N>) + 15) / 16 * 16;
+  static constexpr size_t block_bytes = (sizeof(EdgePointsLds<N, G>) + 15) / 16 * 16;
   static size_t bytes(int n_env, int n_pairs_staged) {
     return block_bytes + size_t(n_env) * sizeof(ShapeDev) + size_t(n_pairs_staged) * sizeof(PairDev);
   }
@@ -1286,7 +1285,7 @@ struct EdgePointsArgs {
   int pairs_staged;
 };
 typedef const __attribute__((address_space(4))) EdgePointsArgs* EdgePointsArgP;
-template <int N, bool GJK>
+template <int N, bool GJK, int G>
 __global__ __launch_bounds__(256) void edge_points_kernel(EdgePointsArgs) {
   // arguments are read through the kernarg segment pointer (a by-value record indexed at run time -- qs.speed[j], the
   // choice between io_a and io_b -- would be copied to scratch)
@@ -1299,9 +1298,9 @@ __global__ __launch_bounds__(256) void edge_points_kernel(EdgePointsArgs) {
   const EdgeIO* __restrict__ tab_b = ka->tab_b;
   const auto& qs = ka->qs;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int G = EdgePointsCfg<N>::G, T = EdgePointsCfg<N>::T, QCAP = EdgePointsCfg<N>::QCAP;
-  EdgePointsLds<N>& lds = *reinterpret_cast<EdgePointsLds<N>*>(smem_raw);
-  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + EdgePointsSmem<N>::block_bytes);
+  constexpr int T = EdgePointsCfg::T, QCAP = EdgePointsCfg::QCAP;
+  EdgePointsLds<N, G>& lds = *reinterpret_cast<EdgePointsLds<N, G>*>(smem_raw);
+  ShapeDev* env_lds = reinterpret_cast<ShapeDev*>(smem_raw + EdgePointsSmem<N, G>::block_bytes);
   const bool group_b = blockIdx.x >= grid_a;
   const EdgeIO* iop = tab_a ? (group_b ? &tab_b[blockIdx.y] : &tab_a[blockIdx.y]) : nullptr;
   const __attribute__((address_space(4))) EdgeIO* iok = group_b ? &ka->io_b : &ka->io_a;
@@ -1780,11 +1779,11 @@ static void edge_check_shape(int n_env, int n_pairs, uint64_t n_edges, int* shap
   if (n_edges < 512 && f8) *shape = 3, *staged = f8 == 2;
 }
 
-template <int N, bool GJK>
+template <int N, bool GJK, int G>
 static rkh_status launch_edge_points_t(hipStream_t s, dim3 grid, size_t smem, const SceneDev* d_scene, const PairDev* pp,
                                        int n_pairs, const QsDev& qs, const EdgeIO& io, const EdgeIO& second,
                                        const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t grid_a, int staged) {
-  auto kern = edge_points_kernel<N, GJK>;
+  auto kern = edge_points_kernel<N, GJK, G>;
   EdgePointsArgs ka;
   ka.sc = d_scene;
   ka.pairs = pp;
@@ -1815,20 +1814,34 @@ rkh_status launch_edge_check(hipStream_t s, int n_dof, int n_env, const SceneDev
   const bool gjk = is_mesh_scene(d_scene);  // scenes without vertex-set shapes run the instantiations without GJK (no scratch)
   static const bool by_points = [] { const char* e = getenv("RKH_EDGE_POINTS"); return !e || atoi(e) != 0; }();
   if (by_points && !is_planar_scene(d_scene)) {  // 3D scenes: one lane per point in the chain kinematics
+    const bool narrow = n_dof > 7 || uint64_t(grid_edges + eb) * n_problems >= 2048;  // 32 points per pass
     size_t with_pairs = 0, without = 0;
-    RKH_DISPATCH_N_QS(n_dof, (with_pairs = EdgePointsSmem<N>::bytes(n_env, n_pairs), without = EdgePointsSmem<N>::bytes(n_env, 0)));
+    if (narrow) {
+      RKH_DISPATCH_N_QS(n_dof, (with_pairs = EdgePointsSmem<N, 32>::bytes(n_env, n_pairs), without = EdgePointsSmem<N, 32>::bytes(n_env, 0)));
+    } else {
+      RKH_DISPATCH_N_QS(n_dof, (with_pairs = EdgePointsSmem<N, 64>::bytes(n_env, n_pairs), without = EdgePointsSmem<N, 64>::bytes(n_env, 0)));
+    }
     const size_t lds_max = 160 * 1024;
     if (without <= lds_max) {
       const int staged = with_pairs <= lds_max;
       const size_t smem = staged ? with_pairs : without;
       rkh_status st = RKH_OK;
-      if (gjk) {
-        RKH_DISPATCH_N_QS(n_dof, (st = launch_edge_points_t<N, true>(s, dim3(grid_edges + eb, n_problems), smem, d_scene, pp, n_pairs,
-                                                                     qs, io, second, tab_a, tab_b, grid_edges, staged)));
+      const dim3 grid(grid_edges + eb, n_problems);
+#define RKH_POINTS_ARGS s, grid, smem, d_scene, pp, n_pairs, qs, io, second, tab_a, tab_b, grid_edges, staged
+      if (narrow) {
+        if (gjk) {
+          RKH_DISPATCH_N_QS(n_dof, (st = launch_edge_points_t<N, true, 32>(RKH_POINTS_ARGS)));
+        } else {
+          RKH_DISPATCH_N_QS(n_dof, (st = launch_edge_points_t<N, false, 32>(RKH_POINTS_ARGS)));
+        }
       } else {
-        RKH_DISPATCH_N_QS(n_dof, (st = launch_edge_points_t<N, false>(s, dim3(grid_edges + eb, n_problems), smem, d_scene, pp, n_pairs,
-                                                                      qs, io, second, tab_a, tab_b, grid_edges, staged)));
+        if (gjk) {
+          RKH_DISPATCH_N_QS(n_dof, (st = launch_edge_points_t<N, true, (N <= 7 ? 64 : 32)>(RKH_POINTS_ARGS)));
+        } else {
+          RKH_DISPATCH_N_QS(n_dof, (st = launch_edge_points_t<N, false, (N <= 7 ? 64 : 32)>(RKH_POINTS_ARGS)));
+        }
       }
+#undef RKH_POINTS_ARGS
       if (st != RKH_OK) return st;
       RKH_HIP(hipGetLastError());
       return RKH_OK;
@@ -1842,14 +1855,11 @@ rkh_status launch_edge_check(hipStream_t s, int n_dof, int n_env, const SceneDev
   RKH_DISPATCH_N_QS(n_dof, hipLaunchKernelGGL((edge_check_kernel<N, GL_, W_, GJK_>), dim3(grid_edges + eb, n_problems),   \
                                            dim3(64 * W_), (SmemLayoutQsW<N, GL_, W_>::bytes(n_env, staged ? n_pairs : 0)), s, \
                                            d_scene, pp, n_pairs, qs, io, second, tab_a, tab_b, grid_edges, staged))
-  switch (shape + (gjk ? 4 : 0)) {
-    case 1: RKH_EDGE_LAUNCH(16, 4, false); break;
-    case 2: RKH_EDGE_LAUNCH(16, 2, false); break;
-    case 3: RKH_EDGE_LAUNCH(16, 8, false); break;
-    case 0: RKH_EDGE_LAUNCH(16, 1, false); break;
-    case 5: RKH_EDGE_LAUNCH(16, 4, true); break;
-    case 6: RKH_EDGE_LAUNCH(16, 2, true); break;
-    case 7: RKH_EDGE_LAUNCH(16, 8, true); break;
+  // (planar scenes, and 3D ones with RKH_EDGE_POINTS=0: one instantiation per shape, support-map query included)
+  switch (shape) {
+    case 1: RKH_EDGE_LAUNCH(16, 4, true); break;
+    case 2: RKH_EDGE_LAUNCH(16, 2, true); break;
+    case 3: RKH_EDGE_LAUNCH(16, 8, true); break;
     default: RKH_EDGE_LAUNCH(16, 1, true); break;
   }
 #undef RKH_EDGE_LAUNCH
