@@ -577,7 +577,7 @@ __device__ __forceinline__ void proximity_frames(const SceneDev* __restrict__ sc
   __syncthreads();
 }
 
-template <int N, int GL, typename WS>
+template <int N, int GL, typename WS, bool GJK = true>
 __device__ double proximity_min(const SceneDev* __restrict__ sc, const CPack<N>& cp,
                                 const double* __restrict__ base, const ShapeDev* __restrict__ env_lds,
                                 const PairDev* __restrict__ pairs, int n_pairs, WS& ws,
@@ -611,7 +611,7 @@ __device__ double proximity_min(const SceneDev* __restrict__ sc, const CPack<N>&
         const double r2 = pr.s1_is_robot ? es.brad : rs.brad;
         skip = (norm_2(c2p - c1) - r1 - r2 > 0.0);
       }
-      if (!skip) d = pr.s1_is_robot ? pair_distance(pr.routine, A, Bv, sc->mesh_verts) : pair_distance(pr.routine, Bv, A, sc->mesh_verts);
+      if (!skip) d = pr.s1_is_robot ? pair_distance<GJK>(pr.routine, A, Bv, sc->mesh_verts) : pair_distance<GJK>(pr.routine, Bv, A, sc->mesh_verts);
     }
     if (d < dmin) dmin = d;
     if (cull_positive) {
@@ -678,7 +678,7 @@ RKH_DI WaveArgP wave_args() {
 // previous round's goal probes); 64/GL edges per wave.
 // GL = 64 (one wave per edge, the latency mapping: rounds of fewer waves than the chip has SIMDs) may use the whole
 // register file of its SIMD; four edges per wave (GL = 16) is the throughput form and keeps two waves per SIMD.
-template <int N, int GL>
+template <int N, int GL, bool GJK>
 __global__ __launch_bounds__(64, GL == 64 ? 1 : 2) void propagate_kernel(WaveArgs) {
   // Every argument is read through the kernarg segment pointer at its point of use (by-value parameters are loaded in the
   // entry block and stay live in scalar registers; once those run out they are spilled into vector-register lanes, and
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(64, GL == 64 ? 1 : 2) void propagate_kernel(WaveArg
     bool free_pt = gm == 0ull;
     if (gl < D) ws.x[gl] = x;
     __syncthreads();
-    const double dmin = proximity_min<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true, !free_pt);
+    const double dmin = proximity_min<N, GL, GroupWs<N>, GJK>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true, !free_pt);
     if (dmin < 0.0) free_pt = false;
     if (edge_valid && gl == 0) edge_io()->accept[e] = free_pt ? 1 : 0;
   }
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(64, GL == 64 ? 1 : 2) void propagate_kernel(WaveArg
     if (!__any(alive)) break;
     if (gl < D) ws.x[gl] = xe;
     __syncthreads();
-    const double dmin = proximity_min<N, GL>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true, !alive);
+    const double dmin = proximity_min<N, GL, GroupWs<N>, GJK>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true, !alive);
     if (dmin < 0.0) alive = false;
     if (alive) {
       x = xe;
@@ -1685,7 +1685,7 @@ __global__ __launch_bounds__(64) void min_distance_kernel(const SceneDev* __rest
       return RKH_ERR_UNSUPPORTED;    \
   }
 
-template <int N, int GL>
+template <int N, int GL, bool GJK>
 static void launch_propagate_t(hipStream_t s, int n_env, const SceneDev* d_scene, const PairDev* d_pairs, int n_pairs,
                                const DynDev& dyn, const EdgeIO& io, uint32_t edges_a, const EdgeIO& io_b,
                                uint32_t edges_b, const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems,
@@ -1710,7 +1710,7 @@ static void launch_propagate_t(hipStream_t s, int n_env, const SceneDev* d_scene
   args.tab_b = tab_b;
   args.grid_a = ga;
   args.gate = gate;
-  hipLaunchKernelGGL((propagate_kernel<N, GL>), grid, dim3(64), (SmemLayout<N, GL>::bytes(n_env)), s, args);
+  hipLaunchKernelGGL((propagate_kernel<N, GL, GJK>), grid, dim3(64), (SmemLayout<N, GL>::bytes(n_env)), s, args);
 }
 
 // Steer `grid_edges` (+ `grid_b` of a second group) edges per problem.  Either the two EdgeIO are given by value
@@ -1733,11 +1733,14 @@ rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev*
   const EdgeIO second = io_b ? *io_b : EdgeIO();
   const PairDev* pp = static_cast<const PairDev*>(d_pairs);
   if (lanes_per_edge == 16) {
-    RKH_DISPATCH_N(n_dof, (launch_propagate_t<N, 16>(s, n_env, d_scene, pp, n_pairs, dyn, io, grid_edges, second, eb, tab_a,
-                                                     tab_b, n_problems, gate)));
-  } else {
-    RKH_DISPATCH_N(n_dof, (launch_propagate_t<N, 64>(s, n_env, d_scene, pp, n_pairs, dyn, io, grid_edges, second, eb, tab_a,
-                                                     tab_b, n_problems, gate)));
+    RKH_DISPATCH_N(n_dof, (launch_propagate_t<N, 16, true>(s, n_env, d_scene, pp, n_pairs, dyn, io, grid_edges, second, eb, tab_a,
+                                                           tab_b, n_problems, gate)));
+  } else if (is_mesh_scene(d_scene)) {
+    RKH_DISPATCH_N(n_dof, (launch_propagate_t<N, 64, true>(s, n_env, d_scene, pp, n_pairs, dyn, io, grid_edges, second, eb, tab_a,
+                                                           tab_b, n_problems, gate)));
+  } else {  // no vertex-set shapes: the instantiation without the support-map query (no private segment)
+    RKH_DISPATCH_N(n_dof, (launch_propagate_t<N, 64, false>(s, n_env, d_scene, pp, n_pairs, dyn, io, grid_edges, second, eb, tab_a,
+                                                            tab_b, n_problems, gate)));
   }
   RKH_HIP(hipGetLastError());
   return RKH_OK;

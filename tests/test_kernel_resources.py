@@ -35,6 +35,19 @@ def test_throughput_steer_kernels_hold_two_waves_per_simd_without_scratch(res):
     assert res["rkh::propagate_pair_step_kernel<6>"]["group_segment_fixed_size"] == 20272
 
 
+def test_latency_kernels_of_scenes_without_vertex_sets_do_not_spill(res):
+    """The one-wave-per-edge steer kernel (small rounds, single problems) and the quasi-static edge walk (graph planners)
+    as instantiated for scenes without vertex-set shapes: no spilled registers, (next to) no private segment -- the
+    support-map query's run-time-indexed simplex arrays are what needs one, and only the `true` instantiations carry it."""
+    d = res["rkh::propagate_kernel<6, 64, false>"]
+    assert d["vgpr_spill_count"] == 0 and d["private_segment_fixed_size"] <= 64, d
+    for g in (32, 64):
+        d = res[f"rkh::edge_points_kernel<6, false, {g}>"]
+        assert d["vgpr_count"] <= 256 and d["vgpr_spill_count"] == 0 and d["private_segment_fixed_size"] == 0, d
+    d = res["rkh::edge_points_kernel<12, false, 32>"]
+    assert d["vgpr_count"] <= 256 and d["vgpr_spill_count"] == 0 and d["private_segment_fixed_size"] == 0, d
+
+
 def test_committed_resource_table_matches_the_build(res):
     """profiles/r03_kernel_resources.txt is the table the documents cite: its rows for the steer and NN kernels must be
     what the current sources compile to (regenerate with `python tools/kernel_resources.py --out ...`)."""
@@ -47,7 +60,7 @@ def test_committed_resource_table_matches_the_build(res):
         rows[name] = [int(x) for x in rest]
     checked = 0
     for k, d in res.items():
-        if not any(t in k for t in ("propagate_pair", "propagate_kernel<6", "nn1_sweep_bf16_kernel<12>", "edge_check_kernel<6")):
+        if not any(t in k for t in ("propagate_pair", "propagate_kernel<6", "nn1_mirror_kernel", "edge_points_kernel<6")):
             continue
         got = [d["vgpr_count"], d["agpr_count"], d["vgpr_spill_count"], d["sgpr_count"], d["private_segment_fixed_size"],
                d["group_segment_fixed_size"]]
