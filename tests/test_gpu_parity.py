@@ -434,6 +434,46 @@ def test_edge_check_matches_interp_topo_walk(L, ctx, oracle):
     assert 0.1 < full.mean() < 0.95              # both blocked and complete edges occur
 
 
+def test_edge_walks_in_a_scene_whose_bounding_spheres_nearly_all_overlap(L, ctx, oracle):
+    """The lane-per-point edge walk (edge_points_kernel) queues the (point, pair) combinations that survive the
+    bounding-sphere cull and runs their closed forms one per thread; when more survive than the queue holds it redoes
+    the pair list in slices.  Forty thin rods of length 1.6 around the C3 arm have bounding spheres that reach across the
+    whole workspace while the rods themselves are rarely touched: ~64 points x several hundred surviving pairs per pass,
+    far beyond the queue's 1024 entries.  Number of predicate calls and returned points against the oracle's walk,
+    for 64 and (a launch of thousands of edges) 32 points per pass."""
+    import copy
+
+    c3 = scenarios.make_c3(1)
+    rng = np.random.default_rng(77)
+    scn = copy.copy(c3)
+    rods = []
+    for _ in range(40):
+        s = T.Shape(kind=T.SHAPE_CCYLINDER, anchor=-1)
+        q = rng.normal(size=4)
+        s.pose = T.make_pose(rng.uniform(-0.9, 0.9, size=3), q / np.linalg.norm(q))
+        s.dims[:] = (1.6, 0.01, 0.0)
+        rods.append(s)
+    scn.shapes = list(c3.shapes) + rods
+    sc, osc = L.Scene(ctx, scn), oracle.OracleScene(scn)
+    lo, hi, mi = c3.meta["lower"], c3.meta["upper"], c3.meta["min_interval"]
+    n = sc.n
+    a = rng.uniform(-1.2, 1.2, size=(4000, n))
+    x = np.zeros((len(a), 2 * n)); x[:, 0::2] = a
+    a = a[osc.min_distance(x) > 0.0]
+    assert len(a) >= 300
+    b = rng.uniform(lo, hi, size=(len(a), n))
+    for count in (96, len(a)):       # a launch of few edges: 64 points per pass; of >= 2048: 32 (pad by repetition)
+        aa, bb = a[:count], b[:count]
+        if count == len(a):
+            reps = (2100 + count - 1) // count
+            aa, bb = np.tile(aa, (reps, 1)), np.tile(bb, (reps, 1))
+        out, nchk = sc.move_position_toward(lo, hi, mi, aa, bb)
+        rout, rnchk = osc.qs_move(lo, hi, mi, aa[:count], bb[:count])
+        assert np.array_equal(nchk[:count], rnchk) and np.array_equal(out[:count], rout)
+        assert np.array_equal(nchk, np.tile(rnchk, len(aa) // count)[: len(aa)])
+    assert nchk.max() > 64 and (np.all(rout == b[: len(rout)], axis=1)).mean() > 0.05
+
+
 # ------------------------------------------------------------------ planner
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_rrt_tree_identical_to_sequential_planner(L, ctx, oracle, c2, seed):
