@@ -342,7 +342,7 @@ struct GraphBatch {
     off_anchk = up8(off_xout + size_t(emax) * D * 8);
     off_aaccept = off_anchk + kGbStageA * 4;
     off_axout = up8(off_aaccept + kGbStageA);
-    res_stride = up8(off_axout + size_t(kGbStageA) * D * 8);
+    res_stride = (off_axout + size_t(kGbStageA) * D * 8 + 15) / 16 * 16;  // gb_download_kernel moves 16-byte words
     RKH_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_res), res_stride * P, hipHostMallocDefault));
     RKH_HIP(hipMalloc(reinterpret_cast<void**>(&d_res), res_stride * P));
     RKH_HIP(hipMemset(d_res, 0, res_stride * P));
