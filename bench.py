@@ -26,6 +26,8 @@ Extra objects on the JSON line:
   steer_kernels the dominant kernels of the timed region: share of the step time, edges/s inside the kernel, fp64
                 operation rate against the no-FMA VALU peak with the EXACT operation count of one f-eval as the restated
                 reference performs it (oracle/flop_count.cpp; `useful` = without its products over structural zeros)
+  collide       the proximity test inside the steer kernels: (robot shape, obstacle) pair tests per second
+                before culling, and the fraction each stage lets through (static reach, bounding cull, closed forms)
   single_problem  P = 1 and P = 16 (one / sixteen problems per GPU, 20 000 vertices each), outside the timed region
   cpu_baseline  the CPU oracle (restatement of the reference planner, -O3 -march=native) on a bounded sample of the
                 same workload, single thread like ReaK itself; host CPU model and core count stated
@@ -387,6 +389,39 @@ def single_problem_rate(lib, scene, scn, P, max_vertices):
     pl.close()
     return {"problems": P, "max_vertices": max_vertices, "value": nodes / dt, "unit": "valid node expansions/s",
             "edges_collision_checked_per_s": edges / dt, "seconds": dt}
+
+
+def collide_counts(lib, scene, scn, configs_per_s):
+    """SURVEY 8(d) `collide`: pair tests per second of the steer kernels' proximity test and what each stage of it culls.
+    The stage counts come from a diagnostic launch of the same proximity code (rkh_diag_proximity_counts) on the vertices
+    of a 20 000-vertex tree of this world -- collision-free states, where the kernels spend their tests; the rate is the
+    configurations the timed region tested (one per executed RK4 step) x the scene's proxy pairs."""
+    pl = lib.RrtPlanner(scene, scn.rrt_params(seed=7000, max_vertices=20000))
+    pl.solve_planning_query()
+    states = pl.tree()["pos"]
+    pl.close()
+    c = scene.proximity_counts(states)
+    per = float(c["states"]) * c["pairs_per_state"]
+    # the same counts on states drawn uniformly from the state box: what the cull lets through when the arm is anywhere
+    rng = np.random.default_rng(3)
+    lo = np.array([scn.dyn.lower[i] for i in range(2 * scn.n_dof)])
+    hi = np.array([scn.dyn.upper[i] for i in range(2 * scn.n_dof)])
+    u = scene.proximity_counts(rng.uniform(lo, hi, size=(65536, 2 * scn.n_dof)))
+    uper = float(u["states"]) * u["pairs_per_state"]
+    uniform = {"states": u["states"], "fraction_past_bounding_cull": u["pairs_past_cull"] / uper,
+               "fraction_closed_form": u["closed_forms"] / uper, "fraction_golden_section": u["golden_section"] / uper,
+               "states_in_collision": u["states_in_collision"] / float(u["states"])}
+    return {"pair_tests_per_s": configs_per_s * c["pairs_per_state"], "configurations_per_s": configs_per_s,
+            "uniform_states": uniform,
+            "pairs_per_configuration": c["pairs_per_state"],
+            "fraction_within_static_reach": c["pairs_in_static_reach"] / max(1, c["pairs_per_state"]),
+            "fraction_past_bounding_cull": c["pairs_past_cull"] / per, "fraction_closed_form": c["closed_forms"] / per,
+            "fraction_golden_section": c["golden_section"] / per, "culled_fraction": 1.0 - c["pairs_past_cull"] / per,
+            "sample": "%d vertices of a 20000-vertex tree of the same world (%d of them in collision by the diagnostic "
+                      "launch)" % (c["states"], c["states_in_collision"]),
+            "note": "pair tests = (robot shape, obstacle) pairs of the scene x configurations tested by the steer kernels in "
+                    "the timed region, before any culling (SURVEY 8(d)); stages: static reach prefix -> fp32 bounding cull -> "
+                    "closed forms (capped cylinder / box pairs: separating-axis screen, then the golden-section search)"}
 
 
 def c3_rrtstar_rate(lib, ctx, events, P=16, max_vertices=20000, knn_n=1 << 20):
@@ -795,6 +830,8 @@ def main():
         if not args.no_microbench and world == 1:
             out["single_problem"] = [single_problem_rate(lib, scene, scn, 1, 20000),
                                      single_problem_rate(lib, scene, scn, 16, 20000)]
+            if tot["steer_ms"] > 0:
+                out["collide"] = collide_counts(lib, scene, scn, tot["steer_steps"] / (tot["steer_ms"] * 1e-3))
             out["c3_rrtstar"] = c3_rrtstar_rate(lib, ctx, events)
             out["c4_prm_meshes"] = c4_prm_rate(lib, ctx)
         if not args.no_cpu_baseline and world == 1:

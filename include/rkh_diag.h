@@ -51,6 +51,13 @@ rkh_status rkh_planner_steer_profile(rkh_planner* p, double* total_ms, uint64_t*
  * free (MEAQR_topology.hpp:550-559).  (The first-generation lane kernel, RKH_LANE_VARIANT=1, does not count.) */
 rkh_status rkh_planner_steer_steps(rkh_planner* p, uint64_t* executed_steps);
 
+/* The proximity test of the two-lanes steer kernels on B states (2 n_dof doubles each), counting what reaches each of
+ * its stages ("collide"): counts[0] = states tested, [1] = (robot shape, obstacle) pairs that pass the
+ * static reach and the bounding cull, [2] = closed forms evaluated, [3] = golden-section searches (capped cylinder /
+ * box), [4] = states found in collision, [5] = proxy pairs of the scene (the tests per state before any culling),
+ * [6] = those within the shapes' static reach.  Scenes of the two-lanes mapping only (serial chains of <= 7 joints). */
+rkh_status rkh_diag_proximity_counts(rkh_scene* scene, const double* x, uint32_t B, uint64_t counts[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -440,8 +440,9 @@ RKH_DI void pair_drain_q2(ScenePtr sc, PairLds<N>& lds) {
 }
 
 // the first queue: closed forms, and the separating-axis screen in front of the golden-section pairs
+// n_exact / n_gold (diagnostic instantiation only): closed forms this lane evaluated, golden-section pairs it queued
 template <int N>
-RKH_DI void pair_drain_q1(ScenePtr sc, PairLds<N>& lds) {
+RKH_DI void pair_drain_q1(ScenePtr sc, PairLds<N>& lds, uint32_t* n_exact = nullptr, uint32_t* n_gold = nullptr) {
   const int lane = threadIdx.x & 63;
   const uint32_t n1 = lds.qn[0] < uint32_t(kQ1Cap) ? lds.qn[0] : uint32_t(kQ1Cap);
 #pragma unroll 1
@@ -476,6 +477,7 @@ RKH_DI void pair_drain_q1(ScenePtr sc, PairLds<N>& lds) {
         } else if (rt != PR_NONE) {
           const double d = a_first ? pair_distance<false>(rt, A, Bv) : pair_distance<false>(rt, Bv, A);
           if (d < 0.0) lds.hit[e] = 1u;
+          if (n_exact) ++*n_exact;
         }
       }
     }
@@ -486,6 +488,7 @@ RKH_DI void pair_drain_q1(ScenePtr sc, PairLds<N>& lds) {
       if (golden && slot < uint32_t(kQ2Cap)) {
         lds.q2[slot] = ent;
         golden = false;
+        if (n_gold) ++*n_gold;
       }
       if (__any(golden)) pair_drain_q2<N>(sc, lds);  // some did not fit: empty the queue, then they try again
     }
@@ -510,6 +513,7 @@ __device__ __forceinline__ bool pair_proximity_free(ScenePtr sc_in, PairLds<N>& 
   }
   const int lane = threadIdx.x & 63;
   const int n_env = sc->n_env, n_robot = sc->n_robot;
+  uint32_t c_q1 = 0, c_exact = 0, c_gold = 0;  // (diagnostic instantiation only)
   if (lane < 2) lds.qn[lane] = 0u;
   if (lane < kPairEdges) lds.hit[lane] = 0u;
   // this lane's cull record of the first obstacle chunk, fetched ahead of the kinematics
@@ -619,6 +623,7 @@ __device__ __forceinline__ bool pair_proximity_free(ScenePtr sc_in, PairLds<N>& 
         uint32_t base = 0u;
         if (cnt) base = atomicAdd(&lds.qn[0], cnt);
         const bool fits = base + cnt <= uint32_t(kQ1Cap);
+        if (DIAG && cnt && fits) c_q1 += cnt;
         if (cnt) {
           unsigned long long mm = mask;
           for (uint32_t k = 0; k < cnt; ++k) {
@@ -628,14 +633,25 @@ __device__ __forceinline__ bool pair_proximity_free(ScenePtr sc_in, PairLds<N>& 
           }
           if (fits) mask = 0ull;
         }
-        if (__any(mask != 0ull) || lds.qn[0] >= 64u) pair_drain_q1<N>(sc, lds);
+        if (__any(mask != 0ull) || lds.qn[0] >= 64u) pair_drain_q1<N>(sc, lds, DIAG ? &c_exact : nullptr, DIAG ? &c_gold : nullptr);
       }
     }
     RKH_STAMP(6)
   }
-  pair_drain_q1<N>(sc, lds);
+  pair_drain_q1<N>(sc, lds, DIAG ? &c_exact : nullptr, DIAG ? &c_gold : nullptr);
   pair_drain_q2<N>(sc, lds);
   RKH_STAMP(7)
+  if (DIAG) {  // stamps[8..10]: (robot shape, obstacle) pairs past the cull, closed forms evaluated, golden-section searches
+    uint32_t v0 = c_q1, v1 = c_exact, v2 = c_gold;
+    for (int off = 32; off > 0; off >>= 1) {
+      v0 += __shfl_xor(v0, off, 64);
+      v1 += __shfl_xor(v1, off, 64);
+      v2 += __shfl_xor(v2, off, 64);
+    }
+    stamps[8] += v0;
+    stamps[9] += v1;
+    stamps[10] += v2;
+  }
   const bool hit = (lds.hit[el] != 0u);
   return !(hit && active);
 #undef RKH_STAMP
@@ -1353,7 +1369,7 @@ __global__ __launch_bounds__(64, 2) void pair_cycles_kernel(const SceneDev* __re
   if (e >= B) e = blockIdx.x * kPairEdges;
   for (int d = 0; d < 2 * N; ++d) RKH_LD(L_::XE + d) = x[uint64_t(e) * 2 * N + d];
   for (int j = 0; j < N; ++j) RKH_LD(L_::U + j) = u[uint64_t(e) * N + j];
-  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool singular = false;
   double accv = 0.0;
   for (int it = 0; it < iters; ++it) {
@@ -1370,6 +1386,50 @@ __global__ __launch_bounds__(64, 2) void pair_cycles_kernel(const SceneDev* __re
     for (int i = 0; i < 8; ++i) out[blockIdx.x * 8 + i] = st[i];
     sink_out[blockIdx.x] = accv + (singular ? 1.0 : 0.0);
   }
+}
+
+// Diagnostic kernel (not on the product path): the proximity test of B states, 32 per wave, counting what survives each
+// stage: out[0] += states tested, [1] += (robot shape, obstacle) pairs past the static reach + fp32 cull (the closed-form
+// stage's input), [2] += closed forms evaluated, [3] += golden-section searches (capped cylinder / box), [4] += states
+// found in collision.
+template <int N>
+__global__ __launch_bounds__(64, 2) void pair_counts_kernel(const SceneDev* __restrict__ sc, const double* __restrict__ x,
+                                                             uint32_t B, unsigned long long* __restrict__ out) {
+  __shared__ PairLds<N> lds;
+  if (threadIdx.x < 3 * (N + 1)) {
+    const int jj = threadIdx.x / 3;
+    lds.axis[jj][threadIdx.x % 3] = sc->joints[jj < N ? jj : N - 1].axis[threadIdx.x % 3];
+  }
+  __syncthreads();
+  typedef PairLayout<N> L_;
+  const int lane = threadIdx.x, h = lane & 1, el = lane >> 1;
+  const uint32_t e = blockIdx.x * kPairEdges + el;
+  const bool valid = e < B;
+  const uint32_t es = valid ? e : blockIdx.x * kPairEdges;
+  for (int d = 0; d < 2 * N; ++d) RKH_LD(L_::XE + d) = x[uint64_t(es) * 2 * N + d];
+  unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool free_state = pair_proximity_free<N, true>((ScenePtr)sc, lds, el, h, true, st);
+  const unsigned long long hits = __ballot(!free_state && valid && h == 0);
+  if (lane == 0) {
+    const uint32_t n_here = (B - blockIdx.x * kPairEdges) < uint32_t(kPairEdges) ? (B - blockIdx.x * kPairEdges) : uint32_t(kPairEdges);
+    atomicAdd(&out[0], (unsigned long long)n_here);
+    atomicAdd(&out[1], st[8]);
+    atomicAdd(&out[2], st[9]);
+    atomicAdd(&out[3], st[10]);
+    atomicAdd(&out[4], (unsigned long long)__popcll(hits));
+  }
+}
+
+rkh_status launch_pair_counts(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, uint32_t B,
+                              unsigned long long* d_out) {
+  const uint32_t waves = (B + kPairEdges - 1) / kPairEdges;
+  switch (n_dof) {
+    case 6: hipLaunchKernelGGL((pair_counts_kernel<6>), dim3(waves), dim3(64), 0, s, d_scene, d_x, B, d_out); break;
+    case 3: hipLaunchKernelGGL((pair_counts_kernel<3>), dim3(waves), dim3(64), 0, s, d_scene, d_x, B, d_out); break;
+    default: set_error("pair diagnostics: instantiated for 3 and 6 joints"); return RKH_ERR_UNSUPPORTED;
+  }
+  RKH_HIP(hipGetLastError());
+  return RKH_OK;
 }
 
 rkh_status launch_pair_cycles(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, const double* d_u,

@@ -366,6 +366,8 @@ rkh_status launch_propagate_pair_steps(hipStream_t s, int n_dof, const SceneDev*
                                        uint32_t pool_blocks = 0, uint32_t* d_pool_cursor = nullptr);
 uint32_t pair_kernel_waves_per_cu(int n_dof);
 uint32_t pair_kernel_edges_per_wave();
+rkh_status launch_pair_counts(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, uint32_t B,
+                              unsigned long long* d_out);
 rkh_status launch_pair_cycles(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, const double* d_u,
                               uint32_t B, int iters, unsigned long long* d_out, double* d_sink);
 rkh_status launch_lane_cycles(hipStream_t s, int n_dof, const SceneDev* d_scene, const double* d_x, const double* d_u,

@@ -785,6 +785,31 @@ rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double
   return RKH_OK;
 }
 
+rkh_status rkh_diag_proximity_counts(rkh_scene* scene, const double* x, uint32_t B, uint64_t counts[8]) {
+  if (scene && reject_branches(scene) != RKH_OK) return RKH_ERR_UNSUPPORTED;
+  if (!scene || !x || !counts || B == 0) return RKH_ERR_BAD_ARG;
+  const int n = scene->host.n_dof;
+  if (!(n <= 7 && scene_fits_lane_kernel(scene->host, 2))) {
+    set_error("proximity counts: a scene of the two-lanes steer mapping is needed");
+    return RKH_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = scene->ctx->stream;
+  DevBuf dx, dout;
+  RKH_HIP(hipMalloc(&dx.p, size_t(B) * 2 * n * 8));
+  RKH_HIP(hipMalloc(&dout.p, 8 * 8));
+  RKH_HIP(hipMemcpyAsync(dx.p, x, size_t(B) * 2 * n * 8, hipMemcpyHostToDevice, s));
+  RKH_HIP(hipMemsetAsync(dout.p, 0, 8 * 8, s));
+  const rkh_status st = launch_pair_counts(s, n, scene->d_scene, dx.as<double>(), B, dout.as<unsigned long long>());
+  if (st != RKH_OK) return st;
+  RKH_HIP(hipMemcpyAsync(counts, dout.p, 8 * 8, hipMemcpyDeviceToHost, s));
+  RKH_HIP(hipStreamSynchronize(s));
+  // what the host knows: proxy pairs of the scene, and the ones inside the shapes' static reach
+  counts[5] = uint64_t(scene->n_pairs);
+  counts[6] = uint64_t(scene->n_pairs_verdict);
+  counts[7] = 0;
+  return RKH_OK;
+}
+
 rkh_status rkh_edge_check(rkh_scene* scene, const double* lower, const double* upper, double min_interval,
                           const double* a, const double* b, uint32_t B, double fraction, double* out,
                           uint32_t* n_checked) {

@@ -81,7 +81,7 @@ EXPORTS = [
     "rkh_scene_create", "rkh_scene_create_with_meshes", "rkh_diag_gjk_distance", "rkh_scene_destroy", "rkh_scene_num_dof", "rkh_scene_num_pairs", "rkh_state_derivative",
     "rkh_min_distance", "rkh_propagate", "rkh_edge_check", "rkh_planner_create", "rkh_planner_destroy",
     "rkh_planner_enqueue", "rkh_planner_sync", "rkh_planner_solve", "rkh_planner_get_tree", "rkh_planner_stream",
-    "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_planner_steer_steps", "rkh_diag_nn_mirror_query", "rkh_diag_feval_cycles", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_create_batch", "rkh_birrtstar_create_qs_batch", "rkh_birrtstar_solve",
+    "rkh_planner_nn_profile", "rkh_planner_nn_pairs", "rkh_planner_steer_profile", "rkh_planner_steer_steps", "rkh_diag_nn_mirror_query", "rkh_diag_feval_cycles", "rkh_diag_proximity_counts", "rkh_planner_create_batch", "rkh_planner_num_problems", "rkh_nn_set_events", "rkh_planner_create_qs_batch", "rkh_rrtstar_create_qs_batch", "rkh_rrtstar_create_batch", "rkh_birrtstar_create_qs_batch", "rkh_birrtstar_solve",
     "rkh_birrtstar_get_graph", "rkh_rrtstar_set_branch_and_bound", "rkh_rrtstar_get_removed", "rkh_rrtstar_destroy", "rkh_rrtstar_solve",
     "rkh_rrtstar_get_graph", "rkh_prm_create_qs_batch", "rkh_prm_create_batch", "rkh_prm_destroy", "rkh_prm_solve", "rkh_prm_get_graph", "rkh_birrt_create_qs_batch", "rkh_birrt_destroy", "rkh_birrt_solve", "rkh_birrt_get_trees", "rkh_planner_get_solution", "rkh_rrtstar_get_solution", "rkh_birrt_get_solution",
 ]
@@ -142,6 +142,7 @@ def load():
     lib.rkh_min_distance.argtypes = [vp, dp, u32, dp]
     lib.rkh_propagate.argtypes = [vp, C.POINTER(T.DynSpace), dp, dp, u32, d, dp, u32p, dp]
     lib.rkh_diag_feval_cycles.argtypes = [vp, dp, dp, u32, C.c_int, C.POINTER(C.c_uint64)]
+    lib.rkh_diag_proximity_counts.argtypes = [vp, dp, u32, C.POINTER(C.c_uint64)]
     lib.rkh_edge_check.argtypes = [vp, dp, dp, d, dp, dp, u32, d, dp, u32p]
     lib.rkh_planner_create.argtypes = [vp, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), C.POINTER(vp)]
     lib.rkh_planner_create_batch.argtypes = [vp, C.POINTER(T.DynSpace), C.POINTER(T.RrtParams), u32, C.POINTER(vp)]
@@ -342,6 +343,14 @@ class Scene:
         pd, M, f = np.zeros((B, self.D)), np.zeros((B, self.n, self.n)), np.zeros((B, self.n))
         _check(self.lib.rkh_state_derivative(self.h, T.dptr(x), T.dptr(u), B, T.dptr(pd), T.dptr(M), T.dptr(f)))
         return pd, M, f
+
+    def proximity_counts(self, x):
+        """Stage counts of the two-lanes steer kernels' proximity test on the states x (rkh_diag_proximity_counts)."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.D)
+        c = (C.c_uint64 * 8)()
+        _check(self.lib.rkh_diag_proximity_counts(self.h, T.dptr(x), x.shape[0], c))
+        return {"states": int(c[0]), "pairs_past_cull": int(c[1]), "closed_forms": int(c[2]), "golden_section": int(c[3]),
+                "states_in_collision": int(c[4]), "pairs_per_state": int(c[5]), "pairs_in_static_reach": int(c[6])}
 
     def diag_feval_cycles(self, x, u, iters=100):
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.D)

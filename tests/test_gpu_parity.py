@@ -1647,3 +1647,18 @@ def test_prm_random_walks_over_the_planar_dynamic_space(L, ctx, oracle):
     assert np.allclose(g["pos"], rg["pos"], rtol=STATE_RTOL, atol=1e-12)
     assert np.allclose(g["density"], rg["density"], rtol=1e-8, atol=1e-12)
     pl.close()
+
+
+def test_proximity_stage_counts_are_consistent(L, ctx, oracle, c2):
+    """rkh_diag_proximity_counts (the `collide` object of bench.py): the counted stages are nested, the number of states
+    found in collision equals the oracle's verdicts on the same states, and a scene's pairs within static reach are a
+    subset of its proxy pairs."""
+    sc, osc = L.Scene(ctx, c2), oracle.OracleScene(c2)
+    rng = np.random.default_rng(3)
+    lo = np.array([c2.dyn.lower[i] for i in range(12)]); hi = np.array([c2.dyn.upper[i] for i in range(12)])
+    x = rng.uniform(lo, hi, size=(5000, 12))
+    c = sc.proximity_counts(x)
+    assert c["states"] == 5000
+    assert 0 < c["pairs_in_static_reach"] <= c["pairs_per_state"] == sc.num_pairs
+    assert c["closed_forms"] + c["golden_section"] <= c["pairs_past_cull"] <= c["states"] * c["pairs_in_static_reach"]
+    assert c["states_in_collision"] == int((osc.min_distance(x) < 0.0).sum())
