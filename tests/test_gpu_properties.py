@@ -181,8 +181,8 @@ def test_rrtstar_and_prm_invariants_at_scale(L, ctx):
 def test_c5_workload_on_one_rank():
     """BASELINE config C5 (independent RRT* seeds sharded over the ranks, best-cost all-reduce) through its own entry,
     `bench.py --workload c5`, on the one rank a test box has: the child process plans two seeds to 40 000 vertices each
-    (the configuration's 1 M per seed is about four minutes of sequential RRT* iterations per problem; 200 000 vertices
-    ran in 50 s, profiles/r03_c5_one_rank_200k.log) and must print the bench contract's JSON line with consistent
+    (the configuration's 1 M per seed is three minutes of sequential RRT* iterations per problem -- run once outside
+    the suite: 188 s, profiles/r03_c5_one_rank_1M.log; 200 000 vertices: 34 s) and must print the bench contract's JSON line with consistent
     counters.  The N > 1 control path (seed blocks per rank, reductions) is covered on the CPU by
     tests/test_distributed.py; no 8-GPU node is available to the builder."""
     import json
