@@ -351,7 +351,8 @@ def steer_occupancy():
 
         res = kr.kernel_resources()
         out = {}
-        for k in ("rkh::propagate_pair_step_kernel<6>", "rkh::propagate_pair_kernel<6>", "rkh::propagate_kernel<6, 64, false>"):
+        for k in ("rkh::propagate_pair_step_kernel<6>", "rkh::propagate_pair_kernel<6>", "rkh::propagate_kernel<6, 64, false, false>",
+                  "rkh::propagate_kernel<6, 64, false, true>"):
             d = res[k]
             lds_waves = (160 * 1024 // d["group_segment_fixed_size"]) if d["group_segment_fixed_size"] else 32
             out[k.replace("rkh::", "")] = {"vgpr": d["vgpr_count"], "vgpr_spills": d["vgpr_spill_count"],

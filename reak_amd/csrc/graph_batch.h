@@ -672,13 +672,20 @@ struct GraphBatch {
     any_edges = true;
   }
 
+  // the steer mapping of a step's launch: one wave per edge, or two (state_derivative_duo) while even the launch's upper
+  // bound of edges leaves half the SIMDs idle (RKH_DUO_THRESHOLD, as in the batch planner)
+  int duo_lanes(uint32_t edges_per_problem) const {
+    static const uint32_t thr = [] { const char* e = getenv("RKH_DUO_THRESHOLD"); return e ? uint32_t(std::max(0, atoi(e))) : 512u; }();
+    return (uint64_t(edges_per_problem) * P <= thr && !scene->host.has_meshes) ? 128 : 64;
+  }
+
   rkh_status run() {
     hipStream_t s = stream;
     RKH_HIP(hipMemcpyAsync(d_cmd, h_cmd, cmd_bytes, hipMemcpyHostToDevice, s));
     if (any_append) hipLaunchKernelGGL(gb_prep_kernel, dim3(P), dim3(64), 0, s, d_aux, DP);
     if (any_stage_a) {
       rkh_status st = dynamic ? launch_propagate(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs_verdict,
-                                                 dyn, EdgeIO(), kGbStageA, nullptr, 0, 64, d_ioa, nullptr, P)
+                                                 dyn, EdgeIO(), kGbStageA, nullptr, 0, duo_lanes(kGbStageA), d_ioa, nullptr, P)
                               : launch_edge_check(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs,
                                                   scene->n_pairs_verdict, qs, EdgeIO(), kGbStageA, nullptr, 0, d_ioa, nullptr, P);
       if (st != RKH_OK) return st;
@@ -692,7 +699,7 @@ struct GraphBatch {
     if (any_edges) {
       // one wave per edge: a step holds at most 2 k candidates per problem, far from filling the two-lanes mappings
       rkh_status st = dynamic ? launch_propagate(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs_verdict,
-                                                 dyn, EdgeIO(), emax, nullptr, 0, 64, d_io, nullptr, P)
+                                                 dyn, EdgeIO(), emax, nullptr, 0, duo_lanes(emax), d_io, nullptr, P)
                               : launch_edge_check(s, n_dof, scene->host.n_env, scene->d_scene, scene->d_pairs,
                                                   scene->n_pairs_verdict, qs, EdgeIO(), emax, nullptr, 0, d_io, nullptr, P);
       if (st != RKH_OK) return st;

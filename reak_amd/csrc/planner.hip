@@ -547,6 +547,7 @@ struct rkh_planner {
   int wave_fit = 1;          // per-round batch scale chosen on the device (round_begin_kernel); RKH_WAVE_FIT=0: off
   double wave_fill = 0.99;   // target fill of the last pass of steer waves (RKH_WAVE_FILL)
   uint32_t wave_slots = 1024;    // SIMDs of the device = concurrent waves of the two-lanes steer kernel
+  uint32_t duo_threshold = 512;   // rounds below this many edges: two waves per edge (RKH_DUO_THRESHOLD; 0 = never)
   uint32_t lane_threshold = 1024;  // rounds with at least this many edges go to the two-lanes-per-edge kernel (one wave-per-edge pass fills the 1024 SIMDs; measured optimum at 4, 16 and 32 problems, tests/diag_lane_threshold.sh)
   uint32_t part_blocks = 0;
   uint64_t max_capacity = 0;
@@ -693,9 +694,22 @@ rkh_status launch_edges(rkh_planner* p, uint32_t grid_a, uint32_t grid_b, const 
     gate_wave.wave_base = p->d_wave_base + (2 * p->P + 1);
     gate_wave.n_segments = 2 * p->P;
   }
-  rkh_status st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
-                                   p->scene->n_pairs_verdict, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, 64, tab_a, tab_b, p->P,
-                                   nullptr, gate_wave);
+  rkh_status st = RKH_OK;
+  if (p->duo_threshold > 0 && compact && p->d_wave_base) {
+    // the smallest rounds (at most half the chip's SIMDs at one wave per edge: a single problem, a few young trees):
+    // two waves per edge (state_derivative_duo), the f-eval's critical path instead of its instruction count
+    KernelGate gate_duo = gate_wave;
+    gate_duo.hi = std::min(p->duo_threshold, p->lane_threshold);
+    gate_wave.lo = gate_duo.hi;
+    st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
+                          p->scene->n_pairs_verdict, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, 128, tab_a, tab_b, p->P, nullptr,
+                          gate_duo);
+    if (st != RKH_OK) return st;
+  }
+  if (gate_wave.lo < gate_wave.hi)
+    st = launch_propagate(p->stream, p->n_dof, p->scene->host.n_env, p->scene->d_scene, p->scene->d_pairs,
+                          p->scene->n_pairs_verdict, p->dyn, EdgeIO(), grid_a, nullptr, grid_b, 64, tab_a, tab_b, p->P, nullptr,
+                          gate_wave);
   if (st != RKH_OK) return st;
   // The two-lanes mapping in two phases when the round is a regular one: half of the edges of a round end within a few
   // steps (tests/diag_edge_lifetimes.py) and leave their lanes idle for the rest of their wave, so the first
@@ -991,6 +1005,8 @@ static rkh_status planner_create_common(rkh_scene* scene, const rkh_dyn_space* s
   if (const char* e = getenv("RKH_BATCH_MAX")) p->b_max = std::max(8, atoi(e));
   p->b_max = std::min<uint32_t>(p->b_max, 4096);
   if (const char* e = getenv("RKH_LANE_THRESHOLD")) p->lane_threshold = uint32_t(std::max(0, atoi(e)));
+  if (const char* e = getenv("RKH_DUO_THRESHOLD")) p->duo_threshold = uint32_t(std::max(0, atoi(e)));
+  if (p->scene->host.has_meshes) p->duo_threshold = 0;  // (instantiated without the support-map query only)
   if (const char* e = getenv("RKH_LANES_PER_EDGE")) {
     p->lanes_per_edge = (atoi(e) == 1) ? 1 : ((atoi(e) == 2) ? 2 : ((atoi(e) == 16) ? 16 : (atoi(e) == 0 ? 0 : 64)));
   } else if (p->n_dof <= 6 && scene_fits_lane_kernel(scene->host, p->lane_variant)) {

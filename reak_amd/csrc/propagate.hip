@@ -63,6 +63,12 @@ struct __attribute__((aligned(16))) GroupWs {  // per-edge LDS workspace
   double Mf[N][N];                  // Tcm^T (Mcm Tcm) before symmetrisation
   double M[N][N];                   // symmetric M, overwritten by its Cholesky factor
   double Rpos[2 * N][3], Rquat[2 * N][4];  // robot shapes, global pose
+  // two waves per edge (state_derivative_duo): x' as the solving wave leaves it for the other one, the number of joints
+  // whose end frames the first wave has published, the first wave's "pivot below 1e-8" verdict
+  double dpx[2 * N];
+  double R2[N][9], RA[N][9];               // rotation matrices of the joint rotations (half-angle quaternion / axis-angle form)
+  double Wj[N][3], ALj[N][3], ACCj[N][3];  // link end frames: angular velocity, angular acceleration, acceleration
+  uint32_t duo_ready, duo_sing;
 };
 
 template <int N, int GL>
@@ -442,6 +448,319 @@ __device__ double state_derivative(const SceneDev* __restrict__ sc_beam, const C
   return out;
 }
 
+// x' = f(x,u) by TWO waves (the latency form of the latency mapping: rounds so small that half the chip's SIMDs would
+// idle even at one wave per edge -- a single problem, a graph planner's step).  One f-eval of state_derivative is ~6.6 k
+// fp64 instructions in one wave's stream, 26.5 k cycles, and its phases are not all dependent:
+//   wave 0: joint / link end frames (the pose half of the base -> tip sweep) -> Jacobian columns -> Mf -> M -> Cholesky factor
+//   wave 1: velocities, accelerations, d'Alembert terms (the other half of the sweep, one joint behind wave 0: it waits on
+//           a counter in LDS, never on a barrier) -> beam -> tip -> base force sweep -> generalized forces
+// then wave 0 solves and leaves x' in LDS for both.  Every value is formed by the same operation sequence as in
+// state_derivative (the two halves of the sweep only share the rotation matrix of a joint's end frame, which each
+// forms from the same quaternion), so the result is the same bits.  Critical path ~15 k cycles.
+RKH_DI void wave_sync() {  // LDS traffic of this wave's lanes, ordered (no block barrier: the other wave is elsewhere)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+template <int N>
+__device__ double state_derivative_duo(const SceneDev* __restrict__ sc_beam, const CPack<N>& cp,
+                                       const JointLds* __restrict__ jl, const double* __restrict__ base, GroupWs<N>& ws,
+                                       double* __restrict__ sink, int gl, int wave, bool* singular,
+                                       unsigned long long* stamps = nullptr) {
+  constexpr int D = 2 * N, GL = 64;
+  const bool lead = (gl == 0);
+  // diagnostic builds only: cycles per phase of this wave (wave 0: sincos, frames, columns, Mf + M, factor, wait, solve;
+  // wave 1: sincos, velocity half, beam, force sweep, wait)
+#define RKH_STAMP(i)                                                \
+  if (stamps) {                                                     \
+    const unsigned long long t_now = __builtin_readcyclecounter(); \
+    stamps[i] += t_now - t_prev;                                    \
+    t_prev = t_now;                                                 \
+  }
+  unsigned long long t_prev = stamps ? __builtin_readcyclecounter() : 0ull;
+  uint32_t branches = 0u;  // bit j: joint j starts a new branch at the chain base (read once, ahead of the serial loops)
+#pragma unroll
+  for (int j = 0; j < N; ++j) branches |= sc_beam->branch_start[j] ? (1u << j) : 0u;
+  if (gl < D) {  // sin / cos (both waves: the same values)
+    const double q = ws.x[gl & ~1];
+    double sn, cs;
+    sincos((gl & 1) ? q : 0.5 * q, &sn, &cs);
+    ws.cs[gl >> 1][(gl & 1) * 2 + 0] = cs;
+    ws.cs[gl >> 1][(gl & 1) * 2 + 1] = sn;
+  }
+  if (wave == 0 && lead) {
+    ws.duo_ready = 0u;
+    ws.duo_sing = 0u;
+  }
+  __syncthreads();
+  RKH_STAMP(0)
+  double Lrow[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) Lrow[k] = 0.0;
+  const int row = gl < N ? gl : N - 1;
+  bool sing = false;
+  if (wave == 0) {
+    {  // ---- pose half of the base -> tip sweep; every joint's end frames are published as soon as they are stored
+      d3 pos = ld3(base);
+      d4 Q = ld4(base + 3);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const int jb = j * 32;
+        if ((branches >> j) & 1u) {
+          const d4 bq = ld4(base + 3);
+          pos = ld3(base) + mul(rotmat(bq), ld3(sc_beam->mount_pos[j]));
+          Q = qmul(bq, ld4(sc_beam->mount_quat[j]));
+        }
+        const d3 axis_n = cget3(cp, jb + JC_AXISN);
+        const double c2 = ws.cs[j][0], s2 = ws.cs[j][1];
+        const d4 tq = d4{c2, axis_n.x * s2, axis_n.y * s2, axis_n.z * s2};
+        const d4 EQ = qmul(Q, tq);
+        st3(lead ? ws.Epos[j] : sink, pos);
+        st4(lead ? ws.Equat[j] : sink, EQ);
+        const d3 op = cget3(cp, jb + JC_OFFP);
+        const m33 R = rotmat(EQ);
+        pos = pos + mul(R, op);
+        Q = qmul(EQ, d4{cget(cp, jb + JC_OFFQ), cget(cp, jb + JC_OFFQ + 1), cget(cp, jb + JC_OFFQ + 2),
+                        cget(cp, jb + JC_OFFQ + 3)});
+        st3(lead ? ws.Lpos[j] : sink, pos);
+        st4(lead ? ws.Lquat[j] : sink, Q);
+        wave_sync();
+        if (lead) __hip_atomic_store(&ws.duo_ready, uint32_t(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    RKH_STAMP(1)
+    // ---- jacobian columns (as in state_derivative)
+    for (int p = gl; p < N * (N + 1) / 2; p += GL) {
+      int b = 0, c = p;
+      while (c > b) {
+        c -= b + 1;
+        ++b;
+      }
+      if (c < sc_beam->branch_first[b]) continue;
+      const d3 cpos = ld3(ws.Epos[c]);
+      const d4 cq = ld4(ws.Equat[c]);
+      const d3 bp = ld3(ws.Lpos[b]);
+      const d4 bq = ld4(ws.Lquat[b]);
+      const m33 R = rotmat(cq);
+      const d4 iq = qinv(cq);
+      const d3 ipos = mulT(-cpos, R);
+      const m33 Ri = rotmat(iq);
+      const d3 f2pos = ipos + mul(Ri, bp);
+      const d4 f2q = qmul(iq, bq);
+      const m33 Rf = rotmat(f2q);
+      const d3 axis = ld3(jl[c].axis);
+      const d3 wt = mulT(axis, Rf);
+      const d3 vt = mulT(cross(axis, f2pos), Rf);
+      st3(ws.Tcm[b][c], vt);
+      st3(ws.Tcm[b][c] + 3, wt);
+    }
+    wave_sync();
+    RKH_STAMP(2)
+    // ---- Mf = Tcm^T (Mcm Tcm), M, Cholesky factor (as in state_derivative; wave-local ordering instead of barriers)
+    for (int e0 = 0; e0 < N * N; e0 += GL) {
+      const bool e_valid = e0 + gl < N * N;
+      const int e = e_valid ? e0 + gl : N * N - 1;
+      const int i = e / N, jx = e % N;
+      double sacc = 0.0;
+      if (i == jx) sacc = sacc + jl[i].joint_inertia;
+#pragma unroll
+      for (int b = 0; b < N; ++b) {
+        const int bb = b * 32;
+        const double mass = cget(cp, bb + JC_MASS);
+        const double inertia[6] = {cget(cp, bb + JC_INER), cget(cp, bb + JC_INER + 1), cget(cp, bb + JC_INER + 2),
+                                   cget(cp, bb + JC_INER + 3), cget(cp, bb + JC_INER + 4), cget(cp, bb + JC_INER + 5)};
+        const int first_b = sc_beam->branch_first[b];
+        if (b >= i && b >= jx && i >= first_b && jx >= first_b) {
+          const double* Ti = ws.Tcm[b][i];
+          const double* Tj = ws.Tcm[b][jx];
+          sacc = sacc + Ti[0] * (mass * Tj[0]);
+          sacc = sacc + Ti[1] * (mass * Tj[1]);
+          sacc = sacc + Ti[2] * (mass * Tj[2]);
+          const d3 P = sym_mul(inertia, mk3(Tj[3], Tj[4], Tj[5]));
+          sacc = sacc + Ti[3] * P.x;
+          sacc = sacc + Ti[4] * P.y;
+          sacc = sacc + Ti[5] * P.z;
+        }
+      }
+      if (e_valid) ws.Mf[i][jx] = sacc;
+    }
+    wave_sync();
+    for (int e = gl; e < N * N; e += GL) {
+      const int i = e / N, jx = e % N;
+      const int lo = i < jx ? i : jx, hi = i < jx ? jx : i;
+      ws.M[i][jx] = (i == jx) ? ws.Mf[i][i] : 0.5 * (ws.Mf[lo][hi] + ws.Mf[hi][lo]);
+    }
+    wave_sync();
+    RKH_STAMP(3)
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double dgl = ws.M[j][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) {
+        const double ljk = ws.M[j][k];
+        dgl = dgl - ljk * ljk;
+      }
+      if (dgl < 1e-8) sing = true;
+      const double ljj = sqrt(dgl);
+      double v = ws.M[row][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v = v - Lrow[k] * ws.M[j][k];
+      v = v / ljj;
+      Lrow[j] = (row == j) ? ljj : v;
+      if (gl < N && row >= j) ws.M[row][j] = Lrow[j];
+      wave_sync();
+    }
+    RKH_STAMP(4)
+  } else {
+    // ---- velocity / acceleration half of the base -> tip sweep.  Only the recurrences w, alpha, acc are serial: the
+    // joint rotation matrices before them and the d'Alembert terms after them take one LANE per joint.
+    if (gl < N) {
+      const d3 axis_n = ld3(jl[gl].axis_n);
+      const double c2 = ws.cs[gl][0], s2 = ws.cs[gl][1];
+      const m33 R2 = rotmat(d4{c2, axis_n.x * s2, axis_n.y * s2, axis_n.z * s2});
+      double* r2 = ws.R2[gl];
+      r2[0] = R2.a11; r2[1] = R2.a12; r2[2] = R2.a13; r2[3] = R2.a21; r2[4] = R2.a22; r2[5] = R2.a23;
+      r2[6] = R2.a31; r2[7] = R2.a32; r2[8] = R2.a33;
+      const m33 Ra = axis_angle_rotmat(ws.cs[gl][2], ws.cs[gl][3], axis_n);  // revolute_joint_3D::doForce's rotation
+      double* ra = ws.RA[gl];
+      ra[0] = Ra.a11; ra[1] = Ra.a12; ra[2] = Ra.a13; ra[3] = Ra.a21; ra[4] = Ra.a22; ra[5] = Ra.a23;
+      ra[6] = Ra.a31; ra[7] = Ra.a32; ra[8] = Ra.a33;
+    }
+    wave_sync();
+    {
+      d3 w = mk3(0, 0, 0), alpha = mk3(0, 0, 0);
+      d3 acc = ld3(base + 7);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const int jb = j * 32;
+        // joint j's end frame from wave 0 (a counter in LDS: wave 0 does not stop for this)
+        while (__hip_atomic_load(&ws.duo_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < uint32_t(j + 1))
+          __builtin_amdgcn_s_sleep(1);
+        if ((branches >> j) & 1u) {
+          w = mk3(0, 0, 0);
+          alpha = mk3(0, 0, 0);
+          acc = ld3(base + 7);
+        }
+        const d3 axis = cget3(cp, jb + JC_AXIS);
+        const double qd = ws.x[2 * j + 1];
+        const m33 R2 = ldm(ws.R2[j]);
+        const d3 wb = mulT(w, R2);
+        const d3 qa = qd * axis;
+        const d3 Ew = wb + qa;
+        const d3 Ealpha = mulT(alpha, R2) + cross(wb, qa);
+        const d3 op = cget3(cp, jb + JC_OFFP);
+        const m33 R = rotmat(ld4(ws.Equat[j]));
+        acc = acc + mul(R, cross(Ew, cross(Ew, op)) + cross(Ealpha, op));
+        const m33 Ro = m33{cget(cp, jb + JC_OFFR + 0), cget(cp, jb + JC_OFFR + 1), cget(cp, jb + JC_OFFR + 2),
+                           cget(cp, jb + JC_OFFR + 3), cget(cp, jb + JC_OFFR + 4), cget(cp, jb + JC_OFFR + 5),
+                           cget(cp, jb + JC_OFFR + 6), cget(cp, jb + JC_OFFR + 7), cget(cp, jb + JC_OFFR + 8)};
+        alpha = mulT(Ealpha, Ro);
+        w = mulT(Ew, Ro);
+        st3(lead ? ws.Wj[j] : sink, w);
+        st3(lead ? ws.ALj[j] : sink, alpha);
+        st3(lead ? ws.ACCj[j] : sink, acc);
+      }
+    }
+    wave_sync();
+    if (gl < N) {  // inertia_3D::doForce terms (inertia.cpp:111-122) of joint gl's link, applied in the backward sweep
+      const d4 Q = ld4(ws.Lquat[gl]);
+      const d3 acc = ld3(ws.ACCj[gl]), alpha = ld3(ws.ALj[gl]), w = ld3(ws.Wj[gl]);
+      const double* inertia = jl[gl].inertia;
+      const d3 Fi = jl[gl].mass * qrot(qinv(Q), acc);
+      const d3 Ti = sym_mul(inertia, alpha) + cross(w, sym_mul(inertia, w));
+      st3(ws.FT[gl], Fi);
+      st3(ws.FT[gl] + 3, Ti);
+    }
+    wave_sync();
+    RKH_STAMP(1)
+    {  // flexible_beam_3D::doForce (as in state_derivative)
+      d3 BF1 = mk3(0, 0, 0), BT1 = mk3(0, 0, 0), BF2 = mk3(0, 0, 0), BT2 = mk3(0, 0, 0);
+      if (sc_beam->beam_on) {
+        const int j1 = sc_beam->beam_j1, j2 = sc_beam->beam_j2;
+        const d3 p1 = ld3(ws.Lpos[j1]);
+        const d4 q1 = ld4(ws.Lquat[j1]);
+        const d3 p2 = j2 >= 0 ? ld3(ws.Lpos[j2]) : ld3(sc_beam->beam_pos);
+        const d4 q2 = j2 >= 0 ? ld4(ws.Lquat[j2]) : ld4(sc_beam->beam_quat);
+        beam_force(p1, q1, p2, q2, sc_beam->beam_rest, sc_beam->beam_k, sc_beam->beam_kt, &BF1, &BT1);
+        if (j2 >= 0) beam_force_anchor2(p1, q1, p2, q2, sc_beam->beam_rest, sc_beam->beam_k, sc_beam->beam_kt, &BF2, &BT2);
+      }
+      st3(lead ? ws.BFT[0] : sink, BF1);
+      st3(lead ? ws.BFT[0] + 3 : sink, BT1);
+      st3(lead ? ws.BFT[1] : sink, BF2);
+      st3(lead ? ws.BFT[1] + 3 : sink, BT2);
+    }
+    wave_sync();
+    RKH_STAMP(2)
+    double f_mine = 0.0;
+    {  // ---- tip -> base sweep (as in state_derivative)
+      d3 LF = mk3(0, 0, 0), LT = mk3(0, 0, 0);
+      const int bj1 = sc_beam->beam_on ? sc_beam->beam_j1 : -1, bj2 = sc_beam->beam_on ? sc_beam->beam_j2 : -1;
+#pragma unroll
+      for (int j = N - 1; j >= 0; --j) {
+        const int jb = j * 32;
+        const d3 axis = cget3(cp, jb + JC_AXIS);
+        if (j + 1 < N && ((branches >> (j + 1 < N ? j + 1 : 0)) & 1u)) {
+          LF = mk3(0, 0, 0);
+          LT = mk3(0, 0, 0);
+        }
+        if (j == bj1) {
+          LF = LF + ld3(ws.BFT[0]);
+          LT = LT + ld3(ws.BFT[0] + 3);
+        }
+        if (j == bj2) {
+          LF = LF + ld3(ws.BFT[1]);
+          LT = LT + ld3(ws.BFT[1] + 3);
+        }
+        LF = LF - ld3(ws.FT[j]);
+        LT = LT - ld3(ws.FT[j] + 3);
+        const m33 Ro = m33{cget(cp, jb + JC_OFFR + 0), cget(cp, jb + JC_OFFR + 1), cget(cp, jb + JC_OFFR + 2),
+                           cget(cp, jb + JC_OFFR + 3), cget(cp, jb + JC_OFFR + 4), cget(cp, jb + JC_OFFR + 5),
+                           cget(cp, jb + JC_OFFR + 6), cget(cp, jb + JC_OFFR + 7), cget(cp, jb + JC_OFFR + 8)};
+        const d3 op = cget3(cp, jb + JC_OFFP);
+        const d3 tmp_force = mul(Ro, LF);
+        const d3 ET = mul(Ro, LT) + cross(op, tmp_force);
+        const m33 Ra = ldm(ws.RA[j]);
+        const double ta = dot(ET, axis);
+        LF = mul(Ra, tmp_force);
+        LT = mul(Ra, ET - ta * axis);
+        const double uj = ws.u[j];
+        const double fj = ta + uj;
+        LT = LT - uj * axis;
+        f_mine = (gl == j) ? fj : f_mine;
+      }
+    }
+    if (gl < N) ws.tmp[gl] = f_mine;
+    RKH_STAMP(3)
+  }
+  __syncthreads();
+  RKH_STAMP(5)
+  if (wave == 0) {  // backsub_Cholesky_impl (mat_cholesky.hpp:160-178): L y = f, then L^T x = y
+    double diag = 1.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) diag = (row == k) ? Lrow[k] : diag;
+    double accv = (gl < N) ? ws.tmp[gl] : 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const double yk = __shfl(accv / diag, k, 64);
+      if (row == k) accv = yk;
+      else if (row > k) accv = accv - Lrow[k] * yk;
+    }
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+      const double xk = __shfl(accv / diag, k, 64);
+      if (row == k) accv = xk;
+      else if (row < k) accv = accv - ws.M[k][row] * xk;
+    }
+    const double qdd = __shfl(accv, gl >> 1, 64);
+    if (gl < D) ws.dpx[gl] = (gl & 1) ? qdd : ws.x[gl + 1];
+    if (sing && lead) ws.duo_sing = 1u;
+  }
+  __syncthreads();
+  RKH_STAMP(6)
+#undef RKH_STAMP
+  if (ws.duo_sing) *singular = true;
+  return gl < D ? ws.dpx[gl] : 0.0;
+}
+
 // Planar scenes (SceneDev::planar): revolute_joint_2D / rigid_link_2D kinematics (revolute_joint.cpp:30-47,
 // rigid_link.cpp:87-99), pose_2D::getGlobalPose of the robot shapes, then proxy_query_pair_2D::findMinimumDistance
 // (proxy_query_model.cpp:163-189) replayed in finder order: every lane computes one pair's cull value and distance,
@@ -678,8 +997,12 @@ RKH_DI WaveArgP wave_args() {
 // previous round's goal probes); 64/GL edges per wave.
 // GL = 64 (one wave per edge, the latency mapping: rounds of fewer waves than the chip has SIMDs) may use the whole
 // register file of its SIMD; four edges per wave (GL = 16) is the throughput form and keeps two waves per SIMD.
-template <int N, int GL, bool GJK>
-__global__ __launch_bounds__(64, GL == 64 ? 1 : 2) void propagate_kernel(WaveArgs) {
+// DUO (GL = 64 only): two waves per edge.  Both run this body in step -- the same loads, the same RK4 glue, the same
+// control flow, so every block barrier is met by both -- and differ inside state_derivative_duo; only the first wave
+// writes results.
+template <int N, int GL, bool GJK, bool DUO = false>
+__global__ __launch_bounds__(DUO ? 128 : 64, GL == 64 ? 1 : 2) void propagate_kernel(WaveArgs) {
+  static_assert(!DUO || GL == 64, "two waves per edge: one edge per block");
   // Every argument is read through the kernarg segment pointer at its point of use (by-value parameters are loaded in the
   // entry block and stay live in scalar registers; once those run out they are spilled into vector-register lanes, and
   // the EdgeIO / DynDev / KernelGate copies alone are ~170 dwords: the kernel then needed 256 registers + 185 spilled)
@@ -719,7 +1042,9 @@ __global__ __launch_bounds__(64, GL == 64 ? 1 : 2) void propagate_kernel(WaveArg
     return (const EdgeIO*)(ka + (group_b ? offsetof(WaveArgs, io_b) : offsetof(WaveArgs, io_a)));
   };
   const uint32_t B = edge_io()->d_B ? *edge_io()->d_B : edge_io()->B;
-  const int lane = threadIdx.x;
+  const int lane = DUO ? int(threadIdx.x & 63u) : int(threadIdx.x);
+  const int wave = DUO ? int(threadIdx.x >> 6) : 0;
+  const bool writer = !DUO || wave == 0;  // the wave whose results leave the block
   const int g = lane / GL, gl = lane % GL, gb = g * GL;
   const uint32_t e0 = blk * G;
   if (e0 >= B) return;
@@ -737,7 +1062,7 @@ __global__ __launch_bounds__(64, GL == 64 ? 1 : 2) void propagate_kernel(WaveArg
   const double lo = (gl < D) ? wave_args()->dyn.lower[gl] : 0.0;
   const double hi = (gl < D) ? wave_args()->dyn.upper[gl] : 0.0;
   if (gl < D) ws.b[gl] = b_d;
-  double* __restrict__ record = edge_valid ? edge_io()->record : nullptr;
+  double* __restrict__ record = (edge_valid && writer) ? edge_io()->record : nullptr;
   const int record_stride = edge_io()->record_stride;
   __syncthreads();
   const CPack<N> cp = load_cpack<N>(lds.joints, lane);
@@ -776,7 +1101,7 @@ __global__ __launch_bounds__(64, GL == 64 ? 1 : 2) void propagate_kernel(WaveArg
     __syncthreads();
     const double dmin = proximity_min<N, GL, GroupWs<N>, GJK>(sc, cp, lds.base, env_lds, pairs, n_pairs, ws, lds.sink[lane], gl, gb, true, !free_pt);
     if (dmin < 0.0) free_pt = false;
-    if (edge_valid && gl == 0) edge_io()->accept[e] = free_pt ? 1 : 0;
+    if (edge_valid && gl == 0 && writer) edge_io()->accept[e] = free_pt ? 1 : 0;
   }
 
   for (int k = 0; k < n_steps; ++k) {
@@ -809,7 +1134,8 @@ __global__ __launch_bounds__(64, GL == 64 ? 1 : 2) void propagate_kernel(WaveArg
       for (int ev = 0; ev < n_evals; ++ev) {
         if (gl < D) ws.x[gl] = xe;
         __syncthreads();
-        const double dp = state_derivative<N, GL>(sc, cp, lds.joints, lds.base, ws, lds.sink[lane], gl, gb, &sing_now);
+        const double dp = DUO ? state_derivative_duo<N>(sc, cp, lds.joints, lds.base, ws, lds.sink[lane], gl, wave, &sing_now)
+                              : state_derivative<N, GL>(sc, cp, lds.joints, lds.base, ws, lds.sink[lane], gl, gb, &sing_now);
         const int stage = ev & 3;
         if (stage == 0) {
           w = xe;
@@ -852,10 +1178,11 @@ __global__ __launch_bounds__(64, GL == 64 ? 1 : 2) void propagate_kernel(WaveArg
       if (record && gl < D) record[(uint64_t(e) * record_stride + n_free) * D + gl] = x;
     }
   }
-  if (singular && gl == 0 && edge_valid) atomicExch(edge_io()->err_flag, int(RKH_ERR_SINGULAR));
-  if (edge_valid && gl < D) edge_io()->x_out[uint64_t(e) * D + gl] = x;
-  if (edge_valid && gl == 0) edge_io()->steps_free[e] = n_free;
-  if (wave_args()->gate.steps_exec && edge_valid && gl == 0 && n_exec) atomicAdd(wave_args()->gate.steps_exec, (unsigned long long)n_exec);
+  if (singular && gl == 0 && edge_valid && writer) atomicExch(edge_io()->err_flag, int(RKH_ERR_SINGULAR));
+  if (edge_valid && gl < D && writer) edge_io()->x_out[uint64_t(e) * D + gl] = x;
+  if (edge_valid && gl == 0 && writer) edge_io()->steps_free[e] = n_free;
+  if (wave_args()->gate.steps_exec && edge_valid && gl == 0 && n_exec && writer)
+    atomicAdd(wave_args()->gate.steps_exec, (unsigned long long)n_exec);
   if (edge_io()->mode != EDGE_PLAIN) {
     const double n_ar = group_norm<N>(ws, a_d - x, gl);
     const double n_ab = group_norm<N>(ws, a_d - b_d, gl);
@@ -865,18 +1192,18 @@ __global__ __launch_bounds__(64, GL == 64 ? 1 : 2) void propagate_kernel(WaveArg
       const double traveled = n_ar;
       const double best_case = edge_io()->best_case ? edge_io()->best_case[ec] : n_ab;
       const bool ok = (!isinf(traveled)) && (traveled < 2.0 * best_case) && (traveled > edge_io()->steer_tol * best_case);
-      if (edge_valid && gl == 0) edge_io()->accept[e] = ok ? 1 : 0;
+      if (edge_valid && gl == 0 && writer) edge_io()->accept[e] = ok ? 1 : 0;
     } else if (edge_io()->mode == EDGE_CONNECT) {
       // planning_visitor_base::can_be_connected (planning_visitors.hpp:385-395); steer_tol carries the connection tolerance
       const bool ok = (!isinf(n_ar)) && (n_rb < edge_io()->steer_tol * n_ar);
-      if (edge_valid && gl == 0) edge_io()->accept[e] = ok ? 1 : 0;
+      if (edge_valid && gl == 0 && writer) edge_io()->accept[e] = ok ? 1 : 0;
     } else if (edge_io()->mode == EDGE_WALK_ACCEPT) {
       // planning_visitor_base::random_walk (planning_visitors.hpp:418-421)
       const bool ok = (!isinf(n_ar)) && (n_ar > edge_io()->steer_tol * edge_io()->best_case[ec]);
-      if (edge_valid && gl == 0) edge_io()->accept[e] = ok ? 1 : 0;
+      if (edge_valid && gl == 0 && writer) edge_io()->accept[e] = ok ? 1 : 0;
     } else if (edge_io()->mode == EDGE_GOAL_PROBE) {
       // C_free distance used by the goal probe (MEAQR_topology.hpp:995-1003)
-      if (edge_valid && gl == 0) edge_io()->goal_dist[si - 1] = (n_ab * 0.05 > n_rb) ? n_ab : INFINITY;
+      if (edge_valid && gl == 0 && writer) edge_io()->goal_dist[si - 1] = (n_ab * 0.05 > n_rb) ? n_ab : INFINITY;
     }
   }
 }
@@ -1634,6 +1961,38 @@ __global__ __launch_bounds__(64) void feval_cycles_kernel(const SceneDev* __rest
   }
 }
 
+// Diagnostic kernel (not on the product path): state_derivative_duo, `iters` f-evals of one state per block of two
+// waves; row 2 b of `out` = wave 0's stamps, row 2 b + 1 = wave 1's (8 counters each, see state_derivative_duo).
+template <int N>
+__global__ __launch_bounds__(128) void feval_cycles_duo_kernel(const SceneDev* __restrict__ sc, const double* __restrict__ x,
+                                                                const double* __restrict__ u, int iters,
+                                                                unsigned long long* __restrict__ out, double* __restrict__ sink_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  BlockLds<N, 64>& lds = *reinterpret_cast<BlockLds<N, 64>*>(smem_raw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int D = 2 * N;
+  stage_chain<N>(sc, lds.joints, lds.base, lane);
+  GroupWs<N>& ws = lds.g[0];
+  double xv = (lane < D) ? x[uint64_t(blockIdx.x) * D + lane] : 0.0;
+  if (lane < N) ws.u[lane] = u[uint64_t(blockIdx.x) * N + lane];
+  __syncthreads();
+  const CPack<N> cp = load_cpack<N>(lds.joints, lane);
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool singular = false;
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    if (lane < D) ws.x[lane] = xv;
+    __syncthreads();
+    const double dp = state_derivative_duo<N>(sc, cp, lds.joints, lds.base, ws, lds.sink[lane], lane, wave, &singular, st);
+    xv = xv + 1e-4 * dp;
+  }
+  st[7] = __builtin_readcyclecounter() - t_begin;
+  if (lane == 0) {
+    for (int i = 0; i < 8; ++i) out[(uint64_t(blockIdx.x) * 2 + wave) * 8 + i] = st[i];
+    if (wave == 0) sink_out[blockIdx.x] = xv + (singular ? 1.0 : 0.0);
+  }
+}
+
 // Kernel: exact minimum proxy-pair distance for B states (no culling).
 template <int N>
 __global__ __launch_bounds__(64) void min_distance_kernel(const SceneDev* __restrict__ sc, const PairDev* __restrict__ pairs,
@@ -1685,7 +2044,7 @@ __global__ __launch_bounds__(64) void min_distance_kernel(const SceneDev* __rest
       return RKH_ERR_UNSUPPORTED;    \
   }
 
-template <int N, int GL, bool GJK>
+template <int N, int GL, bool GJK, bool DUO = false>
 static void launch_propagate_t(hipStream_t s, int n_env, const SceneDev* d_scene, const PairDev* d_pairs, int n_pairs,
                                const DynDev& dyn, const EdgeIO& io, uint32_t edges_a, const EdgeIO& io_b,
                                uint32_t edges_b, const EdgeIO* tab_a, const EdgeIO* tab_b, uint32_t n_problems,
@@ -1710,7 +2069,7 @@ static void launch_propagate_t(hipStream_t s, int n_env, const SceneDev* d_scene
   args.tab_b = tab_b;
   args.grid_a = ga;
   args.gate = gate;
-  hipLaunchKernelGGL((propagate_kernel<N, GL, GJK>), grid, dim3(64), (SmemLayout<N, GL>::bytes(n_env)), s, args);
+  hipLaunchKernelGGL((propagate_kernel<N, GL, GJK, DUO>), grid, dim3(DUO ? 128 : 64), (SmemLayout<N, GL>::bytes(n_env)), s, args);
 }
 
 // Steer `grid_edges` (+ `grid_b` of a second group) edges per problem.  Either the two EdgeIO are given by value
@@ -1732,7 +2091,10 @@ rkh_status launch_propagate(hipStream_t s, int n_dof, int n_env, const SceneDev*
                                   gate);
   const EdgeIO second = io_b ? *io_b : EdgeIO();
   const PairDev* pp = static_cast<const PairDev*>(d_pairs);
-  if (lanes_per_edge == 16) {
+  if (lanes_per_edge == 128 && !is_mesh_scene(d_scene)) {  // two waves per edge (scenes without vertex-set shapes)
+    RKH_DISPATCH_N(n_dof, (launch_propagate_t<N, 64, false, true>(s, n_env, d_scene, pp, n_pairs, dyn, io, grid_edges, second, eb,
+                                                                  tab_a, tab_b, n_problems, gate)));
+  } else if (lanes_per_edge == 16) {
     RKH_DISPATCH_N(n_dof, (launch_propagate_t<N, 16, true>(s, n_env, d_scene, pp, n_pairs, dyn, io, grid_edges, second, eb, tab_a,
                                                            tab_b, n_problems, gate)));
   } else if (is_mesh_scene(d_scene)) {
@@ -1866,6 +2228,14 @@ rkh_status launch_edge_check(hipStream_t s, int n_dof, int n_env, const SceneDev
     default: RKH_EDGE_LAUNCH(16, 1, true); break;
   }
 #undef RKH_EDGE_LAUNCH
+  RKH_HIP(hipGetLastError());
+  return RKH_OK;
+}
+
+rkh_status launch_feval_cycles_duo(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const double* d_x,
+                                   const double* d_u, uint32_t B, int iters, unsigned long long* d_out, double* d_sink) {
+  RKH_DISPATCH_N(n_dof, hipLaunchKernelGGL((feval_cycles_duo_kernel<N>), dim3(B / 2), dim3(128), (SmemLayout<N, 64>::bytes(n_env)),
+                                           s, d_scene, d_x, d_u, iters, d_out, d_sink));
   RKH_HIP(hipGetLastError());
   return RKH_OK;
 }

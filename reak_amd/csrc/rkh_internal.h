@@ -332,6 +332,8 @@ rkh_status launch_edge_check(hipStream_t s, int n_dof, int n_env, const SceneDev
                              int n_pairs, const QsDev& qs, const EdgeIO& io, uint32_t grid_edges,
                              const EdgeIO* io_b = nullptr, uint32_t grid_b = 0, const EdgeIO* tab_a = nullptr,
                              const EdgeIO* tab_b = nullptr, uint32_t n_problems = 1);
+rkh_status launch_feval_cycles_duo(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const double* d_x,
+                                   const double* d_u, uint32_t B, int iters, unsigned long long* d_out, double* d_sink);
 rkh_status launch_feval_cycles(hipStream_t s, int n_dof, int n_env, const SceneDev* d_scene, const void* d_pairs,
                                int n_pairs, const double* d_x, const double* d_u, uint32_t B, int iters,
                                unsigned long long* d_out, double* d_sink);

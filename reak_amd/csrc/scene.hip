@@ -734,9 +734,9 @@ rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const dou
   io.record = record ? drec.as<double>() : nullptr;
   io.record_stride = rec_stride;
   io.err_flag = scene->d_err;
-  int lanes = 64;  // RKH_LANES_PER_EDGE = 64 | 16 | 2 | 1 selects the kernel mapping (identical results)
+  int lanes = 64;  // RKH_LANES_PER_EDGE = 128 (two waves per edge) | 64 | 16 | 2 | 1 selects the kernel mapping (identical results)
   if (const char* ev = getenv("RKH_LANES_PER_EDGE"))
-    lanes = (atoi(ev) == 1) ? 1 : (atoi(ev) == 2 ? 2 : (atoi(ev) == 16 ? 16 : 64));
+    lanes = (atoi(ev) == 1) ? 1 : (atoi(ev) == 2 ? 2 : (atoi(ev) == 16 ? 16 : (atoi(ev) == 128 ? 128 : 64)));
   if ((lanes == 1 || lanes == 2) && !(n <= 7 && scene_fits_lane_kernel(scene->host, lanes))) lanes = 64;  // not a scene for that mapping
   if (lanes == 16 && 2 * n > 16) lanes = 64;
   DevBuf dws;
@@ -775,6 +775,11 @@ rkh_status rkh_diag_feval_cycles(rkh_scene* scene, const double* x, const double
     RKH_HIP(hipMemsetAsync(dout.p, 0, size_t(B) * 8 * 8, s));
     st = launch_pair_cycles(s, n, scene->d_scene, dx.as<double>(), du.as<double>(), B, iters,
                             dout.as<unsigned long long>(), dsink.as<double>());
+  } else if (ev && atoi(ev) == 128) {  // two waves per edge: B / 2 states, rows 2 b / 2 b + 1 = the two waves' counters
+    RKH_HIP(hipMemsetAsync(dout.p, 0, size_t(B) * 8 * 8, s));
+    st = (B >= 2) ? launch_feval_cycles_duo(s, n, scene->host.n_env, scene->d_scene, dx.as<double>(), du.as<double>(), B, iters,
+                                            dout.as<unsigned long long>(), dsink.as<double>())
+                  : RKH_ERR_BAD_ARG;
   } else {
     st = launch_feval_cycles(s, n, scene->host.n_env, scene->d_scene, scene->d_pairs, scene->n_pairs, dx.as<double>(),
                              du.as<double>(), B, iters, dout.as<unsigned long long>(), dsink.as<double>());

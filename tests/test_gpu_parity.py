@@ -3,6 +3,8 @@
 Bars: bit-exact for integer / index work (NN indices and distances, accept bits, parents, node counts,
 free-step counts); propagated fp64 states within 1e-10 relative (sin/cos are OCML on the device and glibc
 in the oracle, everything else rounds identically because the kernels are built with -ffp-contract=off)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -816,7 +818,8 @@ def test_prm_batch_and_resume(L, ctx, oracle):
 
 # ------------------------------------------------------------------ kernel mappings of the steer kernel
 def test_propagate_mappings_are_bit_identical(L, ctx, oracle, c2, monkeypatch):
-    """One wave per edge, 16 lanes per edge and one lane per edge follow the same operation order: identical bits."""
+    """Two waves per edge (state_derivative_duo), one wave per edge, 16 lanes per edge and the two-lanes mappings follow
+    the same operation order: identical bits."""
     sc, osc = L.Scene(ctx, c2), oracle.OracleScene(c2)
     rng = np.random.default_rng(21)
     lo = np.array([c2.dyn.lower[i] for i in range(12)])
@@ -827,10 +830,10 @@ def test_propagate_mappings_are_bit_identical(L, ctx, oracle, c2, monkeypatch):
     a = a[osc.min_distance(a) > 0.01][:200]   # not a multiple of 64: the last wave is ragged
     b = rng.uniform(lo, hi, size=(a.shape[0], 12))
     res = {}
-    for lanes in ("64", "16", "1", "2"):
+    for lanes in ("64", "128", "16", "1", "2"):
         monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
         res[lanes] = sc.steer_position_toward(a, b, record=True)
-    for lanes in ("16", "1", "2"):
+    for lanes in ("128", "16", "1", "2"):
         assert np.array_equal(res[lanes][1], res["64"][1])
         assert np.array_equal(res[lanes][0], res["64"][0])
         assert np.array_equal(res[lanes][2], res["64"][2], equal_nan=True)
@@ -864,7 +867,7 @@ def test_every_robot_shape_is_tested_by_every_mapping(L, ctx, oracle, c2, monkey
                 sc, o2 = L.Scene(ctx, s2), oracle.OracleScene(s2)
                 rc, rout, rsteps, _ = o2.steer(x, t)
                 assert rsteps[0] == 0
-                for lanes in ("64", "16", "1", "2"):
+                for lanes in ("64", "128", "16", "1", "2"):
                     monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
                     assert sc.steer_position_toward(x, t)[1][0] == 0, (k, kind, order, lanes)
 
@@ -890,7 +893,7 @@ def test_c2_with_floor_plane_cylinders_and_a_spherical_tool(L, ctx, oracle, monk
     b = rng.uniform(lo, hi, size=(a.shape[0], 12))
     rc, rout, rsteps, _ = osc.steer(a, b)
     assert (rsteps == 0).sum() > 20 and (rsteps == 20).sum() > 200
-    for lanes in ("64", "16", "2"):
+    for lanes in ("64", "128", "16", "2"):
         monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
         out, steps, _ = sc.steer_position_toward(a, b)
         assert np.array_equal(steps, rsteps), lanes
@@ -973,11 +976,12 @@ def test_flexible_beam_dynamics_and_planner(L, ctx, oracle, monkeypatch):
     a = a[osc.min_distance(a) > 0.01][:60]
     b = rng.uniform(lo, hi, size=(a.shape[0], 12))
     res = {}
-    for lanes in ("64", "1", "2"):
+    for lanes in ("64", "128", "1", "2"):
         monkeypatch.setenv("RKH_LANES_PER_EDGE", lanes)
         res[lanes] = sc.steer_position_toward(a, b)
     assert np.array_equal(res["1"][0], res["64"][0]) and np.array_equal(res["1"][1], res["64"][1])
     assert np.array_equal(res["2"][0], res["64"][0]) and np.array_equal(res["2"][1], res["64"][1])
+    assert np.array_equal(res["128"][0], res["64"][0]) and np.array_equal(res["128"][1], res["64"][1])
     rc, rout, rsteps, _ = osc.steer(a, b)
     assert np.array_equal(res["64"][1], rsteps) and np.allclose(res["64"][0], rout, rtol=1e-9, atol=1e-10)
     monkeypatch.delenv("RKH_LANES_PER_EDGE")
@@ -1318,6 +1322,13 @@ def test_c4_dual_arm_dynamics_with_flexible_beam(L, ctx, oracle):
     out, steps, _ = sc.steer_position_toward(a, b)
     rc, rout, rsteps, _ = osc.steer(a, b)
     assert np.array_equal(steps, rsteps) and np.allclose(out, rout, rtol=1e-9, atol=1e-9)
+    # two waves per edge on the branching chain with the beam: the same bits as one wave per edge
+    os.environ["RKH_LANES_PER_EDGE"] = "128"
+    try:
+        out2, steps2, _ = sc.steer_position_toward(a, b)
+    finally:
+        del os.environ["RKH_LANES_PER_EDGE"]
+    assert np.array_equal(steps2, steps) and np.array_equal(out2, out)
     dyn_scn = copy.copy(scn)
     dyn_scn.start = np.zeros(24)
     dyn_scn.goal = np.zeros(24)

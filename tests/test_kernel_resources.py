@@ -39,8 +39,9 @@ def test_latency_kernels_of_scenes_without_vertex_sets_do_not_spill(res):
     """The one-wave-per-edge steer kernel (small rounds, single problems) and the quasi-static edge walk (graph planners)
     as instantiated for scenes without vertex-set shapes: no spilled registers, (next to) no private segment -- the
     support-map query's run-time-indexed simplex arrays are what needs one, and only the `true` instantiations carry it."""
-    d = res["rkh::propagate_kernel<6, 64, false>"]
-    assert d["vgpr_spill_count"] == 0 and d["private_segment_fixed_size"] <= 64, d
+    for k in ("rkh::propagate_kernel<6, 64, false, false>", "rkh::propagate_kernel<6, 64, false, true>"):  # one / two waves per edge
+        d = res[k]
+        assert d["vgpr_spill_count"] == 0 and d["private_segment_fixed_size"] <= 64, d
     for g in (32, 64):
         d = res[f"rkh::edge_points_kernel<6, false, {g}>"]
         assert d["vgpr_count"] <= 256 and d["vgpr_spill_count"] == 0 and d["private_segment_fixed_size"] == 0, d
