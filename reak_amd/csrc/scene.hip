@@ -734,7 +734,9 @@ rkh_status rkh_propagate(rkh_scene* scene, const rkh_dyn_space* space, const dou
   io.record = record ? drec.as<double>() : nullptr;
   io.record_stride = rec_stride;
   io.err_flag = scene->d_err;
-  int lanes = 64;  // RKH_LANES_PER_EDGE = 128 (two waves per edge) | 64 | 16 | 2 | 1 selects the kernel mapping (identical results)
+  // RKH_LANES_PER_EDGE = 128 (two waves per edge) | 64 | 16 | 2 | 1 selects the kernel mapping (identical results); by
+  // default a call of few edges -- the adaptors steer ONE edge per call -- takes the lowest-latency mapping
+  int lanes = (B <= 512) ? 128 : 64;
   if (const char* ev = getenv("RKH_LANES_PER_EDGE"))
     lanes = (atoi(ev) == 1) ? 1 : (atoi(ev) == 2 ? 2 : (atoi(ev) == 16 ? 16 : (atoi(ev) == 128 ? 128 : 64)));
   if ((lanes == 1 || lanes == 2) && !(n <= 7 && scene_fits_lane_kernel(scene->host, lanes))) lanes = 64;  // not a scene for that mapping
